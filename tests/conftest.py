@@ -1,0 +1,29 @@
+"""pytest configuration: markers + path setup.
+
+``-m "not gpu"``: oracle vs golden vectors, host logic, C-ABI symbol checks,
+gloo world_size-2 data-parallel tests -- no GPU required.
+``-m gpu``: HIP path vs the oracle through the C-ABI on a real MI355X.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name))
+    return load

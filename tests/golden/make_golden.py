@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run only in the build container (needs /root/reference and transformers):
+
+    python tests/golden/make_golden.py
+
+It imports ``tiny_audio`` from /root/reference and the ``transformers`` modules
+the reference calls (WhisperFeatureExtractor, GlmAsrEncoder, Qwen3ForCausalLM),
+loads the seeded numpy weights of ``oracle.weights`` into them, and stores the
+reference's outputs as small .npz fixtures.  Inputs and weights are NOT stored:
+they are regenerated from the same seeds by the tests (``oracle.weights``), so
+the fixtures are pure expected-output data.  Nothing here travels as code to
+the GPU box except this script itself; the reference never does.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+os.environ.setdefault("HF_HUB_OFFLINE", "1")
+
+from oracle import weights as OW  # noqa: E402
+from tests.golden.recipe import SMALL, logmel_waves, encoder_input, proj_input, lm_input, asr_tokens  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(True)
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {name}: " + ", ".join(f"{k}{tuple(np.asarray(v).shape)}" for k, v in arrays.items()),
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ----------------------------------------------------------------------------- 1. log-mel
+def gen_logmel():
+    from transformers import WhisperFeatureExtractor
+    fe = WhisperFeatureExtractor(feature_size=128)
+    fe.padding = False          # tiny_audio/asr_modeling.py:199-200
+    out = fe(logmel_waves(), sampling_rate=16000, padding="longest",
+             return_attention_mask=True, return_tensors="np")          # scripts/train.py:327-333
+    full = fe([OW.synthetic_wave(0)], sampling_rate=16000, padding="longest",
+              return_attention_mask=True, return_tensors="np")
+    odd = fe([OW.synthetic_wave(3, 16000 + 77)], sampling_rate=16000, padding="longest",
+             return_attention_mask=True, return_tensors="np")
+    save("logmel.npz", feats=out["input_features"].astype(np.float32),
+         mask=out["attention_mask"].astype(np.int32),
+         feats_10s=full["input_features"][0, :, ::4].astype(np.float32),   # every 4th frame
+         mask_10s_sum=np.int64(full["attention_mask"].sum()),
+         feats_odd=odd["input_features"].astype(np.float32),
+         mask_odd=odd["attention_mask"].astype(np.int32),
+         mel_filters=fe.mel_filters.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- 2. encoder
+def build_encoder(cfg, wnp):
+    from transformers.models.glmasr.configuration_glmasr import GlmAsrEncoderConfig
+    from transformers.models.glmasr.modeling_glmasr import GlmAsrEncoder
+    c = GlmAsrEncoderConfig(hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"],
+                            num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                            num_mel_bins=cfg["n_mels"])
+    c._attn_implementation = "eager"
+    m = GlmAsrEncoder(c).float().eval()
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in wnp.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all("rotary" in k or "inv_freq" in k for k in missing), missing
+    return m
+
+
+def gen_encoder():
+    cfg = SMALL["enc"]
+    m = build_encoder(cfg, OW.init_encoder(cfg, seed=0))
+    x = encoder_input()
+    with torch.no_grad():
+        out = m(input_features=t(x), output_hidden_states=True)
+    save("encoder_small.npz", last_hidden_state=out.last_hidden_state.numpy(),
+         conv_out=out.hidden_states[0].numpy(), layer0_out=out.hidden_states[1].numpy())
+
+
+# ----------------------------------------------------------------------------- 3. projectors
+def proj_cfg(ptype, **kw):
+    return SimpleNamespace(encoder_dim=SMALL["enc"]["hidden"], llm_dim=SMALL["lm"]["hidden"],
+                           projector_pool_stride=SMALL["k"], projector_hidden_dim=SMALL["proj_hidden"],
+                           projector_type=ptype, num_experts=4, num_experts_per_tok=2,
+                           router_aux_loss_coef=0.01, **kw)
+
+
+def gen_projectors():
+    from tiny_audio.projectors import MLPAudioProjector, MoEAudioProjector
+    x, dy = proj_input()
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    # MLP
+    m = MLPAudioProjector(proj_cfg("mlp")).float()
+    m.load_state_dict({k: t(v) for k, v in OW.init_mlp_projector(E, D, H).items()})
+    xt = t(x).requires_grad_(True)
+    y = m(xt)
+    (y * t(dy)).sum().backward()
+    save("projector_mlp.npz", y=y.detach().numpy(), dx=xt.grad.numpy(),
+         **{"g." + k: p.grad.numpy() for k, p in m.named_parameters()})
+    # MoE, eval mode (no jitter, aux = 0)
+    wm = OW.init_moe_projector(E, D, H)
+    m = MoEAudioProjector(proj_cfg("moe", router_jitter_noise=0.0)).float()
+    m.load_state_dict({k: t(v) for k, v in wm.items()})
+    m.eval()
+    y = m(t(x))
+    (y * t(dy)).sum().backward()
+    arrays = {"y_eval": y.detach().numpy(), "aux_eval": m.get_aux_loss().detach().numpy()}
+    arrays.update({"ge." + k: p.grad.numpy() for k, p in m.named_parameters()
+                   if k in ("norm.weight", "router.weight", "shared_expert.fc2.bias", "experts.2.fc1.bias")})
+    # MoE, train mode with jitter disabled: aux loss (balance + z) is live
+    m.zero_grad()
+    m.train()
+    y = m(t(x))
+    aux = m.get_aux_loss()
+    ((y * t(dy)).sum() + 3.0 * aux).backward()
+    arrays.update({"y_train": y.detach().numpy(), "aux_train": aux.detach().numpy()})
+    arrays.update({"gt." + k: p.grad.numpy() for k, p in m.named_parameters()})
+    save("projector_moe.npz", **arrays)
+
+
+# ----------------------------------------------------------------------------- 4. Qwen3
+def build_lm(cfg, wnp):
+    from transformers import Qwen3Config, Qwen3ForCausalLM
+    c = Qwen3Config(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], intermediate_size=cfg["ffn"],
+                    num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                    num_key_value_heads=cfg["kv_heads"], head_dim=cfg["head_dim"],
+                    rms_norm_eps=cfg["rms_eps"], tie_word_embeddings=True,
+                    rope_parameters={"rope_theta": cfg["rope_theta"], "rope_type": "default"},
+                    max_position_embeddings=4096, attention_bias=False, use_cache=False)
+    c._attn_implementation = "eager"
+    m = Qwen3ForCausalLM(c).float().eval()
+    sd = {k: t(v) for k, v in wnp.items()}
+    sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.tie_weights()
+    return m
+
+
+def gen_lm():
+    cfg = SMALL["lm"]
+    m = build_lm(cfg, OW.init_lm(cfg, seed=1))
+    m.requires_grad_(False)
+    x, att, lab = lm_input()
+    xt = t(x).requires_grad_(True)
+    out = m(inputs_embeds=xt, attention_mask=t(att), labels=t(lab))
+    out.loss.backward()
+    out2 = m(inputs_embeds=t(x), attention_mask=t(att), labels=t(lab), num_items_in_batch=77)
+    save("qwen3_small.npz", logits=out.logits.detach().numpy(), loss=out.loss.detach().numpy(),
+         dx=xt.grad.numpy(), loss_items77=out2.loss.detach().numpy())
+
+
+# ----------------------------------------------------------------------------- 5./6. whole model
+class _StubTokenizer:
+    pad_token = "<pad>"; eos_token = "<|im_end|>"; bos_token = None
+    pad_token_id = SMALL["pad_id"]; eos_token_id = SMALL["eos_id"]; bos_token_id = None
+    padding_side = "right"
+
+    def convert_tokens_to_ids(self, tok):
+        return {"<audio>": SMALL["audio_token_id"], "<|im_end|>": SMALL["eos_id"],
+                "<|endoftext|>": SMALL["pad_id"]}.get(tok)
+
+    def __len__(self):
+        return SMALL["lm"]["vocab"]
+
+
+def build_asr(ptype, pw, **cfg_kw):
+    """ASRModel with the four hub loaders patched."""
+    from transformers import WhisperFeatureExtractor
+    from tiny_audio.asr_config import ASRConfig
+    from tiny_audio import asr_modeling as AM
+    enc = build_encoder(SMALL["enc"], OW.init_encoder(SMALL["enc"], seed=0))
+    lm = build_lm(SMALL["lm"], OW.init_lm(SMALL["lm"], seed=1))
+
+    def _enc(cls, config, dtype):
+        enc.requires_grad_(False); enc.eval(); return enc
+
+    def _lm(cls, config, dtype):
+        lm.requires_grad_(False); lm.train(False); return lm
+
+    def _tok(self, config):
+        self.tokenizer = _StubTokenizer()
+        self.audio_token_id = SMALL["audio_token_id"]
+
+    def _fe(self, config):
+        fe = WhisperFeatureExtractor(feature_size=128); fe.padding = False; return fe
+
+    AM.ASRModel._load_audio_encoder = classmethod(_enc)
+    AM.ASRModel._load_language_model = classmethod(_lm)
+    AM.ASRModel._init_tokenizer = _tok
+    AM.ASRModel._create_feature_extractor = _fe
+    cfg = ASRConfig(audio_config=enc.config, text_config=lm.config, model_dtype="float32",
+                    attn_implementation="eager", projector_type=ptype,
+                    projector_hidden_dim=SMALL["proj_hidden"], projector_pool_stride=SMALL["k"],
+                    audio_token_dropout=0.0, **cfg_kw)
+    model = AM.ASRModel(cfg)
+    model.projector.load_state_dict({k: t(v) for k, v in pw.items()})
+    return model
+
+
+def asr_batch():
+    """Two clips of 2.0 s and 1.28 s -> mel via the reference FE; ragged audio-token counts."""
+    from transformers import WhisperFeatureExtractor
+    waves = [OW.synthetic_wave(0, 32000), OW.synthetic_wave(1, 20480)]
+    fe = WhisperFeatureExtractor(feature_size=128); fe.padding = False
+    a = fe(waves, sampling_rate=16000, padding="longest", return_attention_mask=True, return_tensors="np")
+    mel_len = a["attention_mask"].sum(-1)
+    enc_len = (mel_len + 2 - 2 - 1) // 1 + 1
+    enc_len = (enc_len + 2 - 2 - 1) // 2 + 1
+    counts = (enc_len - 4) // 4 + 1
+    ids, att, lab, counts = asr_tokens(counts.tolist())
+    return dict(input_ids=ids, attention_mask=att, labels=lab,
+                input_features=a["input_features"].astype(np.float32),
+                audio_attention_mask=a["attention_mask"].astype(np.int64), audio_token_counts=counts)
+
+
+def gen_asr():
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    batch = asr_batch()
+    tb = {k: t(v) for k, v in batch.items()}
+    arrays = {"counts": batch["audio_token_counts"], "input_features": batch["input_features"],
+              "audio_attention_mask": batch["audio_attention_mask"]}
+    for ptype, pw, kw in (("mlp", OW.init_mlp_projector(E, D, H), {}),
+                          ("moe", OW.init_moe_projector(E, D, H), {"router_jitter_noise": 0.0})):
+        model = build_asr(ptype, pw, **kw)
+        model.train()
+        out = model(**tb)
+        out.loss.backward()
+        arrays[f"{ptype}.loss"] = out.loss.detach().numpy()
+        arrays[f"{ptype}.logits"] = out.logits.detach().numpy()
+        keep = ("norm.weight", "router.weight", "shared_expert.fc1.bias", "experts.1.fc2.weight")
+        for k, p in model.projector.named_parameters():
+            if ptype == "mlp" or k in keep:
+                arrays[f"{ptype}.g.{k}"] = p.grad.numpy()
+        if ptype == "moe":
+            arrays["moe.aux"] = model.projector.get_aux_loss().detach().numpy()
+    save("asr_small.npz", **arrays)
+
+    # 3 optimizer steps: AdamW(lr 1e-3, wd 0) + clip_grad_norm_(1.0), HF-Trainer loss semantics with
+    # num_items_in_batch = number of label tokens (sum-CE / count == mean for one micro-batch).
+    model = build_asr("mlp", OW.init_mlp_projector(E, D, H))
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.projector.parameters()], lr=1e-3, weight_decay=0.0)
+    losses, gnorms = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        out = model(**tb)
+        out.loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.projector.parameters(), 1.0)
+        opt.step()
+        losses.append(float(out.loss)); gnorms.append(float(gn))
+    save("train3_small.npz", losses=np.array(losses, np.float32), gnorms=np.array(gnorms, np.float32),
+         **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters()})
+
+
+# ----------------------------------------------------------------------------- 7. known answers held by the reference tests
+def gen_known_answers():
+    from tiny_audio.asr_config import compute_encoder_output_length
+    from tiny_audio.asr_modeling import _gather_audio_embeds
+    rng = np.random.RandomState(5)
+    emb = rng.standard_normal((3, 6, 4)).astype(np.float32)
+    cases = {"a": [6, 2, 0], "b": [3, 8, 1]}      # zero counts; count > len (zero padding)
+    arrays = {"emb": emb}
+    for k, c in cases.items():
+        arrays["gather_" + k] = _gather_audio_embeds(t(emb), torch.tensor(c)).numpy()
+        arrays["counts_" + k] = np.array(c)
+    ls = np.array([1, 2, 3, 4, 100, 101, 999, 1000, 3000])
+    arrays["len_in"] = ls
+    arrays["len_conv"] = np.array([compute_encoder_output_length(int(x)) for x in ls])
+    save("known_answers.npz", **arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "asr", "known"]
+    for w in which:
+        {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm,
+         "asr": gen_asr, "known": gen_known_answers}[w]()

@@ -1,0 +1,60 @@
+"""Seeded input recipes shared by make_golden.py (reference side) and the tests
+(oracle / HIP side).  Pure numpy; imports nothing from the reference."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import weights as OW
+
+# ----------------------------------------------------------------------------- shared small config
+SMALL = dict(
+    enc=OW.enc_config(hidden=256, ffn=512, layers=2, heads=4),
+    lm=OW.lm_config(vocab=1024, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2, head_dim=128),
+    k=4, proj_hidden=128, audio_token_id=1023, pad_id=1000, eos_id=1001,
+)
+
+
+def logmel_waves():
+    """Three clips: white noise 2.5 s, a shorter noisy two-tone 1.7003 s (ragged, not a hop
+    multiple after padding is decided by the longest), a chirp 2.5 s."""
+    sr = 16000
+    w0 = OW.synthetic_wave(0, 40000)
+    n1 = 27205
+    tt = np.arange(n1) / sr
+    w1 = (0.3 * np.sin(2 * np.pi * 440 * tt) + 0.05 * np.sin(2 * np.pi * 3000 * tt)
+          + 0.01 * np.random.RandomState(7).standard_normal(n1)).astype(np.float32)
+    tt = np.arange(40000) / sr
+    w2 = (0.2 * np.sin(2 * np.pi * (200 + 1500 * tt) * tt)).astype(np.float32)
+    return [w0, w1, w2]
+
+
+def encoder_input(B=2, T=200, seed=11):
+    return (0.6 * np.random.RandomState(seed).standard_normal((B, 128, T))).astype(np.float32)
+
+
+def proj_input(B=2, S=50, seed=21):
+    E = SMALL["enc"]["hidden"]
+    x = np.random.RandomState(seed).standard_normal((B, S, E)).astype(np.float32)
+    N = (S - 4) // 4 + 1
+    dy = np.random.RandomState(seed + 1).standard_normal((B, N, SMALL["lm"]["hidden"])).astype(np.float32)
+    return x, dy
+
+
+def lm_input(B=2, L=48, seed=31):
+    cfg = SMALL["lm"]
+    rng = np.random.RandomState(seed)
+    x = (rng.standard_normal((B, L, cfg["hidden"])) / np.sqrt(cfg["hidden"])).astype(np.float32)
+    att = np.ones((B, L), dtype=np.int64)
+    att[1, 40:] = 0
+    lab = np.full((B, L), -100, dtype=np.int64)
+    lab[0, 30:48] = rng.randint(0, 1000, 18)
+    lab[1, 28:40] = rng.randint(0, 1000, 12)
+    return x, att, lab
+
+
+
+
+def asr_tokens(counts):
+    """Token stream for the whole-model fixtures (ragged audio-token counts)."""
+    return OW.synthetic_tokens(2, list(counts), SMALL["lm"]["vocab"], SMALL["audio_token_id"],
+                               SMALL["pad_id"], SMALL["eos_id"], n_text=20, n_suffix=8, ragged=True)

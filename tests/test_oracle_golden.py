@@ -1,0 +1,177 @@
+"""Pin the oracle (numpy restatement) against vectors produced by the reference
+itself (tests/golden/make_golden.py) and the known-answer tests the reference's
+own suite holds (tests/test_projectors.py, test_encode_audio_gather.py,
+test_asr_config.py in /root/reference/tests)."""
+import numpy as np
+import pytest
+
+from oracle import encoder as OE
+from oracle import features as OF
+from oracle import model as OM
+from oracle import projectors as OP
+from oracle import qwen3 as OQ
+from oracle import weights as OW
+from tests.golden import recipe as R
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ----------------------------------------------------------------------------- features
+def test_mel_filter_bank(golden):
+    g = golden("logmel.npz")
+    np.testing.assert_allclose(OF.mel_filter_bank().astype(np.float32), g["mel_filters"], rtol=1e-6, atol=1e-9)
+
+
+def test_logmel_ragged_batch(golden):
+    g = golden("logmel.npz")
+    wav, lens = OF.pad_batch(R.logmel_waves())
+    feats, mask = OF.log_mel(wav, lens)
+    assert feats.shape == g["feats"].shape
+    np.testing.assert_array_equal(mask, g["mask"])
+    # reference runs the chain in float32 (its own stated tolerance is 1e-5 on the log-spectrum;
+    # bins near the max-8 floor amplify): atol 2e-4 on the (x+4)/4 scale, mean error much lower.
+    d = np.abs(feats - g["feats"])
+    assert d.max() < 2e-4 and d.mean() < 2e-6, (d.max(), d.mean())
+
+
+def test_logmel_10s_and_odd_length(golden):
+    g = golden("logmel.npz")
+    wav, lens = OF.pad_batch([OW.synthetic_wave(0)])
+    feats, mask = OF.log_mel(wav, lens)
+    assert feats.shape == (1, 128, 1000) and int(mask.sum()) == int(g["mask_10s_sum"]) == 1000
+    assert np.abs(feats[0, :, ::4] - g["feats_10s"]).max() < 2e-4
+    wav, lens = OF.pad_batch([OW.synthetic_wave(3, 16000 + 77)])
+    feats, mask = OF.log_mel(wav, lens)
+    np.testing.assert_array_equal(mask, g["mask_odd"])
+    assert np.abs(feats - g["feats_odd"]).max() < 2e-4
+
+
+def test_length_formulas(golden):
+    g = golden("known_answers.npz")
+    np.testing.assert_array_equal(OF.conv_out_length(g["len_in"]), g["len_conv"])
+    # reference tests/test_asr_config.py:150-175, tests/test_projectors.py:65-69,152-156
+    assert OF.conv_out_length(100) == 50 and OF.conv_out_length(1) == 1 and OF.conv_out_length(3000) == 1500
+    assert [OF.mlp_out_length(x) for x in (100, 104, 4, 101)] == [25, 26, 1, 25]
+    # tests/test_asr_processing.py:212-233: 80 valid mel frames -> 10 <audio> tokens
+    m = np.zeros((1, 200), np.int32); m[0, :80] = 1
+    assert OF.audio_token_counts(m).tolist() == [10]
+
+
+def test_gather_audio_embeds(golden):
+    g = golden("known_answers.npz")
+    for k in ("a", "b"):
+        np.testing.assert_array_equal(OM.gather_audio_embeds(g["emb"], g["counts_" + k]), g["gather_" + k])
+
+
+# ----------------------------------------------------------------------------- encoder
+def test_encoder_small(golden):
+    g = golden("encoder_small.npz")
+    cfg = R.SMALL["enc"]
+    w = OW.init_encoder(cfg, seed=0)
+    out, hs = OE.encoder_forward(R.encoder_input(), w, cfg, return_all=True)
+    assert relerr(hs[0], g["conv_out"]) < 2e-5
+    assert relerr(hs[1], g["layer0_out"]) < 2e-5
+    assert relerr(out, g["last_hidden_state"]) < 5e-5
+
+
+# ----------------------------------------------------------------------------- projectors
+def test_mlp_projector_fwd_bwd(golden):
+    g = golden("projector_mlp.npz")
+    E, D, H = R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"], R.SMALL["proj_hidden"]
+    w = OW.init_mlp_projector(E, D, H)
+    x, dy = R.proj_input()
+    y, c = OP.mlp_forward(x, w)
+    assert relerr(y, g["y"]) < 1e-5
+    grads = OP.mlp_backward(dy, w, c, need_dx=True)
+    for k in w:
+        assert relerr(grads[k], g["g." + k]) < 5e-5, k
+    dx = np.zeros_like(x); n = grads["_dx_stacked"].shape[1]
+    dx[:, : n * 4] = grads["_dx_stacked"].reshape(2, n * 4, E)
+    assert relerr(dx, g["dx"]) < 5e-5
+
+
+def test_moe_projector_fwd_bwd(golden):
+    g = golden("projector_moe.npz")
+    E, D, H = R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"], R.SMALL["proj_hidden"]
+    w = OW.init_moe_projector(E, D, H)
+    x, dy = R.proj_input()
+    y, aux, c = OP.moe_forward(x, w, training=False)
+    assert relerr(y, g["y_eval"]) < 1e-5 and float(aux) == float(g["aux_eval"]) == 0.0
+    grads = OP.moe_backward(dy, w, c, d_aux=0.0)
+    for k in [k[3:] for k in g.files if k.startswith("ge.")]:
+        assert relerr(grads[k], g["ge." + k]) < 1e-4, k
+    y, aux, c = OP.moe_forward(x, w, training=True, jitter_noise=None)
+    assert relerr(y, g["y_train"]) < 1e-5
+    assert abs(float(aux) - float(g["aux_train"])) < 1e-6 * max(1.0, abs(float(g["aux_train"])))
+    grads = OP.moe_backward(dy, w, c, d_aux=3.0)
+    for k in w:
+        assert relerr(grads[k], g["gt." + k]) < 1e-4, k
+
+
+# ----------------------------------------------------------------------------- LM
+def test_qwen3_small_fwd_loss_dx(golden):
+    g = golden("qwen3_small.npz")
+    cfg = R.SMALL["lm"]
+    w = OW.init_lm(cfg, seed=1)
+    x, att, lab = R.lm_input()
+    logits, cache = OQ.lm_forward(x, att, w, cfg)
+    valid = att.astype(bool)
+    assert relerr(logits[valid], g["logits"][valid]) < 5e-5      # rows at padded positions are don't-care
+    loss, dlogits, n = OQ.causal_lm_loss(logits, lab)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    loss77, _, _ = OQ.causal_lm_loss(logits, lab, num_items_in_batch=77)
+    assert abs(float(loss77) - float(g["loss_items77"])) < 2e-5 * float(g["loss_items77"])
+    dx = OQ.lm_backward_dx(dlogits, w, cfg, cache)
+    assert relerr(dx, g["dx"]) < 1e-4
+
+
+# ----------------------------------------------------------------------------- whole model
+def _asr_setup(golden, ptype):
+    g = golden("asr_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    pw = OW.init_mlp_projector(E, D, H) if ptype == "mlp" else OW.init_moe_projector(E, D, H)
+    W = dict(encoder=OW.init_encoder(S["enc"], 0), lm=OW.init_lm(S["lm"], 1), projector=pw)
+    cfg = dict(enc=S["enc"], lm=S["lm"], projector_type=ptype, k=S["k"], audio_token_id=S["audio_token_id"])
+    ids, att, lab, counts = R.asr_tokens(g["counts"])
+    batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=g["input_features"],
+                 audio_token_counts=counts)
+    return g, W, cfg, batch
+
+
+@pytest.mark.parametrize("ptype", ["mlp", "moe"])
+def test_asr_forward_backward(golden, ptype):
+    g, W, cfg, batch = _asr_setup(golden, ptype)
+    # the token-count contract: features built by the oracle give the same counts as the reference's
+    np.testing.assert_array_equal(OF.audio_token_counts(g["audio_attention_mask"]), g["counts"])
+    out = OM.asr_forward(batch, W, cfg, training=True)
+    assert abs(float(out["loss"]) - float(g[ptype + ".loss"])) < 3e-5 * float(g[ptype + ".loss"])
+    valid = batch["attention_mask"].astype(bool)
+    assert relerr(out["logits"][valid], g[ptype + ".logits"][valid]) < 1e-4
+    grads, _ = OM.asr_backward(out, W, cfg)
+    for k in [k[len(ptype) + 3:] for k in g.files if k.startswith(ptype + ".g.")]:
+        assert relerr(grads[k], g[f"{ptype}.g.{k}"]) < 3e-4, k
+    if ptype == "moe":
+        assert abs(float(out["aux_loss"]) - float(g["moe.aux"])) < 1e-6
+
+
+def test_train_three_steps(golden):
+    """Config 1 plumbing + row a13: AdamW + clip semantics pinned on 3 steps."""
+    g3 = golden("train3_small.npz")
+    _, W, cfg, batch = _asr_setup(golden, "mlp")
+    state = {}
+    losses, gnorms = [], []
+    for _ in range(3):
+        l, gn = OM.train_step(batch, W, cfg, state, lr=1e-3, max_grad_norm=1.0, weight_decay=0.0)
+        losses.append(l); gnorms.append(gn)
+    np.testing.assert_allclose(losses, g3["losses"], rtol=2e-4)
+    np.testing.assert_allclose(gnorms, g3["gnorms"], rtol=2e-3)
+    assert losses[2] < losses[0]
+    # Adam normalises each element's step to O(lr): elements whose gradient is rounding noise may move
+    # differently, so bound the mean tightly and the max by 10% of the 3-step travel (3 * lr).
+    for k in W["projector"]:
+        d = np.abs(W["projector"][k] - g3["w." + k])
+        assert d.mean() < 1e-7 and d.max() < 3e-4, (k, d.mean(), d.max())
