@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- training-step audio-seconds/second of the tiny-audio projector-training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one full optimizer step of BASELINE.json configs[1]: B synthetic 10 s / 16 kHz clips per GPU ->
+GPU log-mel -> frozen GLM-ASR encoder (32 layers) -> MLP projector (H=D=1024) -> frozen Qwen3-0.6B (28 layers,
+L=192 tokens, 125 <audio> placeholders, 36 label tokens) -> shifted CE -> backward through LM (dX) and
+projector (dW) -> flat gradient all-reduce (RCCL, N>1) -> global-norm clip + AdamW.  Inputs (waveforms, token
+ids) are resident in HBM before the timed region; random-init weights at the true shapes (no checkpoints offline).
+
+The single JSON line carries `roofline` (dominant kernel = the MFMA GEMM, timed in situ with HIP events on
+its launch stream) and, at N=1, `cpu_baseline` (the numpy oracle timed on the host cores on one clip).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (2:1-sparse marketing figure is 5 PF)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=192)
+    ap.add_argument("--logits", choices=["labelled", "full"], default="labelled",
+                    help="'full' additionally materialises outputs.logits [B, L, V] (bf16) every step as the reference does; "
+                         "'labelled' computes the loss head only on label positions (identical loss and gradients)")
+    ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024):
+    """BASELINE.md section 3 (2*MAC, dense).  lm_head is counted at the positions actually computed."""
+    conv = 0.983 + 4.915
+    enc = 32 * (2 * 500 * 4 * 1280 ** 2 + 4 * 500 ** 2 * 1280 + 4 * 500 * 1280 * 5120) / 1e9
+    proj_f = 2 * 125 * (5120 * H + H * D) / 1e9
+    proj_b = 2 * 125 * (2 * 5120 * H + 2 * H * D) / 1e9 - 2 * 125 * 5120 * H / 1e9        # dW1, dW2, dA1 (no dX)
+    lm_body = 28 * (2 * L * (1024 * 2048 + 2 * 1024 * 1024 + 2048 * 1024 + 3 * 1024 * 3072) + 2 * L * L * 2048) / 1e9
+    head_rows = (L if full_logits else 0) + n_label
+    head = 2 * head_rows * 1024 * V / 1e9 + 2 * n_label * 1024 * V / 1e9                  # fwd (+ labelled dH backward)
+    return conv + enc + proj_f + proj_b + 2 * lm_body + head
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the ta355 hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)            # RCCL over xGMI
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.asr_processing import LogMelFeatureExtractor
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    from oracle import weights as OW
+
+    cfg = ASRConfig(projector_type="mlp", projector_hidden_dim=1024, audio_token_dropout=a.dropout)
+    model = ASRModel(cfg, device=dev, init="random", seed=0)      # identical frozen + projector weights on every rank
+    torch.manual_seed(0)
+    model.projector.linear_1.reset_parameters(); model.projector.linear_2.reset_parameters()
+    model.train()
+    fe = LogMelFeatureExtractor(128, dev)
+    trainer = ASRTrainer(model, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0,
+                                                  warmup_steps=500, max_steps=50000, lr_scheduler_type="polynomial",
+                                                  lr_scheduler_kwargs={"power": 0.5}))
+    B, L, V = a.batch, a.seq_len, cfg.text_config.vocab_size
+    # synthetic inputs of SURVEY.md 8(d), resident in HBM: wav = 0.1 * N(0,1), 160000 samples per clip
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    wav = 0.1 * torch.randn(B, 160000, device=dev, generator=g)
+    lens = torch.full((B,), 160000, device=dev, dtype=torch.int64)
+    ids, att, lab, counts = OW.synthetic_tokens(B, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    ids_d, att_d, lab_d = (torch.from_numpy(x).to(dev) for x in (ids, att, lab))
+    counts_d = torch.from_numpy(counts).to(dev)
+    from tiny_audio_amd import ops
+    rows, tg, n = ops.label_rows(lab_d)
+    n_lab = int(n.item())
+    label_meta = (rows, tg, n_lab)                                # the collator knows label positions on the host
+
+    def step():
+        feats, _mask = fe.extract(wav, lens)                      # K1 on the GPU, inside the timed step
+        batch = dict(input_ids=ids_d, input_features=feats, attention_mask=att_d, labels=lab_d,
+                     audio_token_counts=counts_d, label_meta=label_meta)
+        if a.logits == "full":
+            trainer.flat.zero_grad() if trainer._micro == 0 else None
+            out = model(**batch, num_items_in_batch=1.0, return_logits=True)
+            out.loss.backward()
+            with torch.no_grad():
+                trainer.flat.count_slot.add_(float(out.n_label_tokens)); trainer.flat.loss_slot.add_(out.loss.detach().reshape(1))
+            trainer.optimizer_step()
+        else:
+            trainer.training_step(batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = trainer.last_loss()
+    ms = dt / a.steps * 1e3
+    value = world * B * 10.0 * a.steps / dt
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        import ctypes as C
+        lib = _lib.lib()
+        lib.ta_profile_gemm(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        lib.ta_profile_gemm(0)
+        tms, tfl, nl = C.c_double(), C.c_double(), C.c_long()
+        lib.ta_profile_gemm_collect(C.byref(tms), C.byref(tfl), C.byref(nl))
+        achieved = tfl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
+        roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogue variants)", "bound": "mfma",
+                    "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": nl.value // 2, "avg_launch_us": round(tms.value * 1e3 / max(nl.value, 1), 2),
+                    "gemm_ms_per_step": round(tms.value / 2, 3),
+                    "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3)}
+
+    cpu = None
+    if not a.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(model, cfg, L)
+
+    if rank == 0:
+        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full")
+        rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
+               "config": {"workload": "configs[1]: MLP projector (H=D=1024) bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
+                                      "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,
+                          "clips_per_gpu": B, "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
+                          "logits": a.logits, "audio_token_dropout": a.dropout,
+                          "algorithmic_gflop_per_clip": round(gf, 1),
+                          "step_tflops": round(gf * world * B / (ms * 1e-3) / 1e3, 1)},
+               "final_loss": round(loss, 4), "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, cfg, L):
+    """The numpy oracle (a 'port': the reference's Python cannot travel) timed on the host cores on a bounded
+    sample: ONE 10 s clip, one full-depth training step (forward + backward), fp32, same weights as the GPU model."""
+    from oracle import features as OF
+    from oracle import model as OM
+    from oracle import weights as OW
+    enc, lm = cfg.audio_config, cfg.text_config
+    ecfg = OW.enc_config(enc.hidden_size, enc.intermediate_size, enc.num_hidden_layers, enc.num_attention_heads)
+    lcfg = OW.lm_config(lm.vocab_size, lm.hidden_size, lm.intermediate_size, lm.num_hidden_layers, lm.num_attention_heads,
+                        lm.num_key_value_heads, lm.head_dim, lm.rms_norm_eps, lm.rope_theta)
+    W = dict(encoder=model.audio_tower.export_state_dict_hf(), lm=model.language_model.export_state_dict_hf(),
+             projector={k: v.detach().float().cpu().numpy() for k, v in model.projector.state_dict().items()})
+    ocfg = dict(enc=ecfg, lm=lcfg, projector_type="mlp", k=4, audio_token_id=cfg.audio_token_id)
+    ids, att, lab, counts = OW.synthetic_tokens(1, 125, lm.vocab_size, cfg.audio_token_id, cfg.pad_token_id,
+                                                cfg.eos_token_id, L=L)
+    t0 = time.perf_counter()
+    wav, lens = OF.pad_batch([OW.synthetic_wave(0)])
+    feats, _ = OF.log_mel(wav, lens)
+    batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
+    out = OM.asr_forward(batch, W, ocfg, training=True)
+    OM.asr_backward(out, W, ocfg)
+    dt = time.perf_counter() - t0
+    return {"value": round(10.0 / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 clip x 1 full-depth training step (log-mel + fwd + bwd, fp32 numpy/OpenBLAS oracle), "
+                      f"{dt:.1f} s of CPU work, loss {float(out['loss']):.4f}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/* ta355.h -- C ABI of libta355.so: the MI355X-native (gfx950) projector-training hot path of
+ * alexkroman/tiny-audio.  Plain pointers + sizes + a hipStream_t; no torch types; every function
+ * returns an int status (0 = ok, 1 = bad argument, 2 = launch failure) and never allocates device
+ * memory: callers pass workspaces sized by the matching *_workspace_bytes() query.  All pointers are
+ * DEVICE pointers unless a comment says "host".  `long` is 64-bit (LP64).  bf16 buffers are passed as
+ * `void*` (raw bfloat16 bits).
+ *
+ * The reference has no FFI of its own (it is 100 % Python on top of torch/transformers); the seams this
+ * library sits behind are the reference's nn.Module boundaries.  Each entry point
+ * names the reference interface it replaces; INTEGRATION.md shows the ctypes stubs a maintainer adds.
+ */
+#ifndef TA355_H
+#define TA355_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define TA_OK 0
+#define TA_ERR_ARG 1
+#define TA_ERR_LAUNCH 2
+
+int ta_version(void); /* ABI version, currently 1 */
+
+/* ============================================================================================
+ * Composite ops (what a binding would call)
+ * ============================================================================================ */
+
+/* ---- log-mel features: replaces WhisperFeatureExtractor.__call__ as used at
+ *      scripts/train.py:327-333 and tiny_audio/asr_processing.py:74-80
+ *      (TF:models/whisper/feature_extraction_whisper.py:135-168,330-339).
+ * wav [B, Ls] f32 zero-padded to the longest clip, lens [B] true sample counts.
+ * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once.
+ * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.  clip_max_ws: int[B]. */
+int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
+                  const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st);
+
+/* ---- frozen GLM-ASR encoder: replaces model.audio_tower(input_features=...).last_hidden_state
+ *      (tiny_audio/asr_modeling.py:448-450; TF:models/glmasr/modeling_glmasr.py:313-327). */
+typedef struct {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b; /* [H] */
+  const void* wqkv;   /* bf16 [3H, H] rows = q | k | v */
+  const float* bqkv;  /* [3H] (k part zero: k_proj has no bias) */
+  const void* wo;     /* bf16 [H, H] */
+  const float* bo;
+  const void* w1;     /* bf16 [F, H] */
+  const float* b1;
+  const void* w2;     /* bf16 [H, F] */
+  const float* b2;
+} ta_enc_layer;
+
+typedef struct {
+  int hidden, ffn, n_layers, heads, n_mels, max_pos;
+  float ln_eps;
+  const void* conv1_w;  /* bf16 [H, 3*n_mels], column = tap*n_mels + cin */
+  const float* conv1_b;
+  const void* conv2_w;  /* bf16 [H, 3*H], column = tap*H + cin */
+  const float* conv2_b;
+  const float *norm_w, *norm_b;
+  const float *rope_cos, *rope_sin; /* [max_pos, 16] (partial rotary: 32 of 64 dims) */
+  const ta_enc_layer* layers;       /* host array [n_layers] */
+} ta_encoder_weights;
+
+long ta_encoder_workspace_bytes(const ta_encoder_weights* w, int B, int T);
+/* feats [B, n_mels, T] f32 -> out_bf16 [B*S, H] (and/or out_f32), S = (T-1)/2+1.
+ * frame_keep [B*S] f32 or NULL: the train-time whole-frame dropout mask of
+ * ASRModel._maybe_drop_audio_tokens (tiny_audio/asr_modeling.py:458-479), fused into the final LayerNorm. */
+int ta_encoder_forward(const ta_encoder_weights* w, const float* feats, int B, int T, const float* frame_keep,
+                       void* out_bf16, float* out_f32, void* ws, long ws_bytes, hipStream_t st);
+
+/* ---- MLP projector: replaces MLPAudioProjector.forward + its autograd backward
+ *      (tiny_audio/projectors.py:57-71,79-87). x bf16 [B, S, E] -> y f32 [B*N, D], N = (S-k)/k+1. */
+typedef struct {
+  int enc_dim, k, hidden, llm_dim;
+  float eps;
+  const void* w1;   /* bf16 [Hd, k*E]   (cast of linear_1.weight) */
+  const void* w2;   /* bf16 [D, Hd]     (cast of linear_2.weight) */
+  const void* w2_t; /* bf16 [Hd, D]     (transposed cast, for dA = dH2 W2) */
+  const float* g1;  /* norm.weight   [Hd] */
+  const float* g2;  /* norm_2.weight [D]  */
+} ta_mlp_weights;
+
+long ta_mlp_tape_bytes(const ta_mlp_weights* w, int B, int S);
+long ta_mlp_bwd_workspace_bytes(const ta_mlp_weights* w, int B, int S);
+int ta_mlp_projector_forward(const ta_mlp_weights* w, const void* x_bf16, int B, int S, float* y, void* tape,
+                             hipStream_t st);
+/* dy f32 [B*N, D] -> dW1 [Hd,kE], dg1 [Hd], dW2 [D,Hd], dg2 [D] (f32, overwritten). */
+int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x_bf16, int B, int S, const float* dy,
+                              const void* tape, float* dW1, float* dg1, float* dW2, float* dg2, void* ws,
+                              long ws_bytes, hipStream_t st);
+
+/* ---- frozen Qwen3 LM + shifted CE: replaces model.language_model(inputs_embeds=, attention_mask=, labels=)
+ *      together with the embed/masked_scatter glue of ASRModel.forward
+ *      (tiny_audio/asr_modeling.py:497-526; TF:models/qwen3/modeling_qwen3.py:367-508; TF:loss/loss_utils.py:33-71)
+ *      and its activation-gradient backward (encoder + LM frozen: dX only). */
+typedef struct {
+  const float* ln_in_w;             /* [D] */
+  const void *wqkv, *wqkv_t;        /* bf16 [NQKV, D], [D, NQKV]; rows = q | k | v */
+  const float *qn_w, *kn_w;         /* [head_dim] */
+  const void *wo, *wo_t;            /* bf16 [D, Hq*hd], [Hq*hd, D] */
+  const float* ln_post_w;           /* [D] */
+  const void *wgu, *wgu_t;          /* bf16 [2F, D] rows = gate | up, [D, 2F] */
+  const void *wd, *wd_t;            /* bf16 [D, F], [F, D] */
+} ta_lm_layer;
+
+typedef struct {
+  int vocab, vocab_pad, hidden, ffn, n_layers, heads, kv_heads, head_dim, max_pos;
+  float eps;
+  const float* embed_f32;   /* [vocab, D]   input embedding (fp32 master, as the reference looks it up) */
+  const void* embed_bf16;   /* [vocab_pad, D] tied lm_head, rows >= vocab zero */
+  const void* embed_t_bf16; /* [D, vocab_pad] */
+  const float* norm_w;
+  const float *rope_cos, *rope_sin; /* [max_pos, head_dim/2] */
+  const ta_lm_layer* layers;        /* host array */
+} ta_lm_weights;
+
+long ta_lm_tape_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows);
+long ta_lm_workspace_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows);
+/* ids [B,L] i64; src_row [B*L] from ta_audio_index (or NULL = text only); audio f32 [*, D] projector output;
+ * kmask [B,L] int32 attention mask (NULL = all ones); pos [B*L] int32 (NULL = arange(L));
+ * label_rows/label_targets: the n_label_rows positions whose shifted label != -100 (ta_label_rows);
+ * loss_scale = 1 / num_items_in_batch.  loss: device scalar, ACCUMULATED into (zero it first).
+ * logits_out: optional [B*L, vocab_pad] bf16 full logits (the reference's outputs.logits), else NULL. */
+int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio,
+                       const int* kmask, const int* pos, int B, int L, const int* label_rows,
+                       const long* label_targets, int n_label_rows, float loss_scale, float* loss,
+                       float* nll_rows, void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st);
+/* d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written); d_embeds optional [B*L, D]. */
+int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
+                   const int* label_rows, int n_label_rows, float* d_audio, long n_audio_rows, float* d_embeds,
+                   const void* tape, void* ws, long ws_bytes, hipStream_t st);
+
+/* ============================================================================================
+ * Primitive kernels (exported for the parity tests; also what the composites are built from)
+ * ============================================================================================ */
+
+/* C = epilogue(A[M,K] x W[N,K]^T).  A/C rows are mapped  row -> (row / rpb) * bs + (row % rpb) * ld
+ * (rpb <= 0 means "no batching").  act: 0 none, 1 erf-GELU.  residual: f32, C's row map.
+ * splits > 1: split-K through splitk_ws (f32 [splits, M, N]); then no bias/act, plain C layout. */
+int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
+                    long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
+                    int out_bf16, int splits, float* splitk_ws, hipStream_t st);
+long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
+/* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
+ * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */
+int ta_profile_gemm(int enable);
+int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launches);
+
+int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
+                     const float* rowscale, int M, int H, float eps, hipStream_t st);
+int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd, int M, int H,
+                   float eps, int act_gelu, hipStream_t st);
+int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd, const float* w, const float* dres,
+                   float* dx_f32, void* dx_bf16, float* dw_accum, int M, int H, int act_gelu, hipStream_t st);
+
+int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
+                     int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, hipStream_t st);
+int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V, const void* dO,
+                     long dO_stride, const void* dOT, const float* LSE, const float* Delta, const int* kmask,
+                     void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal,
+                     float scale, hipStream_t st);
+int ta_enc_qkv_post(const void* qkv, const float* cosT, const float* sinT, void* Q, void* K, void* VT, int B, int H,
+                    int S, int Sp, hipStream_t st);
+int ta_lm_qkv_post_fwd(const void* qkv0, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
+                       const int* pos, void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* rq, float* rk,
+                       int B, int Hq, int Hkv, int L, int Lp, float eps, hipStream_t st);
+int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv0, const float* rq,
+                       const float* rk, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
+                       const int* pos, void* dqkv, int B, int Hq, int Hkv, int L, hipStream_t st);
+int ta_attn_bwd_prep(const void* dO, const void* O, float* Delta, void* dOT, int B, int Hq, int L, int Lp,
+                     hipStream_t st);
+
+int ta_swiglu_fwd(const void* gu, void* act, long M, int F, hipStream_t st);
+int ta_swiglu_bwd(const void* dact, const void* gu, void* dgu, long M, int F, hipStream_t st);
+int ta_cast_f32_bf16(const float* x, void* y, long n, hipStream_t st);
+int ta_transpose_to_bf16(const void* in, int in_is_f32, long ld_in, long in_bs, int in_rpb, void* out, long ld_out,
+                         int R, int C, hipStream_t st);
+int ta_feats_to_time_major(const float* feats, void* out, int B, int C, int T, hipStream_t st);
+int ta_zero_pad_rows(void* buf, int B, int T, int C, hipStream_t st);
+
+/* <audio> placeholder bookkeeping: _gather_audio_embeds + masked_scatter
+ * (tiny_audio/asr_modeling.py:27-44,511-515). */
+int ta_audio_index(const long* ids, const long* counts, int* src_row, int B, int L, int N, long audio_id,
+                   hipStream_t st);
+int ta_embed_scatter(const long* ids, const int* src_row, const float* emb, const float* audio, float* x0,
+                     void* x0_bf16, int n_rows, int D, long vocab, hipStream_t st);
+int ta_audio_grad_gather(const int* src_row, const float* dx0, float* d_audio, int n_rows, int D, hipStream_t st);
+int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st);
+int ta_scatter_rows_f32(const float* in, const int* idx, float* out, int n, int D, hipStream_t st);
+int ta_bernoulli_keep(float* keep, long n, float keep_prob, unsigned long long seed, hipStream_t st);
+
+int ta_cross_entropy(const void* logits, int logits_bf16, long ldl, const int* rows, const long* targets, int n, int V,
+                     float scale, float* nll, float* loss_accum, void* dlogits_bf16, long ldd, hipStream_t st);
+int ta_label_rows(const long* labels, int B, int L, int* rows, long* targets, int* n_out, hipStream_t st);
+
+/* optimizer: clip_grad_norm_(max_norm) + AdamW on fp32 masters (configs/training/production.yaml:5-9) */
+int ta_grad_sqnorm(const float* g, long n, float* accum, hipStream_t st);
+int ta_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, const float* sqnorm, float max_norm, float grad_scale,
+                  const float* denom, hipStream_t st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TA355_H */

@@ -1,0 +1,103 @@
+"""-m "not gpu": exercise the Python plumbing of the MI355X path end to end on a GPU-less box.
+
+``_lib.DRY_RUN`` swaps every kernel-launching C entry point for a stub that only marshals its arguments through
+the real ctypes prototypes (arity / type / pointer conversion) -- so a wrong argument order, a missing tensor or
+a shape bug in the host code fails here instead of on the GPU box.  No numerics are checked (nothing is computed);
+the numerics live in the -m gpu tests.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as OW
+from tiny_audio_amd import _lib
+
+
+@pytest.fixture()
+def dry():
+    _lib.DRY_RUN = True
+    try:
+        yield _lib.lib()
+    finally:
+        _lib.DRY_RUN = False
+        _lib._LIB = None
+
+
+def test_full_training_step_plumbing(dry):
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.asr_processing import ASRProcessor, LogMelFeatureExtractor
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=2, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, audio_token_dropout=0.1)
+    m = ASRModel(cfg, device="cpu", init="none")
+    m.audio_tower.load_state_dict_hf(OW.init_encoder(enc, 0))
+    m.language_model.load_state_dict_hf(OW.init_lm(lm, 1))
+    m.load_state_dict({"projector." + k: torch.from_numpy(v) for k, v in OW.init_mlp_projector(256, 256, 128).items()})
+    assert set(m.state_dict()) == {"projector.linear_1.weight", "projector.norm.weight", "projector.linear_2.weight",
+                                   "projector.norm_2.weight"}                     # asr_modeling.py:398-422
+    fe = LogMelFeatureExtractor(128, "cpu")
+    f = fe([OW.synthetic_wave(0, 16000), OW.synthetic_wave(1, 12000)], sampling_rate=16000)
+    assert f["input_features"].shape == (2, 128, 100) and f["attention_mask"].shape == (2, 100)
+    proc = ASRProcessor(fe, m.projector)
+    assert proc.audio_token_counts(torch.ones(2, 100, dtype=torch.int32)).tolist() == [12, 12]
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 9], 1000, 999, 990, 991, n_text=10, n_suffix=4, ragged=True)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=f["input_features"], attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts))
+    m.train()
+    out = m(**batch, label_meta=(torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 19))
+    assert out.logits.shape == (2, ids.shape[1], 1000) and out.loss.shape == ()
+    out.loss.backward()
+    for p in m.projector.parameters():
+        assert p.grad is not None and p.grad.shape == p.shape
+    tr = ASRTrainer(m, TrainingArguments(gradient_accumulation_steps=2))
+    lm_meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 19)
+    tr.training_step({**batch, "label_meta": lm_meta})
+    assert tr.global_step == 0
+    tr.training_step({**batch, "label_meta": lm_meta})
+    assert tr.global_step == 1 and m.projector._pack_versions is None
+    names = set(dry.calls)
+    for must in ("ta_logmel_f32", "ta_encoder_forward", "ta_mlp_projector_forward", "ta_mlp_projector_backward",
+                 "ta_audio_index", "ta_lm_forward_loss", "ta_lm_backward", "ta_bernoulli_keep", "ta_grad_sqnorm", "ta_adamw_step"):
+        assert must in names, must
+    # random-init path + weight export round trip (bench.py's cpu_baseline leg)
+    m2 = ASRModel(cfg, device="cpu", init="random", seed=3)
+    sd = m2.audio_tower.export_state_dict_hf()
+    assert set(sd) == set(OW.init_encoder(enc, 0)) and sd["conv2.weight"].shape == (256, 256, 3)
+    sl = m2.language_model.export_state_dict_hf()
+    assert set(sl) == set(OW.init_lm(lm, 1)) and sl["model.layers.1.mlp.up_proj.weight"].shape == (512, 256)
+    enc2 = type(m2.audio_tower)(cfg.audio_config, "cpu").load_state_dict_hf(OW.init_encoder(enc, 0))
+    rt = enc2.export_state_dict_hf()
+    w0 = OW.init_encoder(enc, 0)
+    for k in ("conv1.weight", "layers.1.self_attn.v_proj.bias", "layers.0.mlp.fc2.weight"):
+        np.testing.assert_allclose(rt[k], w0[k], atol=2e-2 * np.abs(w0[k]).max())      # bf16 storage round trip
+
+
+def test_primitive_wrappers_marshal(dry):
+    from tiny_audio_amd import ops
+    bf, f32 = torch.bfloat16, torch.float32
+    A, W = torch.zeros(70, 128, dtype=bf), torch.zeros(256, 128, dtype=bf)
+    assert ops.gemm_nt(A, W, bias=torch.zeros(256), residual=torch.zeros(70, 256), act=1, out_dtype=f32).shape == (70, 256)
+    assert ops.gemm_nt(A, W, out_dtype=f32, splits=2).dtype == f32
+    x = torch.zeros(10, 256)
+    ops.layernorm(x, torch.ones(256), torch.zeros(256), out_f32=True)
+    yb, yf, r = ops.rmsnorm_fwd(x, torch.ones(256), act_gelu=True, out_f32=True)
+    ops.rmsnorm_bwd(x, x, r, torch.ones(256), dres=x, want_dw=True)
+    B, Hq, Hkv, L = 2, 4, 2, 70
+    qkv0 = torch.zeros(B * L, (Hq + 2 * Hkv) * 128, dtype=bf)
+    cs = torch.zeros(256, 64)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(qkv0, torch.ones(128), torch.ones(128), cs, cs, B, Hq, Hkv, L)
+    O, lse = ops.attention_fwd(Q, K, VT, L, True, 0.1, kmask=torch.ones(B, L, dtype=torch.int32))
+    delta, dOT = ops.attn_bwd_prep(O, O, B, Hq, L)
+    dQ, dK, dV = ops.attention_bwd(Q, QT, K, KT, V, O, dOT, lse, delta, L, True, 0.1)
+    ops.lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, torch.ones(128), torch.ones(128), cs, cs, B, Hq, Hkv, L)
+    ops.enc_qkv_post(torch.zeros(B * 77, 3 * 4 * 64, dtype=bf), torch.zeros(128, 16), torch.zeros(128, 16), B, 4, 77)
+    gu = torch.zeros(9, 64, dtype=bf)
+    ops.swiglu_bwd(ops.swiglu_fwd(gu, 32), gu, 32)
+    ops.transpose_to_bf16(ops.cast_bf16(torch.zeros(8, 12)), ld_out=64)
+    ops.audio_index(torch.zeros(2, 8, dtype=torch.int64), torch.zeros(2, dtype=torch.int64), 3, 5)
+    ops.label_rows(torch.zeros(2, 8, dtype=torch.int64))
+    ops.cross_entropy(torch.zeros(4, 128), torch.zeros(4, dtype=torch.int64), 100, 0.25)
+    ops.bernoulli_keep(10, 0.9, 1, "cpu")
+    ops.adamw_step(torch.zeros(8), torch.zeros(8), torch.zeros(8), torch.zeros(8), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1,
+                   sqnorm=torch.zeros(1), max_norm=1.0, denom=torch.ones(1))

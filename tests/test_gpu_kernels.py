@@ -1,0 +1,382 @@
+"""-m gpu: every primitive kernel of libta355.so, called through the C ABI, against a plain fp32
+reference of the same op (torch on the same device, fp32 math).  Tolerances are stated per test:
+bf16 operands (8 mantissa bits) with fp32 accumulation => relative error ~ 2^-8 on outputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tiny_audio_amd import ops
+
+DEV = "cuda"
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=F32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def cos_sim(a, b):
+    a, b = a.float().flatten(), b.float().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 1280, 1280), (77, 384, 3840), (2048, 1024, 4096)])
+@pytest.mark.parametrize("out_bf16", [True, False])
+def test_gemm_plain(M, N, K, out_bf16):
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    C = ops.gemm_nt(A, W, out_dtype=BF16 if out_bf16 else F32)
+    ref = A.float() @ W.float().T                      # asymmetric operands: a transposed store would not pass
+    assert relerr(C, ref) < (1.5e-2 if out_bf16 else 2e-3)
+
+
+def test_gemm_epilogues():
+    M, N, K = 515, 640, 256
+    A, W = rnd(M, K, seed=3, dtype=BF16), rnd(N, K, seed=4, scale=1 / math.sqrt(K), dtype=BF16)
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    ref = A.float() @ W.float().T + bias
+    assert relerr(ops.gemm_nt(A, W, bias=bias, out_dtype=F32), ref) < 2e-3
+    assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=F32), torch.nn.functional.gelu(ref)) < 2e-3
+    assert relerr(ops.gemm_nt(A, W, bias=bias, residual=res, out_dtype=F32), ref + res) < 2e-3
+    inplace = res.clone()
+    ops.gemm_nt(A, W, bias=bias, residual=inplace, out=inplace)
+    assert relerr(inplace, ref + res) < 2e-3
+    assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=BF16), torch.nn.functional.gelu(ref)) < 1.5e-2
+
+
+@pytest.mark.parametrize("splits", [2, 5, 16])
+def test_gemm_splitk(splits):
+    M, N, K = 200, 256, 64 * 37
+    A, W = rnd(M, K, seed=7, dtype=BF16), rnd(N, K, seed=8, scale=1 / math.sqrt(K), dtype=BF16)
+    ref = A.float() @ W.float().T
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32, splits=splits), ref) < 2e-3
+    add = rnd(M, N, seed=9)
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32, splits=splits, residual=add), ref + add) < 2e-3
+
+
+def test_gemm_conv_rowmap():
+    """Conv1d(k=3, pad=1, stride s) as a row-mapped GEMM over a zero-padded time-major buffer."""
+    B, T, Cin, Cout = 3, 37, 128, 256
+    x = rnd(B, Cin, T, seed=10)
+    w = rnd(Cout, Cin, 3, seed=11, scale=1 / math.sqrt(3 * Cin))
+    bias = rnd(Cout, seed=12)
+    xp = torch.zeros(B, T + 2, Cin, device=DEV, dtype=BF16)
+    xp[:, 1:T + 1] = x.transpose(1, 2).to(BF16)
+    wp = w.permute(0, 2, 1).reshape(Cout, 3 * Cin).to(BF16).contiguous()
+    for stride in (1, 2):
+        S = (T + 2 - 3) // stride + 1
+        out = ops.gemm_nt(xp, wp, M=B * S, N=Cout, K=3 * Cin, bias=bias, out_dtype=F32,
+                          a_map=(stride * Cin, S, (T + 2) * Cin))
+        ref = torch.nn.functional.conv1d(xp[:, 1:T + 1].float().transpose(1, 2), wp.float().reshape(Cout, 3, Cin).permute(0, 2, 1),
+                                         bias, stride=stride, padding=1)
+        assert relerr(out.reshape(B, S, Cout), ref.transpose(1, 2)) < 2e-3
+    # mapped output: rows land at offset +1 row inside a padded [B, T+2, Cout] buffer, pad rows untouched
+    outp = torch.full((B, T + 2, Cout), 7.0, device=DEV, dtype=BF16)
+    ops.gemm_nt(xp, wp, M=B * T, N=Cout, K=3 * Cin, bias=bias, out=outp, a_map=(Cin, T, (T + 2) * Cin),
+                c_map=(Cout, T, (T + 2) * Cout, Cout))
+    ref = torch.nn.functional.conv1d(xp[:, 1:T + 1].float().transpose(1, 2), wp.float().reshape(Cout, 3, Cin).permute(0, 2, 1),
+                                     bias, stride=1, padding=1).transpose(1, 2)
+    assert relerr(outp[:, 1:T + 1], ref) < 1.5e-2
+    assert float(outp[:, 0].float().min()) == 7.0 and float(outp[:, T + 1].float().max()) == 7.0
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("H", [256, 1280, 5120])
+def test_layernorm(H):
+    M = 333
+    x, w, b = rnd(M, H, seed=1, scale=3.0) + 0.5, 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    rs = (torch.arange(M, device=DEV) % 3 != 0).float()
+    yb, yf = ops.layernorm(x, w, b, 1e-5, rowscale=rs, out_bf16=True, out_f32=True)
+    ref = torch.nn.functional.layer_norm(x, (H,), w, b, 1e-5) * rs[:, None]
+    assert relerr(yf, ref) < 1e-5
+    assert relerr(yb, ref) < 8e-3
+
+
+@pytest.mark.parametrize("H,gelu", [(1024, False), (1024, True), (2048, False), (5120, False), (128, True)])
+def test_rmsnorm_fwd_bwd(H, gelu):
+    M = 301
+    x = rnd(M, H, seed=1, scale=2.0).requires_grad_(True)
+    w = (1 + 0.1 * rnd(H, seed=2)).requires_grad_(True)
+    dy = rnd(M, H, seed=3)
+    dres = rnd(M, H, seed=4)
+    r = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
+    y = w * (x * r)
+    if gelu:
+        y = torch.nn.functional.gelu(y)
+    y.backward(dy)
+    yb, yf, rstd = ops.rmsnorm_fwd(x.detach(), w.detach(), 1e-6, act_gelu=gelu, out_bf16=True, out_f32=True)
+    assert relerr(yf, y) < 1e-5 and relerr(yb, y) < 8e-3 and relerr(rstd, r.flatten()) < 1e-5
+    dx, dxb, dw = ops.rmsnorm_bwd(dy, x.detach(), rstd, w.detach(), dres=dres, act_gelu=gelu, want_dw=True)
+    assert relerr(dx, x.grad + dres) < 2e-5
+    assert relerr(dxb, x.grad + dres) < 8e-3
+    assert relerr(dw, w.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, causal, scale, kmask=None):
+    """q [B,Hq,L,d], k/v [B,Hkv,L,d] fp32 (autograd-capable)."""
+    B, Hq, L, d = q.shape
+    g = Hq // k.shape[1]
+    kr, vr = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+    s = (q @ kr.transpose(-1, -2)) * scale
+    allow = torch.ones(B, 1, L, L, dtype=torch.bool, device=q.device)
+    if causal:
+        allow = allow & torch.tril(torch.ones(L, L, dtype=torch.bool, device=q.device))
+    if kmask is not None:
+        allow = allow & (kmask[:, None, None, :] != 0)
+    s = s.masked_fill(~allow, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return p @ vr, torch.logsumexp(s, -1)
+
+
+def to_T(x, Lp):
+    B, H, L, d = x.shape
+    out = torch.zeros(B, H, d, Lp, device=x.device, dtype=x.dtype)
+    out[..., :L] = x.transpose(-1, -2)
+    return out.contiguous()
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,L,causal,masked", [(64, 4, 4, 500, False, False), (64, 3, 3, 64, False, False),
+                                                       (128, 4, 2, 192, True, True), (128, 2, 1, 70, True, False),
+                                                       (128, 4, 2, 257, True, True)])
+def test_attention_fwd(hd, Hq, Hkv, L, causal, masked):
+    B = 2
+    q, k, v = rnd(B, Hq, L, hd, seed=1), rnd(B, Hkv, L, hd, seed=2), rnd(B, Hkv, L, hd, seed=3)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, L, dtype=torch.int32, device=DEV)
+        kmask[1, L - 37:] = 0
+    qb, kb, vb = q.to(BF16), k.to(BF16), v.to(BF16)
+    scale = hd ** -0.5
+    O, lse = ops.attention_fwd(qb.contiguous(), kb.contiguous(), to_T(vb, ops.pad64(L)), L, causal, scale, kmask)
+    ref, ref_lse = ref_attention(qb.float(), kb.float(), vb.float(), causal, scale, kmask)
+    ref = ref.transpose(1, 2).reshape(B * L, Hq * hd)
+    assert relerr(O, ref) < 2e-2, relerr(O, ref)
+    assert float((lse - ref_lse).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("L,masked", [(192, True), (64, False), (150, True)])
+def test_attention_bwd(L, masked):
+    B, Hq, Hkv, hd = 2, 4, 2, 128
+    q, k, v = (rnd(B, h, L, hd, seed=s).to(BF16).float().requires_grad_(True) for h, s in ((Hq, 1), (Hkv, 2), (Hkv, 3)))
+    dO = rnd(B * L, Hq * hd, seed=4).to(BF16)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, L, dtype=torch.int32, device=DEV)
+        kmask[0, L - 20:] = 0
+    scale = hd ** -0.5
+    ref, _ = ref_attention(q, k, v, True, scale, kmask)
+    ref_tok = ref.transpose(1, 2).reshape(B * L, Hq * hd)
+    valid_q = torch.ones(B, L, dtype=torch.bool, device=DEV) if kmask is None else (kmask != 0)
+    dO_eff = dO.float() * valid_q.reshape(B * L, 1)            # padded query rows carry no gradient in the model
+    ref_tok.backward(dO_eff)
+    Lp = ops.pad64(L)
+    qb, kb, vb = q.detach().to(BF16), k.detach().to(BF16), v.detach().to(BF16)
+    O, lse = ops.attention_fwd(qb, kb, to_T(vb, Lp), L, True, scale, kmask)
+    dOb = dO_eff.to(BF16).contiguous()
+    delta, dOT = ops.attn_bwd_prep(dOb, O, B, Hq, L)
+    ref_delta = (dOb.float() * O.float()).reshape(B, L, Hq, hd).sum(-1).transpose(1, 2)
+    assert relerr(delta, ref_delta) < 1e-3
+    assert relerr(dOT[..., :L], dOb.reshape(B, L, Hq, hd).permute(0, 2, 3, 1)) == 0.0
+    dQ, dK, dV = ops.attention_bwd(qb, to_T(qb, Lp), kb, to_T(kb, Lp), vb, dOb, dOT, lse, delta, L, True, scale, kmask)
+    assert cos_sim(dQ, q.grad) > 0.999 and relerr(dQ, q.grad) < 3e-2
+    assert cos_sim(dK, k.grad) > 0.999 and relerr(dK, k.grad) < 3e-2
+    assert cos_sim(dV, v.grad) > 0.999 and relerr(dV, v.grad) < 3e-2
+
+
+# ----------------------------------------------------------------------------- RoPE / QK-norm
+def rope_tables(n, rot, theta):
+    inv = 1.0 / (theta ** (torch.arange(0, rot, 2, dtype=F32) / rot))
+    f = torch.arange(n, dtype=F32)[:, None] * inv[None]
+    return f.cos().to(DEV).contiguous(), f.sin().to(DEV).contiguous()
+
+
+def rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], -1)
+
+
+def test_enc_qkv_post():
+    B, H, S = 2, 5, 77
+    qkv = rnd(B * S, 3 * H * 64, seed=1).to(BF16)
+    cos, sin = rope_tables(128, 32, 10000.0)
+    Q, K, VT = ops.enc_qkv_post(qkv, cos, sin, B, H, S)
+    x = qkv.float().reshape(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)          # [3,B,H,S,64]
+    c = torch.cat([cos[:S], cos[:S]], -1)[None, None]; s = torch.cat([sin[:S], sin[:S]], -1)[None, None]
+
+    def rope(t):
+        r = t[..., :32] * c + rot_half(t[..., :32]) * s
+        return torch.cat([r, t[..., 32:]], -1)
+    assert relerr(Q, rope(x[0])) < 8e-3 and relerr(K, rope(x[1])) < 8e-3
+    assert relerr(VT[..., :S], x[2].transpose(-1, -2)) == 0.0
+    assert float(VT[..., S:].float().abs().max()) == 0.0
+
+
+def test_lm_qkv_post_fwd_bwd():
+    B, Hq, Hkv, L, hd = 2, 4, 2, 70, 128
+    NQKV = (Hq + 2 * Hkv) * hd
+    x0 = rnd(B * L, NQKV, seed=1).to(BF16)
+    qn, kn = 1 + 0.1 * rnd(hd, seed=2), 1 + 0.1 * rnd(hd, seed=3)
+    cos, sin = rope_tables(256, hd, 1e6)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn, kn, cos, sin, B, Hq, Hkv, L)
+    xf = x0.float().requires_grad_(True)
+    xs = xf.reshape(B, L, Hq + 2 * Hkv, hd)
+    c = torch.cat([cos[:L], cos[:L]], -1)[None, :, None]; s = torch.cat([sin[:L], sin[:L]], -1)[None, :, None]
+
+    def nr(t, w):
+        r = torch.rsqrt((t * t).mean(-1, keepdim=True) + 1e-6)
+        n = w * (t * r)
+        return n * c + rot_half(n) * s, r
+    q_ref, rq_ref = nr(xs[:, :, :Hq], qn)
+    k_ref, rk_ref = nr(xs[:, :, Hq:Hq + Hkv], kn)
+    v_ref = xs[:, :, Hq + Hkv:]
+    assert relerr(Q, q_ref.transpose(1, 2)) < 8e-3 and relerr(K, k_ref.transpose(1, 2)) < 8e-3
+    assert relerr(V, v_ref.transpose(1, 2)) == 0.0
+    assert relerr(rq, rq_ref.reshape(B * L, Hq)) < 1e-5 and relerr(rk, rk_ref.reshape(B * L, Hkv)) < 1e-5
+    for T_, X_ in ((QT, Q), (KT, K), (VT, V)):
+        assert relerr(T_[..., :L], X_.transpose(-1, -2)) == 0.0 and float(T_[..., L:].float().abs().max()) == 0.0
+    dQ, dK, dV = rnd(B, Hq, L, hd, seed=5).to(BF16), rnd(B, Hkv, L, hd, seed=6).to(BF16), rnd(B, Hkv, L, hd, seed=7).to(BF16)
+    (q_ref * dQ.float().transpose(1, 2)).sum().add((k_ref * dK.float().transpose(1, 2)).sum()).add(
+        (v_ref * dV.float().transpose(1, 2)).sum()).backward()
+    dqkv = ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn, kn, cos, sin, B, Hq, Hkv, L)
+    assert relerr(dqkv, xf.grad) < 1e-2 and cos_sim(dqkv, xf.grad) > 0.9999
+
+
+# ----------------------------------------------------------------------------- element-wise / movement
+def test_swiglu():
+    M, F = 300, 768
+    gu = rnd(M, 2 * F, seed=1).to(BF16)
+    g, u = gu.float()[:, :F].clone().requires_grad_(True), gu.float()[:, F:].clone().requires_grad_(True)
+    act = torch.nn.functional.silu(g) * u
+    assert relerr(ops.swiglu_fwd(gu, F), act) < 8e-3
+    d = rnd(M, F, seed=2).to(BF16)
+    act.backward(d.float())
+    dgu = ops.swiglu_bwd(d, gu, F)
+    assert relerr(dgu[:, :F], g.grad) < 1e-2 and relerr(dgu[:, F:], u.grad) < 1e-2
+
+
+def test_cast_transpose():
+    x = rnd(130, 200, seed=1)
+    assert relerr(ops.cast_bf16(x), x) < 4e-3
+    t = ops.transpose_to_bf16(x, ld_out=192)
+    assert torch.equal(t[:, :130], x.to(BF16).T.contiguous()) and float(t[:, 130:].float().abs().max()) == 0.0
+    xb = rnd(4, 50, 64, seed=2).to(BF16)      # frame-stack row map: rows (b, n) = 4 frames, tail frames dropped
+    N = (50 - 4) // 4 + 1
+    t = ops.transpose_to_bf16(xb.reshape(-1, 64)[:1], ld_out=64)  # smoke the bf16 path
+    xs = xb[:, :N * 4].reshape(4 * N, 256)
+    fake = torch.empty(4 * N, 256, device=DEV, dtype=BF16)        # shape carrier: R = 4N, C = 256
+    import ctypes as C
+    from tiny_audio_amd import _lib
+    out = torch.empty(256, 64, device=DEV, dtype=BF16)
+    _lib.check(_lib.lib().ta_transpose_to_bf16(ops.ptr(xb), 0, 256, 50 * 64, N, ops.ptr(out), 64, 4 * N, 256, ops.stream()))
+    assert torch.equal(out[:, :4 * N], xs.T.contiguous()) and float(out[:, 4 * N:].float().abs().max()) == 0.0
+
+
+def test_audio_index_and_scatter():
+    from oracle import model as OM
+    B, L, N, D, V, AID = 3, 40, 9, 64, 100, 99
+    rng = np.random.RandomState(0)
+    ids = rng.randint(0, 90, (B, L)).astype(np.int64)
+    counts = np.array([9, 4, 11])                 # last sample asks for more rows than the projector produced
+    for b, c in enumerate(counts):
+        ids[b, 2:2 + c] = AID
+    y = rng.standard_normal((B, N, D)).astype(np.float32)
+    emb = rng.standard_normal((V, D)).astype(np.float32)
+    ref = OM.masked_scatter_rows(emb[ids], ids == AID, OM.gather_audio_embeds(y, counts))
+    src = ops.audio_index(torch.from_numpy(ids).to(DEV), torch.from_numpy(counts).to(DEV), N, AID)
+    x0 = torch.empty(B * L, D, device=DEV)
+    from tiny_audio_amd import _lib
+    _lib.check(_lib.lib().ta_embed_scatter(ops.ptr(torch.from_numpy(ids).to(DEV)), ops.ptr(src), ops.ptr(torch.from_numpy(emb).to(DEV)),
+                                           ops.ptr(torch.from_numpy(y).to(DEV)), ops.ptr(x0), None, B * L, D, V, ops.stream()))
+    np.testing.assert_array_equal(x0.cpu().numpy().reshape(B, L, D), ref)
+    dx0 = torch.randn(B * L, D, device=DEV)
+    dy = torch.zeros(B * N, D, device=DEV)
+    _lib.check(_lib.lib().ta_audio_grad_gather(ops.ptr(src), ops.ptr(dx0), ops.ptr(dy), B * L, D, ops.stream()))
+    s = src.cpu().numpy()
+    ref_dy = np.zeros((B * N, D), np.float32)
+    ref_dy[s[s >= 0]] = dx0.cpu().numpy()[s >= 0]
+    np.testing.assert_array_equal(dy.cpu().numpy(), ref_dy)
+
+
+def test_label_rows_and_cross_entropy():
+    B, L, V, Vp = 3, 50, 1000 + 3, 1024
+    labels = torch.full((B, L), -100, dtype=torch.int64)
+    labels[0, 10:30] = torch.randint(0, V, (20,)); labels[1, 0:5] = torch.randint(0, V, (5,)); labels[2, 49] = 7
+    rows, tg, n = ops.label_rows(labels.to(DEV))
+    n = int(n.item())
+    shift = torch.cat([labels[:, 1:], torch.full((B, 1), -100)], 1).reshape(-1)
+    exp_rows = torch.nonzero(shift != -100).flatten()
+    assert n == exp_rows.numel()
+    assert torch.equal(rows[:n].cpu().long(), exp_rows) and torch.equal(tg[:n].cpu(), shift[exp_rows])
+    logits = rnd(n, Vp, seed=3, scale=3.0)
+    logits[:, V:] = 50.0                                         # padding columns must be ignored
+    scale = 1.0 / n
+    loss, nll, dl = ops.cross_entropy(logits, tg[:n].contiguous(), V, scale)
+    lf = logits[:, :V].clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, tg[:n], reduction="sum") * scale
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * float(ref)
+    assert relerr(dl[:, :V], lf.grad) < 1e-2 and float(dl[:, V:].float().abs().max()) == 0.0
+    lb = logits.to(BF16)
+    loss_b, _, _ = ops.cross_entropy(lb, tg[:n].contiguous(), V, scale)
+    ref_b = torch.nn.functional.cross_entropy(lb[:, :V].float(), tg[:n], reduction="sum") * scale
+    assert abs(float(loss_b) - float(ref_b)) < 1e-4 * float(ref_b)
+
+
+def test_adamw_and_clip():
+    n = 10007
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sq = torch.zeros(1, device=DEV)
+    cnt = torch.full((1,), 4.0, device=DEV)
+    for step in (1, 2, 3):
+        gs = g * step
+        pt.grad = (gs / 4.0).clone()
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        sq.zero_()
+        ops.grad_sqnorm(gs, sq)
+        assert abs(float(sq) - float((gs.double() ** 2).sum())) < 1e-4 * float(sq)
+        ops.adamw_step(p, gs, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, sqnorm=sq, max_norm=1.0, denom=cnt)
+    d = (p - pt.detach()).abs()
+    assert float(d.mean()) < 1e-7 and float(d.max()) < 3e-4
+
+
+def test_bernoulli_keep():
+    k = ops.bernoulli_keep(200000, 0.9, 123, DEV)
+    assert set(k.unique().tolist()) <= {0.0, 1.0} and abs(float(k.mean()) - 0.9) < 5e-3
+    assert torch.equal(k, ops.bernoulli_keep(200000, 0.9, 123, DEV)) and not torch.equal(k, ops.bernoulli_keep(200000, 0.9, 124, DEV))
+
+
+# ----------------------------------------------------------------------------- log-mel vs the oracle
+def test_logmel_vs_oracle(golden):
+    from oracle import features as OF
+    from tests.golden import recipe as R
+    from tiny_audio_amd.asr_processing import LogMelFeatureExtractor
+    fe = LogMelFeatureExtractor(128, DEV)
+    out = fe(R.logmel_waves(), sampling_rate=16000)
+    g = golden("logmel.npz")
+    wav, lens = OF.pad_batch(R.logmel_waves())
+    of, om = OF.log_mel(wav, lens)
+    f = out["input_features"].cpu().numpy()
+    np.testing.assert_array_equal(out["attention_mask"].cpu().numpy(), om)
+    # exact-f32 DFT (400-term FMA chain) vs float64 FFT: same tolerance class as the reference's own f32 chain
+    assert np.abs(f - of).max() < 5e-4 and np.abs(f - of).mean() < 1e-5
+    assert np.abs(f - g["feats"]).max() < 5e-4                       # and vs the reference's own output
+    out = fe([R.OW.synthetic_wave(3, 16000 + 77)], sampling_rate=16000)
+    np.testing.assert_array_equal(out["attention_mask"].cpu().numpy(), g["mask_odd"])
+    assert np.abs(out["input_features"].cpu().numpy() - g["feats_odd"]).max() < 5e-4

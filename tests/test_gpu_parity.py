@@ -1,0 +1,269 @@
+"""-m gpu: the HIP hot path (composites through the C ABI + the Python drop-in modules) against
+  (1) the committed golden vectors produced by the reference itself (tests/golden/*.npz, reduced widths), and
+  (2) the numpy oracle on the same seeded inputs at the TRUE layer widths (reduced depth so the oracle takes seconds),
+plus size-independent properties at BASELINE.json's full shapes.
+
+Stated tolerances (bf16 MFMA operands, fp32 accumulate / residual / norms / softmax / CE):
+  encoder / projector outputs: rel-to-max error <= 2e-2      logits: atol 5e-2 on O(1..10) magnitudes
+  loss: relative 5e-3                                          projector gradients: cosine >= 0.999
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import encoder as OE
+from oracle import model as OM
+from oracle import projectors as OP
+from oracle import qwen3 as OQ
+from oracle import weights as OW
+from tests.golden import recipe as R
+
+if torch.cuda.is_available():
+    from tiny_audio_amd.asr_config import ASRConfig, EncoderConfig, LMConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.encoder import GlmAsrEncoderMI355X
+    from tiny_audio_amd.language_model import Qwen3MI355X
+    from tiny_audio_amd.projectors import MLPAudioProjector
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    from tiny_audio_amd import ops
+
+DEV = "cuda"
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def cosine(a, b):
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def npy(t):
+    return t.detach().float().cpu().numpy()
+
+
+def build_model(enc_cfg, lm_cfg, proj_hidden, wE, wL, wP, **kw):
+    cfg = ASRConfig(audio_config=enc_cfg, text_config=lm_cfg, projector_hidden_dim=proj_hidden,
+                    audio_token_id=kw.pop("audio_token_id"), **kw)
+    m = ASRModel(cfg, device=DEV, init="none")
+    m.audio_tower.load_state_dict_hf(wE)
+    m.language_model.load_state_dict_hf(wL)
+    m.load_state_dict({"projector." + k: torch.from_numpy(v) for k, v in wP.items()})
+    return m
+
+
+# ============================================================================ (1) golden vectors from the reference
+def test_encoder_vs_golden(golden):
+    g = golden("encoder_small.npz")
+    cfg = R.SMALL["enc"]
+    enc = GlmAsrEncoderMI355X(EncoderConfig(cfg), DEV).load_state_dict_hf(OW.init_encoder(cfg, 0))
+    out = enc(torch.from_numpy(R.encoder_input()), return_f32=True).last_hidden_state
+    assert relmax(npy(out), g["last_hidden_state"]) < 2e-2
+
+
+def test_mlp_projector_vs_golden(golden):
+    g = golden("projector_mlp.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    cfg = ASRConfig(audio_config=S["enc"], text_config=S["lm"], projector_hidden_dim=H)
+    p = MLPAudioProjector(cfg).to(DEV)
+    p.load_state_dict({k: torch.from_numpy(v) for k, v in OW.init_mlp_projector(E, D, H).items()})
+    x, dy = R.proj_input()
+    y = p(torch.from_numpy(x).to(DEV).to(torch.bfloat16))
+    assert relmax(npy(y), g["y"]) < 2e-2
+    y.backward(torch.from_numpy(dy).to(DEV))
+    for k, prm in p.named_parameters():
+        assert cosine(npy(prm.grad), g["g." + k]) > 0.999, k
+        assert relmax(npy(prm.grad), g["g." + k]) < 4e-2, k
+
+
+def test_asr_model_vs_golden(golden):
+    g = golden("asr_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    m = build_model(S["enc"], S["lm"], H, OW.init_encoder(S["enc"], 0), OW.init_lm(S["lm"], 1),
+                    OW.init_mlp_projector(E, D, H), audio_token_id=S["audio_token_id"])
+    ids, att, lab, counts = R.asr_tokens(g["counts"])
+    m.train()
+    out = m(input_ids=torch.from_numpy(ids), input_features=torch.from_numpy(g["input_features"]),
+            attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts))
+    out.loss.backward()
+    ref_loss = float(g["mlp.loss"])
+    assert abs(float(out.loss) - ref_loss) < 5e-3 * ref_loss
+    valid = att.astype(bool)
+    assert np.abs(npy(out.logits)[valid] - g["mlp.logits"][valid]).max() < 5e-2
+    for k, prm in m.projector.named_parameters():
+        assert cosine(npy(prm.grad), g["mlp.g." + k]) > 0.999, k
+
+
+def test_three_training_steps_vs_golden(golden):
+    """Row a13: AdamW + global-norm clip through the HIP optimizer kernels on the reference's 3-step fixture."""
+    g, g3 = golden("asr_small.npz"), golden("train3_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    m = build_model(S["enc"], S["lm"], H, OW.init_encoder(S["enc"], 0), OW.init_lm(S["lm"], 1),
+                    OW.init_mlp_projector(E, D, H), audio_token_id=S["audio_token_id"])
+    ids, att, lab, counts = R.asr_tokens(g["counts"])
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.from_numpy(g["input_features"]),
+                 attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts))
+    m.train()
+    tr = ASRTrainer(m, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0))
+    losses, gnorms = [], []
+    for _ in range(3):
+        tr.training_step(batch)
+        losses.append(tr.last_loss()); gnorms.append(tr.last_grad_norm())
+    np.testing.assert_allclose(losses, g3["losses"], rtol=5e-3)
+    np.testing.assert_allclose(gnorms, g3["gnorms"], rtol=3e-2)
+    assert losses[2] < losses[0]
+    for k, prm in m.projector.named_parameters():
+        d = np.abs(npy(prm) - g3["w." + k])
+        assert d.mean() < 2e-4, (k, d.mean())            # each Adam step moves a weight by <= lr = 1e-3
+
+
+# ============================================================================ (2) oracle at true widths, reduced depth
+TRUE_ENC = OW.enc_config(layers=2)
+TRUE_LM = OW.lm_config(vocab=5003, layers=2)        # true widths; small odd vocab exercises the padded-column masking
+AID, PAD, EOS = 5002, 4990, 4991
+
+
+def test_encoder_true_width_vs_oracle():
+    w = OW.init_encoder(TRUE_ENC, 0)
+    enc = GlmAsrEncoderMI355X(EncoderConfig(TRUE_ENC), DEV).load_state_dict_hf(w)
+    x = (0.6 * np.random.RandomState(3).standard_normal((2, 128, 301))).astype(np.float32)   # odd T, S = 151
+    ref = OE.encoder_forward(x, w, TRUE_ENC)
+    out = enc(torch.from_numpy(x), return_f32=True).last_hidden_state
+    assert out.shape == (2, 151, 1280)
+    assert relmax(npy(out), ref) < 2e-2 and cosine(npy(out), ref) > 0.9995
+    keep = (np.random.RandomState(4).rand(2, 151) < 0.8).astype(np.float32)
+    out = enc(torch.from_numpy(x), frame_keep=torch.from_numpy(keep).reshape(-1), return_f32=True).last_hidden_state
+    assert relmax(npy(out), ref * keep[:, :, None]) < 2e-2
+    assert float(npy(out)[keep == 0].__abs__().max()) == 0.0          # dropped frames are exactly zero, no rescale
+
+
+@pytest.mark.parametrize("hidden", [1024, 2048])
+def test_mlp_projector_true_width_vs_oracle(hidden):
+    E, D = 1280, 1024
+    w = OW.init_mlp_projector(E, D, hidden)
+    cfg = ASRConfig(audio_config=TRUE_ENC, text_config=TRUE_LM, projector_hidden_dim=hidden)
+    p = MLPAudioProjector(cfg).to(DEV)
+    p.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    rng = np.random.RandomState(5)
+    x = rng.standard_normal((3, 102, E)).astype(np.float32)          # 102 frames: tail of 2 is dropped (N = 25)
+    xb = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    y = p(xb)
+    xr = npy(xb)
+    ref, c = OP.mlp_forward(xr, w)
+    assert y.shape == (3, 25, D) and relmax(npy(y), ref) < 2e-2
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    y.backward(torch.from_numpy(dy).to(DEV))
+    gr = OP.mlp_backward(dy, w, c)
+    for k, prm in p.named_parameters():
+        assert cosine(npy(prm.grad), gr[k]) > 0.999, k
+
+
+def _true_batch(B=2, T=200):
+    feats = (0.6 * np.random.RandomState(6).standard_normal((B, 128, T))).astype(np.float32)
+    n_audio = ((T - 1) // 2 + 1 - 4) // 4 + 1
+    counts = [n_audio, n_audio - 5][:B]
+    ids, att, lab, counts = OW.synthetic_tokens(B, counts, TRUE_LM["vocab"], AID, PAD, EOS, n_text=14, n_suffix=6, ragged=True)
+    return dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
+
+
+def test_full_model_true_width_vs_oracle():
+    wE, wL = OW.init_encoder(TRUE_ENC, 0), OW.init_lm(TRUE_LM, 1)
+    wP = OW.init_mlp_projector(1280, 1024, 1024)
+    m = build_model(TRUE_ENC, TRUE_LM, 1024, wE, wL, wP, audio_token_id=AID)
+    b = _true_batch()
+    m.train()
+    out = m(**{k: torch.from_numpy(v) for k, v in b.items()})
+    out.loss.backward()
+    W = dict(encoder=wE, lm=wL, projector={k: v.copy() for k, v in wP.items()})
+    cfg = dict(enc=TRUE_ENC, lm=TRUE_LM, projector_type="mlp", k=4, audio_token_id=AID)
+    ref = OM.asr_forward(b, W, cfg, training=True)
+    grads, _ = OM.asr_backward(ref, W, cfg)
+    assert abs(float(out.loss) - float(ref["loss"])) < 5e-3 * float(ref["loss"])
+    assert out.n_label_tokens == ref["n_label_tokens"]
+    valid = b["attention_mask"].astype(bool)
+    assert np.abs(npy(out.logits)[valid] - ref["logits"][valid]).max() < 5e-2
+    for k, prm in m.projector.named_parameters():
+        assert cosine(npy(prm.grad), grads[k]) > 0.999, k
+    # sum-CE / num_items semantics of the HF Trainer (TF:loss/loss_utils.py:33-46)
+    out77 = m(**{k: torch.from_numpy(v) for k, v in b.items()}, num_items_in_batch=77, return_logits=False)
+    assert abs(float(out77.loss) * 77 - float(out.loss) * out.n_label_tokens) < 1e-3 * float(out.loss) * out.n_label_tokens
+    assert out77.logits is None
+
+
+def test_lm_text_only_and_dx_vs_oracle():
+    """Row a9/a10 in isolation: inputs_embeds-level gradient of the frozen LM (no audio)."""
+    wL = OW.init_lm(TRUE_LM, 1)
+    lm = Qwen3MI355X(LMConfig(TRUE_LM), DEV).load_state_dict_hf(wL)
+    rng = np.random.RandomState(8)
+    B, L = 2, 70
+    ids = rng.randint(0, 4900, (B, L)).astype(np.int64)
+    att = np.ones((B, L), np.int64); att[1, 55:] = 0
+    lab = np.full((B, L), -100, np.int64); lab[0, 40:70] = ids[0, 40:70]; lab[1, 30:55] = ids[1, 30:55]
+    rows, tg, n = ops.label_rows(torch.from_numpy(lab).to(DEV))
+    n = int(n.item())
+    loss, nll, logits, ctx = lm.forward_loss(torch.from_numpy(ids).to(DEV), None, None, torch.from_numpy(att).to(DEV).int(),
+                                             rows, tg, n, 1.0 / n, want_logits=True)
+    x0 = wL["model.embed_tokens.weight"][ids]
+    ref_logits, cache = OQ.lm_forward(x0, att, wL, TRUE_LM)
+    ref_loss, dlogits, n_ref = OQ.causal_lm_loss(ref_logits, lab)
+    assert n == n_ref and abs(float(loss) - float(ref_loss)) < 5e-3 * float(ref_loss)
+    valid = att.astype(bool)
+    got = npy(logits).reshape(B, L, -1)[:, :, :TRUE_LM["vocab"]]
+    assert np.abs(got[valid] - ref_logits[valid]).max() < 5e-2
+    _, d_emb = lm.backward_from_ctx(ctx, 1, want_d_embeds=True)
+    ref_dx = OQ.lm_backward_dx(dlogits, wL, TRUE_LM, cache)
+    got_dx = npy(d_emb).reshape(B, L, -1)
+    assert cosine(got_dx[valid], ref_dx[valid]) > 0.999
+    assert relmax(got_dx[valid], ref_dx[valid]) < 5e-2
+
+
+# ============================================================================ size-independent properties at full shapes
+def test_full_size_properties():
+    """BASELINE config: full depth (32 + 28 layers), 10 s clips, L = 192 -- too big for the oracle,
+    so check invariants: finite loss near ln(V) for random weights, batch-permutation equivariance of per-token
+    NLL, gradient linearity in the loss scale, zero gradient for a clip whose labels are all ignored."""
+    torch.manual_seed(0)
+    cfg = ASRConfig(audio_token_dropout=0.0)
+    m = ASRModel(cfg, device=DEV, init="random", seed=0)
+    B, L = 3, 192
+    V = cfg.text_config.vocab_size
+    feats = torch.randn(B, 128, 1000) * 0.5
+    ids, att, lab, counts = OW.synthetic_tokens(B, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    lab[2] = -100                                               # third clip carries no labels
+    tb = dict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab),
+              audio_token_counts=torch.from_numpy(counts))
+    m.train()
+    out = m(input_features=feats, **tb, return_logits=False)
+    assert out.n_label_tokens == 72 and np.isfinite(float(out.loss))
+    assert abs(float(out.loss) - np.log(V)) < 3.0
+    out.loss.backward()
+    g1 = {k: p.grad.clone() for k, p in m.projector.named_parameters()}
+    nll1 = out.nll.clone()
+    # permutation of the batch permutes per-token NLLs and leaves the (mean) gradient unchanged
+    perm = [1, 0, 2]
+    m.zero_grad()
+    out2 = m(input_features=feats[perm], **{k: v[perm] for k, v in tb.items()}, return_logits=False)
+    out2.loss.backward()
+    assert torch.allclose(torch.cat([nll1[36:72], nll1[0:36]]), out2.nll, rtol=2e-3, atol=2e-3)
+    for k, p in m.projector.named_parameters():
+        assert cosine(npy(p.grad), npy(g1[k])) > 0.9995, k
+    # gradient scales linearly with 1/num_items
+    m.zero_grad()
+    out3 = m(input_features=feats, **tb, return_logits=False, num_items_in_batch=36)
+    out3.loss.backward()
+    for k, p in m.projector.named_parameters():
+        assert cosine(npy(p.grad), npy(g1[k])) > 0.99999 and abs(float(p.grad.norm() / g1[k].norm()) - 2.0) < 2e-3
+    # a batch made only of the unlabelled clip: loss 0, all gradients exactly 0
+    m.zero_grad()
+    out4 = m(input_features=feats[2:], **{k: v[2:] for k, v in tb.items()}, return_logits=False)
+    assert out4.n_label_tokens == 0 and float(out4.loss) == 0.0
+    out4.loss.backward()
+    for k, p in m.projector.named_parameters():
+        assert float(p.grad.abs().max()) == 0.0, k

@@ -1,0 +1,177 @@
+"""-m "not gpu": host-side logic of the MI355X path -- the C ABI loads and exports every symbol the header
+declares, config / length formulas / schedules, feature tables, and the data-parallel reduction (gloo, world 2)."""
+import ctypes as C
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tiny_audio_amd import _lib
+from tiny_audio_amd.asr_config import ASRConfig, compute_encoder_output_length
+from tiny_audio_amd.trainer import FlatTrainable, TrainingArguments, allreduce_flat, lr_multiplier
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_library_builds_and_exports_every_declared_symbol():
+    _lib.build()
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    handle = _lib.lib()                      # binds every prototype; AttributeError if one is not exported
+    for name in protos:
+        assert hasattr(handle, name), name
+    assert handle.ta_version() == 1
+    # every extern "C" ta_* symbol the library exports is declared in the header (no undocumented entry points)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T ta_" in l}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_header_cites_the_reference_interfaces():
+    text = open(_lib.HEADER).read()
+    for cite in ("tiny_audio/asr_modeling.py:448-450", "tiny_audio/projectors.py:57-71", "scripts/train.py:327-333",
+                 "tiny_audio/asr_modeling.py:27-44", "TF:loss/loss_utils.py:33-71"):
+        assert cite in text, cite
+
+
+def test_host_only_queries_run_without_a_gpu():
+    L = _lib.lib()
+    mw = _lib.MlpWeights(enc_dim=1280, k=4, hidden=1024, llm_dim=1024, eps=1e-6)
+    tape = L.ta_mlp_tape_bytes(C.byref(mw), 32, 500)
+    assert tape >= 32 * 125 * (1024 * 4 * 2 + 1024 * 2)       # h1 + h2 (f32) + a1 (bf16)
+    ew = _lib.EncoderWeights(hidden=1280, ffn=5120, n_layers=32, heads=20, n_mels=128, max_pos=1500, ln_eps=1e-5)
+    ws = L.ta_encoder_workspace_bytes(C.byref(ew), 32, 1000)
+    assert 0.3e9 < ws < 2e9
+    lw = _lib.LmWeights(vocab=151670, vocab_pad=151680, hidden=1024, ffn=3072, n_layers=28, heads=16, kv_heads=8,
+                        head_dim=128, max_pos=4096, eps=1e-6)
+    assert 5e9 < L.ta_lm_tape_bytes(C.byref(lw), 32, 192, 1152) < 20e9
+    assert L.ta_gemm_splitk_ws_bytes(100, 64, 4) == 100 * 64 * 4 * 4 and L.ta_gemm_splitk_ws_bytes(100, 64, 1) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    from tiny_audio_amd.projectors import MLPAudioProjector
+    p = MLPAudioProjector(ASRConfig())
+    with pytest.raises(_lib.Ta355Error):
+        p(torch.zeros(1, 8, 1280))
+    src = "".join(open(os.path.join(ROOT, "tiny_audio_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "tiny_audio_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src      # the product never touches the checker
+
+
+# ----------------------------------------------------------------------------- config / formulas (reference known answers)
+def test_config_and_length_formulas():
+    c = ASRConfig()
+    assert (c.encoder_dim, c.llm_dim, c.projector_pool_stride) == (1280, 1024, 4)
+    assert c.audio_config.num_hidden_layers == 32 and c.text_config.num_key_value_heads == 8
+    # reference tests/test_asr_config.py:150-175
+    assert [compute_encoder_output_length(x) for x in (100, 1, 3000)] == [50, 1, 1500]
+    assert compute_encoder_output_length(torch.tensor([100, 1000])).tolist() == [50, 500]
+    from tiny_audio_amd.projectors import MLPAudioProjector, PROJECTOR_CLASSES
+    p = MLPAudioProjector(c)
+    assert [p.get_output_length(x) for x in (100, 104, 4)] == [25, 26, 1]      # tests/test_projectors.py:65-69
+    assert set(p.state_dict()) == {"linear_1.weight", "norm.weight", "linear_2.weight", "norm_2.weight"}
+    assert sum(v.numel() for v in p.parameters()) == 6_293_504
+    assert "mlp" in PROJECTOR_CLASSES
+    with pytest.raises(ValueError):
+        ASRConfig(audio_config=dict(hidden=1280, heads=10))                      # head_dim 128 encoder: unsupported
+
+
+def test_gather_semantics_helper(golden):
+    from tiny_audio_amd.asr_modeling import _gather_audio_embeds
+    g = golden("known_answers.npz")
+    for k in ("a", "b"):
+        out = _gather_audio_embeds(torch.from_numpy(g["emb"]), torch.from_numpy(g["counts_" + k]))
+        np.testing.assert_array_equal(out.numpy(), g["gather_" + k])
+
+
+def test_feature_tables(golden):
+    from tiny_audio_amd.asr_processing import dft_tables, slaney_mel_filters
+    g = golden("logmel.npz")
+    np.testing.assert_allclose(slaney_mel_filters(128), g["mel_filters"], rtol=1e-6, atol=1e-9)
+    dft, win = dft_tables()
+    assert dft.shape == (400, 402) and win.shape == (400,)
+    x = np.random.RandomState(0).standard_normal(400)
+    spec = np.fft.rfft(x * win)
+    np.testing.assert_allclose((x * win) @ dft[:, :201].astype(np.float64), spec.real, atol=2e-5)
+    np.testing.assert_allclose(-((x * win) @ dft[:, 201:].astype(np.float64)), spec.imag, atol=2e-5)
+    np.testing.assert_array_equal(win, torch.hann_window(400).numpy())    # feature_extraction_whisper.py:141
+
+
+def test_lr_schedules():
+    a = TrainingArguments(learning_rate=1e-3, warmup_steps=10, max_steps=110, lr_scheduler_type="cosine")
+    assert lr_multiplier(0, a) == 0.0 and lr_multiplier(5, a) == 0.5 and lr_multiplier(10, a) == 1.0
+    assert abs(lr_multiplier(60, a) - 0.5) < 1e-12 and lr_multiplier(110, a) < 1e-12
+    p = TrainingArguments(learning_rate=1e-3, warmup_steps=500, max_steps=10500, lr_scheduler_type="polynomial",
+                          lr_scheduler_kwargs={"power": 0.5})                    # transcription.yaml:22-25
+    assert abs(lr_multiplier(500, p) - 1.0) < 1e-9
+    assert abs(lr_multiplier(8000, p) - ((1e-3 - 1e-7) * math.sqrt(0.25) + 1e-7) / 1e-3) < 1e-9
+    assert lr_multiplier(20000, p) == 1e-7 / 1e-3
+
+
+def test_flat_trainable_views_and_decay_groups():
+    from tiny_audio_amd.projectors import MLPAudioProjector
+    m = torch.nn.Module()
+    m.projector = MLPAudioProjector(ASRConfig(audio_config=dict(hidden=128, heads=2), text_config=dict(hidden=64, heads=2, kv_heads=1),
+                                              projector_hidden_dim=64))
+    w0 = m.projector.linear_1.weight.detach().clone()
+    ft = FlatTrainable(list(m.named_parameters()), device="cpu")
+    assert ft.n == sum(ft.sizes) and ft.flat_g.numel() == ft.n + 2
+    assert torch.equal(m.projector.linear_1.weight, w0)
+    assert m.projector.linear_1.weight.data_ptr() == ft.flat_p[ft.offsets[0]:].data_ptr()
+    assert dict(zip(ft.names, ft.decay)) == {"projector.linear_1.weight": True, "projector.norm.weight": False,
+                                             "projector.linear_2.weight": True, "projector.norm_2.weight": False}
+    (m.projector.linear_2.weight.sum() * 2).backward()                            # autograd accumulates into the flat views
+    o = ft.offsets[2]
+    assert torch.all(ft.flat_g[o:o + ft.sizes[2]] == 2.0) and float(ft.flat_g[:ft.offsets[2]].abs().sum()) == 0.0
+    ft.zero_grad()
+    assert float(ft.flat_g.abs().sum()) == 0.0
+
+
+# ----------------------------------------------------------------------------- data parallel: gloo, world_size 2
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 4, bias=False)                    # same weights on every rank
+    ft = FlatTrainable([("w", lin.weight)], device="cpu")
+    # rank r holds (r+1)*3 "label tokens"; the per-rank objective is the SUM of per-token losses
+    n_tok = (rank + 1) * 3
+    x = torch.arange(n_tok * 8, dtype=torch.float32).reshape(n_tok, 8) / 10 + rank
+    loss_sum = (lin(x) ** 2).sum()
+    ft.zero_grad()
+    loss_sum.backward()
+    ft.count_slot.add_(float(n_tok)); ft.loss_slot.add_(loss_sum.detach().reshape(1))
+    allreduce_flat(ft.flat_g)
+    q.put((rank, ft.grads.clone().numpy(), float(ft.count_slot), float(ft.loss_slot)))
+    dist.destroy_process_group()
+
+
+def test_dp_allreduce_matches_single_process_global_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in procs])
+    [p.join(60) for p in procs]
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 4, bias=False)
+    xs = [torch.arange((r + 1) * 3 * 8, dtype=torch.float32).reshape((r + 1) * 3, 8) / 10 + r for r in range(world)]
+    total = sum((lin(x) ** 2).sum() for x in xs)
+    total.backward()
+    for rank, g, cnt, ls in res:
+        np.testing.assert_allclose(g, lin.weight.grad.reshape(-1).numpy(), rtol=1e-5)    # SUM over ranks
+        assert cnt == 9.0 and abs(ls - float(total)) < 1e-3 * float(total)
+    # => grads / count == gradient of the global MEAN over all 9 tokens: HF Trainer's sum-CE / num_items semantics

@@ -1,0 +1,176 @@
+"""ctypes binding of libta355.so (the C-ABI boundary, include/ta355.h).
+
+* ``build()`` compiles every HIP source for gfx950 with hipcc into
+  ``tiny_audio_amd/libta355.so`` (in-tree, so it travels with the repo snapshot).
+* ``lib()`` loads it and binds EVERY prototype found in the header (argument and
+  return types are parsed from the header text, so header and binding cannot drift).
+* There is no fallback: if the shared object is absent ``lib()`` raises, and every
+  op raises ``Ta355Error`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "ta355.h")
+CSRC = os.path.join(HERE, "csrc")
+SO_PATH = os.path.join(HERE, "libta355.so")
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
+           "logmel.hip", "optim.hip", "api.hip"]
+
+
+class Ta355Error(RuntimeError):
+    pass
+
+
+# ----------------------------------------------------------------------------- structs (must mirror ta355.h)
+class EncLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo",
+                                          "w1", "b1", "w2", "b2")]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("ffn", C.c_int), ("n_layers", C.c_int), ("heads", C.c_int),
+                ("n_mels", C.c_int), ("max_pos", C.c_int), ("ln_eps", C.c_float),
+                ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+                ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("layers", C.POINTER(EncLayer))]
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("enc_dim", C.c_int), ("k", C.c_int), ("hidden", C.c_int), ("llm_dim", C.c_int), ("eps", C.c_float),
+                ("w1", C.c_void_p), ("w2", C.c_void_p), ("w2_t", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
+
+
+class LmLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_in_w", "wqkv", "wqkv_t", "qn_w", "kn_w", "wo", "wo_t", "ln_post_w",
+                                          "wgu", "wgu_t", "wd", "wd_t")]
+
+
+class LmWeights(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("vocab_pad", C.c_int), ("hidden", C.c_int), ("ffn", C.c_int),
+                ("n_layers", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int), ("head_dim", C.c_int),
+                ("max_pos", C.c_int), ("eps", C.c_float),
+                ("embed_f32", C.c_void_p), ("embed_bf16", C.c_void_p), ("embed_t_bf16", C.c_void_p),
+                ("norm_w", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("layers", C.POINTER(LmLayer))]
+
+
+# ----------------------------------------------------------------------------- header parsing
+_SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "unsigned long long": C.c_ulonglong,
+            "hipStream_t": C.c_void_p}
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        return C.c_void_p
+    ty = re.sub(r"\b\w+$", "", decl).strip() if decl not in _SCALARS else decl   # drop the parameter name
+    ty = ty.replace("const ", "").strip()
+    if ty not in _SCALARS:
+        raise ValueError(f"unmapped C type in ta355.h: {decl!r}")
+    return _SCALARS[ty]
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [argtypes])} for every ``int|long ta_*(...)`` prototype."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long)\s+(ta_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        argtypes = [] if args in ("", "void") else [_ctype(a) for a in args.split(",")]
+        protos[name] = (_SCALARS[ret], argtypes)
+    return protos
+
+
+# ----------------------------------------------------------------------------- build / load
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every kernel source into one shared object (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), HEADER]
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", *srcs, "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise Ta355Error("hipcc failed:\n" + r.stdout + r.stderr)
+    return SO_PATH
+
+
+_LIB = None
+
+# Test instrumentation ONLY (tests/test_dryrun_plumbing.py): with DRY_RUN set, kernel-launching entry points are
+# replaced by stubs that marshal their arguments through the real ctypes prototypes (catching arity / type /
+# None-pointer mistakes in the Python plumbing on a GPU-less box) and then do NOTHING.  It computes no results and
+# is never a fallback: nothing in the package sets it.
+DRY_RUN = False
+
+
+class _DryLib:
+    def __init__(self, handle):
+        self._h = handle
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name.endswith("_bytes") or name == "ta_version":
+            return fn
+
+        def stub(*args):
+            if len(args) != len(fn.argtypes):
+                raise TypeError(f"{name}: expected {len(fn.argtypes)} arguments, got {len(args)}")
+            for i, (a, t) in enumerate(zip(args, fn.argtypes)):
+                try:
+                    t.from_param(a)
+                except Exception as e:  # noqa: BLE001
+                    raise TypeError(f"{name}: argument {i} ({a!r}) does not convert to {t.__name__}") from e
+            self.calls.append(name)
+            return 0
+        return stub
+
+
+def lib():
+    """The loaded library with every header prototype bound.  Raises if libta355.so is missing."""
+    global _LIB
+    if DRY_RUN:
+        if not isinstance(_LIB, _DryLib):
+            _LIB = None
+            real = _load()
+            _LIB = _DryLib(real)
+        return _LIB
+    if isinstance(_LIB, _DryLib):
+        _LIB = None
+    return _load()
+
+
+def _load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise Ta355Error(f"{SO_PATH} not found: run `python __graft_entry__.py` (build()) first. "
+                             "There is no CPU fallback for the ta355 hot path.")
+        handle = C.CDLL(SO_PATH)
+        for name, (ret, argtypes) in parse_header().items():
+            fn = getattr(handle, name)        # AttributeError if the header declares something not exported
+            fn.restype = ret
+            fn.argtypes = argtypes
+        _LIB = handle
+    return _LIB
+
+
+def check(status: int, what: str = "ta355 call"):
+    if status != 0:
+        raise Ta355Error(f"{what} failed with status {status} "
+                         f"({ {1: 'bad argument', 2: 'kernel launch failure'}.get(status, 'unknown')})")

@@ -1,0 +1,163 @@
+"""ASRModel on MI355X: drop-in for the training path of ``tiny_audio/asr_modeling.py``.
+
+Same constructor argument (an ASRConfig), same ``forward(input_ids, input_features, audio_attention_mask,
+attention_mask, labels, audio_token_counts, ...)`` -> object with ``.loss`` / ``.logits``, same sub-module
+names (``audio_tower``, ``projector``, ``language_model``), projector-only ``state_dict()`` with the
+reference's key names (asr_modeling.py:398-422).  Encoder and LM are frozen; ``loss.backward()`` produces
+gradients for the projector parameters only, through two HIP composites (LM dX backward, projector backward).
+
+There is no CPU path: without libta355.so / a GPU every entry point raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .asr_config import ASRConfig, compute_encoder_output_length
+from .encoder import GlmAsrEncoderMI355X
+from .language_model import FrozenLMLoss, Qwen3MI355X
+from .ops import F32
+from .projectors import PROJECTOR_CLASSES
+
+
+class CausalLMOutput:
+    def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None):
+        self.loss, self.logits, self.nll, self.n_label_tokens, self.aux_loss = loss, logits, nll, n_label_tokens, aux_loss
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+def _gather_audio_embeds(audio_embeds: torch.Tensor, token_counts: torch.Tensor) -> torch.Tensor:
+    """Reference semantics of tiny_audio/asr_modeling.py:27-44 in plain torch (utility / tests only; the
+    training path never materialises the packed tensor: ``ta_audio_index`` maps rows directly)."""
+    _, max_len, _ = audio_embeds.shape
+    needed = int(token_counts.max().item())
+    if needed > max_len:
+        audio_embeds = torch.nn.functional.pad(audio_embeds, (0, 0, 0, needed - max_len))
+        max_len = needed
+    mask = torch.arange(max_len, device=audio_embeds.device).unsqueeze(0) < token_counts.unsqueeze(1)
+    return audio_embeds[mask]
+
+
+class ASRModel(nn.Module):
+    config_class = ASRConfig
+    main_input_name = "input_features"
+    TRANSCRIBE_PROMPT = "Transcribe the speech to text"
+
+    def __init__(self, config: ASRConfig, device="cuda", init="random", seed=0, **kwargs):
+        super().__init__()
+        self.config = config
+        self.device_ = torch.device(device)
+        self.audio_tower = GlmAsrEncoderMI355X(config.audio_config, device=device)        # asr_modeling.py:140
+        self.language_model = Qwen3MI355X(config.text_config, device=device)              # :143
+        self.audio_token_id = config.audio_token_id
+        self.projector = self._create_projector(config).to(device=device, dtype=F32)      # :163
+        if init == "random":
+            self.audio_tower.random_init(seed)
+            self.language_model.random_init(seed + 1)
+        if getattr(config, "use_lora", False):
+            raise NotImplementedError("LoRA stage-2 (config 5) is a 'next' row; see DESIGN.md")
+        if getattr(config, "freeze_projector", False):
+            self.projector.requires_grad_(False)
+        self._drop_seed = 0x5EED + seed
+
+    def _create_projector(self, config):
+        projector_type = getattr(config, "projector_type", "mlp")
+        cls = PROJECTOR_CLASSES.get(projector_type)
+        if cls is None:
+            raise ValueError(f"Unknown projector_type: {projector_type}. Valid options: {list(PROJECTOR_CLASSES.keys())}")
+        return cls(config)
+
+    # frozen sub-models hold plain device buffers, not Parameters: parameters()/state_dict() are projector-only
+    def state_dict(self, *args, **kwargs):
+        return {f"projector.{k}": v for k, v in self.projector.state_dict().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        sub = {k[len("projector."):]: v for k, v in sd.items() if k.startswith("projector.")}
+        out = self.projector.load_state_dict(sub, strict=strict)
+        if hasattr(self.projector, "_pack_versions"):
+            self.projector._pack_versions = None
+        return out
+
+    def train(self, mode: bool = True):
+        """Frozen sub-modules never enter train mode (asr_modeling.py:344-357)."""
+        super().train(mode)
+        self.audio_tower.train(False)
+        self.language_model.train(False)
+        return self
+
+    def _compute_encoder_output_lengths(self, audio_attention_mask):
+        return compute_encoder_output_length(audio_attention_mask.sum(dim=-1), self.config.encoder_conv_layers)
+
+    def _frame_keep_mask(self, B, S, frame_keep=None):
+        """Whole-frame Bernoulli keep mask of _maybe_drop_audio_tokens (asr_modeling.py:458-479); applied inside
+        the encoder's final LayerNorm kernel.  ``frame_keep`` injects a mask (parity tests)."""
+        if frame_keep is not None:
+            return frame_keep
+        p = float(getattr(self.config, "audio_token_dropout", 0.0))
+        if not self.training or p <= 0.0:
+            return None
+        self._drop_seed += 1
+        return ops.bernoulli_keep(B * S, 1.0 - p, self._drop_seed, self.device_)
+
+    def _encode_audio(self, audio_features, frame_keep=None):
+        """-> projector output [B, N, llm_dim] fp32 (packing into <audio> rows happens in the LM op)."""
+        B, _, T = audio_features.shape
+        S = self.audio_tower.output_length(T)
+        keep = self._frame_keep_mask(B, S, frame_keep)
+        hidden = self.audio_tower(audio_features, frame_keep=keep).last_hidden_state      # no_grad inside
+        return self.projector(hidden)
+
+    def forward(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
+                audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None, audio_token_counts: Optional[torch.Tensor] = None,
+                num_items_in_batch=None, return_logits: bool = True, frame_keep=None, label_meta=None, **kwargs):
+        """Training/eval forward (tiny_audio/asr_modeling.py:481-533).
+
+        ``num_items_in_batch``: as in HF Trainer -- loss = sum(nll) / num_items_in_batch (default: the number of
+        label tokens in this batch, i.e. the mean).  ``return_logits=False`` skips materialising the [B, L, V]
+        logits (the HF Trainer discards them on the training path).  ``label_meta=(rows, targets, n)`` lets a
+        collator that already knows the label positions on the host avoid one device->host sync.
+        """
+        dev = self.device_
+        if input_ids is None:
+            raise ValueError("input_ids is required")
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        B, L = ids.shape
+        audio, src_row = None, None
+        if input_features is not None:
+            y = self._encode_audio(input_features.to(dev), frame_keep)                    # [B, N, D]
+            N = y.shape[1]
+            if audio_token_counts is None:
+                audio_token_counts = (ids == self.audio_token_id).sum(dim=-1)
+            counts = audio_token_counts.to(device=dev, dtype=torch.int64).contiguous()
+            src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
+            audio = y.reshape(B * N, -1)
+        kmask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int32).contiguous()
+        n_lab, rows, targets = 0, None, None
+        if labels is not None:
+            if label_meta is not None:
+                rows, targets, n_lab = label_meta
+            else:
+                rows, targets, n = ops.label_rows(labels.to(device=dev, dtype=torch.int64).contiguous())
+                n_lab = int(n.item())                                                      # one host sync
+        scale = 1.0 / float(num_items_in_batch if num_items_in_batch is not None else max(n_lab, 1))
+        if audio is None:
+            audio = torch.zeros((1, self.config.llm_dim), device=dev, dtype=F32)
+        loss, nll, logits = FrozenLMLoss.apply(audio, self.language_model, ids, src_row, kmask, rows, targets, n_lab,
+                                               scale, bool(return_logits))
+        V = self.config.text_config.vocab_size
+        logits = logits.reshape(B, L, -1)[:, :, :V] if return_logits else None
+        aux = None
+        if labels is None:
+            loss = None
+        elif hasattr(self.projector, "get_aux_loss"):
+            aux = self.projector.get_aux_loss()
+            if aux is not None and aux.numel() > 0:
+                loss = loss + aux.to(loss.device)                                          # asr_modeling.py:528-531
+        return CausalLMOutput(loss=loss, logits=logits, nll=nll[:n_lab] if labels is not None else None,
+                              n_label_tokens=n_lab, aux_loss=aux)

@@ -1,0 +1,377 @@
+// ta355 composite ops: the layer loops of the hot path, orchestrated on the host side of the C ABI so a
+// binding makes one call per reference nn.Module boundary (see include/ta355.h).  Pure kernel launches on
+// the caller's stream: no allocation, no synchronisation, graph-capturable.
+#include "common.h"
+#include "../../include/ta355.h"
+
+extern "C" int ta_version(void) { return 1; }
+
+namespace {
+struct Carver {
+  char* base; size_t off;
+  explicit Carver(void* b) : base((char*)b), off(0) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+  size_t total() const { return (off + 255) & ~(size_t)255; }
+};
+inline int pad64(int x) { return (x + 63) / 64 * 64; }
+inline int gemm(const void* A, const void* W, void* C, int M, int N, int K, const float* bias, const float* res, int act,
+                int out_bf16, hipStream_t st) {
+  return ta_gemm_bf16_nt(A, W, C, M, N, K, K, 0, 0, N, 0, 0, 0, bias, res, act, out_bf16, 1, nullptr, st);
+}
+// split-K heuristic: fill the 512 resident workgroup slots (256 CUs x 2) when the tile grid is small
+inline int pick_splits(int M, int N, int K) {
+  const long tiles = (long)ta_cdiv(M, 128) * ta_cdiv(N, 128);
+  int s = 1;
+  while (tiles * s < 512 && K / 64 / (s * 2) >= 8 && s < 64) s *= 2;
+  return s;
+}
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+}  // namespace
+
+// ============================================================================ encoder
+namespace {
+struct EncWs {
+  bf16_t *x0, *x1, *xn, *qkv, *q, *k, *vt, *ao, *hf;
+  float* xr;
+  size_t bytes;
+};
+EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
+  const int H = w->hidden, S = (T - 1) / 2 + 1, Sp = pad64(S);
+  const long M = (long)B * S;
+  Carver c(base);
+  EncWs e;
+  e.x0 = c.take<bf16_t>((size_t)B * (T + 2) * w->n_mels);
+  e.x1 = c.take<bf16_t>((size_t)B * (T + 2) * H);
+  e.xr = c.take<float>((size_t)M * H);
+  e.xn = c.take<bf16_t>((size_t)M * H);
+  e.qkv = c.take<bf16_t>((size_t)M * 3 * H);
+  e.q = c.take<bf16_t>((size_t)M * H);
+  e.k = c.take<bf16_t>((size_t)M * H);
+  e.vt = c.take<bf16_t>((size_t)B * H * Sp);
+  e.ao = c.take<bf16_t>((size_t)M * H);
+  e.hf = c.take<bf16_t>((size_t)M * w->ffn);
+  e.bytes = c.total();
+  return e;
+}
+}  // namespace
+
+extern "C" long ta_encoder_workspace_bytes(const ta_encoder_weights* w, int B, int T) {
+  return (long)enc_carve(w, B, T, nullptr).bytes;
+}
+
+extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feats, int B, int T, const float* frame_keep,
+                                  void* out_bf16, float* out_f32, void* ws, long ws_bytes, hipStream_t st) {
+  if (B <= 0 || T <= 0) return TA_OK;
+  const int H = w->hidden, F = w->ffn, NM = w->n_mels, nh = w->heads;
+  if (H % 128 || F % 128 || (3 * NM) % 64 || H / nh != 64 || (!out_bf16 && !out_f32)) return TA_ERR_ARG;
+  const int S = (T - 1) / 2 + 1, Sp = pad64(S);
+  if (S > w->max_pos) return TA_ERR_ARG;
+  const int M = B * S;
+  EncWs e = enc_carve(w, B, T, ws);
+  if ((long)e.bytes > ws_bytes) return TA_ERR_ARG;
+  // conv front end as two row-mapped GEMMs over zero-padded time-major buffers
+  RC(ta_feats_to_time_major(feats, e.x0, B, NM, T, st));
+  RC(ta_zero_pad_rows(e.x1, B, T, H, st));
+  RC(ta_gemm_bf16_nt(e.x0, w->conv1_w, e.x1, B * T, H, 3 * NM, NM, T, (long)(T + 2) * NM, H, T, (long)(T + 2) * H, H,
+                     w->conv1_b, nullptr, 1, 1, 1, nullptr, st));
+  RC(ta_gemm_bf16_nt(e.x1, w->conv2_w, e.xr, M, H, 3 * H, 2L * H, S, (long)(T + 2) * H, H, 0, 0, 0, w->conv2_b, nullptr,
+                     1, 0, 1, nullptr, st));
+  const float scale = 0.125f;   // head_dim ** -0.5, head_dim = 64
+  for (int l = 0; l < w->n_layers; ++l) {
+    const ta_enc_layer& L = w->layers[l];
+    RC(ta_layernorm_f32(e.xr, L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr, M, H, w->ln_eps, st));
+    RC(gemm(e.xn, L.wqkv, e.qkv, M, 3 * H, H, L.bqkv, nullptr, 0, 1, st));
+    RC(ta_enc_qkv_post(e.qkv, w->rope_cos, w->rope_sin, e.q, e.k, e.vt, B, nh, S, Sp, st));
+    RC(ta_attention_fwd(e.q, e.k, e.vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, st));
+    RC(gemm(e.ao, L.wo, e.xr, M, H, H, L.bo, e.xr, 0, 0, st));
+    RC(ta_layernorm_f32(e.xr, L.ln2_w, L.ln2_b, e.xn, nullptr, nullptr, M, H, w->ln_eps, st));
+    RC(gemm(e.xn, L.w1, e.hf, M, F, H, L.b1, nullptr, 1, 1, st));
+    RC(gemm(e.hf, L.w2, e.xr, M, H, F, L.b2, e.xr, 0, 0, st));
+  }
+  RC(ta_layernorm_f32(e.xr, w->norm_w, w->norm_b, out_bf16, out_f32, frame_keep, M, H, w->ln_eps, st));
+  return TA_OK;
+}
+
+// ============================================================================ MLP projector
+namespace {
+struct MlpTape { float *h1, *r1, *h2, *r2; bf16_t* a1; size_t bytes; };
+MlpTape mlp_tape(const ta_mlp_weights* w, int B, int S, void* base) {
+  const int N = (S - w->k) / w->k + 1;
+  const long Mp = (long)B * N;
+  Carver c(base);
+  MlpTape t;
+  t.h1 = c.take<float>((size_t)Mp * w->hidden);
+  t.r1 = c.take<float>((size_t)Mp);
+  t.a1 = c.take<bf16_t>((size_t)Mp * w->hidden);
+  t.h2 = c.take<float>((size_t)Mp * w->llm_dim);
+  t.r2 = c.take<float>((size_t)Mp);
+  t.bytes = c.total();
+  return t;
+}
+struct MlpBwdWs { float *dh2, *da1, *skws; bf16_t *dh2b, *dh2T, *a1T, *dh1b, *dh1T, *xsT; size_t bytes; };
+MlpBwdWs mlp_bwd_ws(const ta_mlp_weights* w, int B, int S, void* base) {
+  const int N = (S - w->k) / w->k + 1, Hd = w->hidden, D = w->llm_dim, In = w->k * w->enc_dim;
+  const long Mp = (long)B * N; const int Kp = pad64((int)Mp);
+  Carver c(base);
+  MlpBwdWs s;
+  s.dh2 = c.take<float>((size_t)Mp * D);
+  s.dh2b = c.take<bf16_t>((size_t)Mp * D);
+  s.dh2T = c.take<bf16_t>((size_t)D * Kp);
+  s.a1T = c.take<bf16_t>((size_t)Hd * Kp);
+  s.da1 = c.take<float>((size_t)Mp * Hd);
+  s.dh1b = c.take<bf16_t>((size_t)Mp * Hd);
+  s.dh1T = c.take<bf16_t>((size_t)Hd * Kp);
+  s.xsT = c.take<bf16_t>((size_t)In * Kp);
+  const int s1 = pick_splits(Hd, In, Kp), s2 = pick_splits(D, Hd, Kp);
+  const size_t sk1 = (size_t)ta_gemm_splitk_ws_bytes(Hd, In, s1), sk2 = (size_t)ta_gemm_splitk_ws_bytes(D, Hd, s2);
+  s.skws = c.take<float>((sk1 > sk2 ? sk1 : sk2) / 4 + 4);
+  s.bytes = c.total();
+  return s;
+}
+}  // namespace
+
+extern "C" long ta_mlp_tape_bytes(const ta_mlp_weights* w, int B, int S) { return (long)mlp_tape(w, B, S, nullptr).bytes; }
+extern "C" long ta_mlp_bwd_workspace_bytes(const ta_mlp_weights* w, int B, int S) {
+  return (long)mlp_bwd_ws(w, B, S, nullptr).bytes;
+}
+
+extern "C" int ta_mlp_projector_forward(const ta_mlp_weights* w, const void* x, int B, int S, float* y, void* tape,
+                                        hipStream_t st) {
+  const int k = w->k, E = w->enc_dim, Hd = w->hidden, D = w->llm_dim, In = k * E;
+  const int N = (S - k) / k + 1;
+  if (B <= 0 || N <= 0) return TA_OK;
+  if (In % 64 || Hd % 64 || D % 4 || Hd % 4) return TA_ERR_ARG;
+  const int Mp = B * N;
+  MlpTape t = mlp_tape(w, B, S, tape);
+  // frame stacking is a row map of the encoder output: row (b,n) starts at b*S*E + n*k*E   (projectors.py:79-87)
+  RC(ta_gemm_bf16_nt(x, w->w1, t.h1, Mp, Hd, In, In, N, (long)S * E, Hd, 0, 0, 0, nullptr, nullptr, 0, 0, 1, nullptr, st));
+  RC(ta_rmsnorm_fwd(t.h1, w->g1, t.a1, nullptr, t.r1, Mp, Hd, w->eps, 1, st));
+  RC(gemm(t.a1, w->w2, t.h2, Mp, D, Hd, nullptr, nullptr, 0, 0, st));
+  RC(ta_rmsnorm_fwd(t.h2, w->g2, nullptr, y, t.r2, Mp, D, w->eps, 0, st));
+  return TA_OK;
+}
+
+extern "C" int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x, int B, int S, const float* dy,
+                                         const void* tape, float* dW1, float* dg1, float* dW2, float* dg2, void* ws,
+                                         long ws_bytes, hipStream_t st) {
+  const int k = w->k, E = w->enc_dim, Hd = w->hidden, D = w->llm_dim, In = k * E;
+  const int N = (S - k) / k + 1;
+  if (B <= 0 || N <= 0) return TA_OK;
+  const int Mp = B * N, Kp = pad64(Mp);
+  MlpTape t = mlp_tape(w, B, S, (void*)tape);
+  MlpBwdWs s = mlp_bwd_ws(w, B, S, ws);
+  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
+  if (hipMemsetAsync(dg1, 0, (size_t)Hd * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+  if (hipMemsetAsync(dg2, 0, (size_t)D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+  // norm_2 backward -> dH2 ; dW2 = dH2^T A1 ; dA1 = dH2 W2
+  RC(ta_rmsnorm_bwd(dy, t.h2, t.r2, w->g2, nullptr, nullptr, s.dh2b, dg2, Mp, D, 0, st));
+  RC(ta_transpose_to_bf16(s.dh2b, 0, D, 0, 0, s.dh2T, Kp, Mp, D, st));
+  RC(ta_transpose_to_bf16(t.a1, 0, Hd, 0, 0, s.a1T, Kp, Mp, Hd, st));
+  const int s2 = pick_splits(D, Hd, Kp);
+  RC(ta_gemm_bf16_nt(s.dh2T, s.a1T, dW2, D, Hd, Kp, Kp, 0, 0, Hd, 0, 0, 0, nullptr, nullptr, 0, 0, s2, s.skws, st));
+  RC(gemm(s.dh2b, w->w2_t, s.da1, Mp, Hd, D, nullptr, nullptr, 0, 0, st));
+  // GELU' + norm backward -> dH1 ; dW1 = dH1^T Xs
+  RC(ta_rmsnorm_bwd(s.da1, t.h1, t.r1, w->g1, nullptr, nullptr, s.dh1b, dg1, Mp, Hd, 1, st));
+  RC(ta_transpose_to_bf16(s.dh1b, 0, Hd, 0, 0, s.dh1T, Kp, Mp, Hd, st));
+  RC(ta_transpose_to_bf16(x, 0, In, (long)S * E, N, s.xsT, Kp, Mp, In, st));
+  const int s1 = pick_splits(Hd, In, Kp);
+  RC(ta_gemm_bf16_nt(s.dh1T, s.xsT, dW1, Hd, In, Kp, Kp, 0, 0, In, 0, 0, 0, nullptr, nullptr, 0, 0, s1, s.skws, st));
+  return TA_OK;
+}
+
+// ============================================================================ Qwen3 LM
+namespace {
+struct LmLayerTape {
+  float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
+  bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
+};
+struct LmTape {
+  LmLayerTape* L;    // host array (static storage below)
+  float *x_final, *r_f;
+  bf16_t *hn, *dlogits;
+  size_t bytes;
+};
+constexpr int MAX_LM_LAYERS = 64;
+struct LmDims { int D, F, nq, nkv, hd, NQKV, Lp; long M; };
+LmDims lm_dims(const ta_lm_weights* w, int B, int L) {
+  LmDims d;
+  d.D = w->hidden; d.F = w->ffn; d.nq = w->heads; d.nkv = w->kv_heads; d.hd = w->head_dim;
+  d.NQKV = (d.nq + 2 * d.nkv) * d.hd; d.Lp = pad64(L); d.M = (long)B * L;
+  return d;
+}
+LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLayerTape* store) {
+  const LmDims d = lm_dims(w, B, L);
+  Carver c(base);
+  LmTape t; t.L = store;
+  for (int l = 0; l < w->n_layers; ++l) {
+    LmLayerTape& p = store[l];
+    p.x_in = c.take<float>((size_t)d.M * d.D);
+    p.r_in = c.take<float>((size_t)d.M);
+    p.qkv0 = c.take<bf16_t>((size_t)d.M * d.NQKV);
+    p.rq = c.take<float>((size_t)d.M * d.nq);
+    p.rk = c.take<float>((size_t)d.M * d.nkv);
+    p.q = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
+    p.k = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
+    p.v = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
+    p.qt = c.take<bf16_t>((size_t)B * d.nq * d.hd * d.Lp);
+    p.kt = c.take<bf16_t>((size_t)B * d.nkv * d.hd * d.Lp);
+    p.vt = c.take<bf16_t>((size_t)B * d.nkv * d.hd * d.Lp);
+    p.ao = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
+    p.lse = c.take<float>((size_t)B * d.nq * L);
+    p.x1 = c.take<float>((size_t)d.M * d.D);
+    p.r_post = c.take<float>((size_t)d.M);
+    p.gu = c.take<bf16_t>((size_t)d.M * 2 * d.F);
+  }
+  t.x_final = c.take<float>((size_t)d.M * d.D);
+  t.r_f = c.take<float>((size_t)d.M);
+  t.hn = c.take<bf16_t>((size_t)d.M * d.D);
+  t.dlogits = c.take<bf16_t>((size_t)(n_lab > 0 ? n_lab : 1) * w->vocab_pad);
+  t.bytes = c.total();
+  return t;
+}
+struct LmWs {
+  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv;
+  float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
+  size_t bytes;
+};
+LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
+  const LmDims d = lm_dims(w, B, L);
+  const int nl = n_lab > 0 ? n_lab : 1;
+  Carver c(base);
+  LmWs s;
+  s.xn = c.take<bf16_t>((size_t)d.M * d.D);
+  s.act = c.take<bf16_t>((size_t)d.M * d.F);
+  s.hl = c.take<bf16_t>((size_t)nl * d.D);
+  s.logits = c.take<float>((size_t)nl * w->vocab_pad);
+  s.dhl = c.take<float>((size_t)nl * d.D);
+  s.dhn = c.take<float>((size_t)d.M * d.D);
+  s.dxa = c.take<float>((size_t)d.M * d.D);
+  s.dxb32 = c.take<float>((size_t)d.M * d.D);
+  s.dxn = c.take<float>((size_t)d.M * d.D);
+  s.dxb = c.take<bf16_t>((size_t)d.M * d.D);
+  s.dact = c.take<bf16_t>((size_t)d.M * d.F);
+  s.dgu = c.take<bf16_t>((size_t)d.M * 2 * d.F);
+  s.dao = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
+  s.dot = c.take<bf16_t>((size_t)B * d.nq * d.hd * d.Lp);
+  s.delta = c.take<float>((size_t)B * d.nq * L);
+  s.dq = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
+  s.dk = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
+  s.dv = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
+  s.dqkv = c.take<bf16_t>((size_t)d.M * d.NQKV);
+  const int sp = pick_splits(nl, d.D, w->vocab_pad);
+  s.skws = c.take<float>((size_t)ta_gemm_splitk_ws_bytes(nl, d.D, sp) / 4 + 4);
+  s.bytes = c.total();
+  return s;
+}
+}  // namespace
+
+extern "C" long ta_lm_tape_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows) {
+  LmLayerTape store[MAX_LM_LAYERS];
+  if (w->n_layers > MAX_LM_LAYERS) return -1;
+  return (long)lm_tape(w, B, L, n_label_rows, nullptr, store).bytes;
+}
+extern "C" long ta_lm_workspace_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows) {
+  return (long)lm_ws(w, B, L, n_label_rows, nullptr).bytes;
+}
+
+extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio,
+                                  const int* kmask, const int* pos, int B, int L, const int* label_rows,
+                                  const long* label_targets, int n_lab, float loss_scale, float* loss, float* nll_rows,
+                                  void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (w->n_layers > MAX_LM_LAYERS || w->head_dim != 128 || w->hidden % 128 || w->ffn % 64 || w->vocab_pad % 128 ||
+      w->vocab > w->vocab_pad || L > w->max_pos)
+    return TA_ERR_ARG;
+  const LmDims d = lm_dims(w, B, L);
+  const int M = (int)d.M;
+  LmLayerTape store[MAX_LM_LAYERS];
+  LmTape t = lm_tape(w, B, L, n_lab, tape, store);
+  LmWs s = lm_ws(w, B, L, n_lab, ws);
+  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
+  const float scale = 1.0f / sqrtf((float)d.hd);
+  float* x = store[0].x_in;
+  // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
+  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
+  for (int l = 0; l < w->n_layers; ++l) {
+    const ta_lm_layer& Lw = w->layers[l];
+    LmLayerTape& p = store[l];
+    float* x_next = (l + 1 < w->n_layers) ? store[l + 1].x_in : t.x_final;
+    RC(ta_rmsnorm_fwd(p.x_in, Lw.ln_in_w, s.xn, nullptr, p.r_in, M, d.D, w->eps, 0, st));
+    RC(gemm(s.xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
+                          p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
+    RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    RC(gemm(p.ao, Lw.wo, p.x1, M, d.D, d.nq * d.hd, nullptr, p.x_in, 0, 0, st));
+    RC(ta_rmsnorm_fwd(p.x1, Lw.ln_post_w, s.xn, nullptr, p.r_post, M, d.D, w->eps, 0, st));
+    RC(gemm(s.xn, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_swiglu_fwd(p.gu, s.act, M, d.F, st));
+    RC(gemm(s.act, Lw.wd, x_next, M, d.D, d.F, nullptr, p.x1, 0, 0, st));
+  }
+  RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
+  if (logits_out)   // the reference's outputs.logits (bf16 under autocast), all positions
+    RC(gemm(t.hn, w->embed_bf16, logits_out, M, w->vocab_pad, d.D, nullptr, nullptr, 0, 1, st));
+  if (n_lab > 0) {
+    // loss (and dlogits for backward) only over the positions that carry a label: identical value, the
+    // ignored rows contribute exactly zero to both loss and gradient.
+    RC(ta_gather_rows_bf16(t.hn, label_rows, s.hl, n_lab, d.D, st));
+    RC(gemm(s.hl, w->embed_bf16, s.logits, n_lab, w->vocab_pad, d.D, nullptr, nullptr, 0, 0, st));
+    RC(ta_cross_entropy(s.logits, 0, w->vocab_pad, nullptr, label_targets, n_lab, w->vocab, loss_scale, nll_rows, loss,
+                        t.dlogits, w->vocab_pad, st));
+  }
+  return TA_OK;
+}
+
+extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
+                              const int* label_rows, int n_lab, float* d_audio, long n_audio_rows, float* d_embeds,
+                              const void* tape, void* ws, long ws_bytes, hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (w->n_layers > MAX_LM_LAYERS) return TA_ERR_ARG;
+  const LmDims d = lm_dims(w, B, L);
+  const int M = (int)d.M;
+  LmLayerTape store[MAX_LM_LAYERS];
+  LmTape t = lm_tape(w, B, L, n_lab, (void*)tape, store);
+  LmWs s = lm_ws(w, B, L, n_lab, ws);
+  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
+  const float scale = 1.0f / sqrtf((float)d.hd);
+  if (d_audio && hipMemsetAsync(d_audio, 0, (size_t)n_audio_rows * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+  if (n_lab <= 0) {
+    if (d_embeds && hipMemsetAsync(d_embeds, 0, (size_t)M * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+    return TA_OK;
+  }
+  // d hidden (labelled rows) = dlogits x E   (split-K over the vocabulary), scattered back to all positions
+  const int sp = pick_splits(n_lab, d.D, w->vocab_pad);
+  RC(ta_gemm_bf16_nt(t.dlogits, w->embed_t_bf16, s.dhl, n_lab, d.D, w->vocab_pad, w->vocab_pad, 0, 0, d.D, 0, 0, 0, nullptr,
+                     nullptr, 0, 0, sp, s.skws, st));
+  if (hipMemsetAsync(s.dhn, 0, (size_t)M * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+  RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
+  float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
+  float* dx_alt = s.dxb32;
+  RC(ta_rmsnorm_bwd(s.dhn, t.x_final, t.r_f, w->norm_w, nullptr, dx, s.dxb, nullptr, M, d.D, 0, st));
+  for (int l = w->n_layers - 1; l >= 0; --l) {
+    const ta_lm_layer& Lw = w->layers[l];
+    const LmLayerTape& p = store[l];
+    // ---- MLP: x2 = x1 + down(silu(gate) * up)
+    RC(gemm(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
+    RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, 0, st));
+    RC(ta_rmsnorm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt, s.dxb, nullptr, M, d.D, 0, st));
+    // ---- attention: x1 = x + o_proj(attn)
+    RC(gemm(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
+    RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
+                        B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv, B,
+                          d.nq, d.nkv, L, st));
+    RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, 0, st));
+    RC(ta_rmsnorm_bwd(s.dxn, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, s.dxb, nullptr, M, d.D, 0, st));
+  }
+  if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return TA_ERR_LAUNCH;
+  if (d_audio && src_row) RC(ta_audio_grad_gather(src_row, dx, d_audio, M, d.D, st));
+  return TA_OK;
+}

@@ -1,0 +1,474 @@
+// ta355 fused attention (flash-style, online softmax, MFMA 16x16x32 bf16), gfx950.
+//
+//   attn_fwd_kernel<64,false>   GLM-ASR encoder self-attention: non-causal, NO mask (padded frames are
+//                               attended to, exactly as the reference does), 20 heads x 64
+//                               (TF:models/glmasr/modeling_glmasr.py:187-217)
+//   attn_fwd_kernel<128,true>   Qwen3 attention: causal + key-padding mask, GQA 16q/8kv x 128
+//                               (TF:models/qwen3/modeling_qwen3.py:185-208,264-275)
+//   attn_bwd_dq_kernel / attn_bwd_dkv_kernel   activation gradients of the latter (frozen LM, dX only)
+//
+// Formulation: everything is computed TRANSPOSED so that the softmax row (one query) lives in one
+// lane column:  S^T[key,q] = K Q^T  -> lane holds q = lane&15 and 4 consecutive keys per 16-key
+// sub-tile.  Row max / sum need only two cross-lane steps (xor 16, 32); the running rescale of
+// O^T[d,q] is lane-local; P^T feeds the second MFMA as the B operand straight from registers (the
+// MFMA k-slot permutation is applied identically to the A operand, read from a [d][key] image of V).
+// That image comes from the producer (qkv_post kernels write V^T / K^T / Q^T / dO^T copies: HBM is
+// plentiful, LDS transposes are not free), so every LDS tile here is a plain row-major copy:
+//   "row tiles"  [64 rows][HD]   stride HD*2+32 B  -> conflict-free ds_read_b128 fragments
+//   "col tiles"  [HD rows][64]   stride 144 B      -> conflict-free ds_read_b64 fragment halves
+#include "common.h"
+
+#define KV_TILE 64
+#define CT_STRIDE 144          // bytes, [d][64 keys] tiles
+#define LOG2E 1.4426950408889634f
+#define NEG_BIG (-1.0e30f)
+
+template <int HD> struct RowTile { static constexpr int STRIDE = HD * 2 + 32; static constexpr int BYTES = 64 * STRIDE; };
+template <int HD> struct ColTile { static constexpr int BYTES = HD * CT_STRIDE; };
+
+// ---- staging helpers: global -> registers (issued early) -> LDS (written after the barrier)
+template <int HD>
+struct RowStage {   // 64 rows x HD bf16, 256 threads
+  static constexpr int N = HD / 32;   // 16-byte chunks per thread
+  uint4 v[N];
+  __device__ __forceinline__ void load(const bf16_t* base, long row_stride, int row0, int nrows_valid, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch / (HD / 8), c = ch % (HD / 8);
+      int gr = row0 + r; if (gr > nrows_valid - 1) gr = nrows_valid - 1; if (gr < 0) gr = 0;
+      v[i] = *(const uint4*)(base + (long)gr * row_stride + c * 8);
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch / (HD / 8), c = ch % (HD / 8);
+      *(uint4*)(lds + r * RowTile<HD>::STRIDE + c * 16) = v[i];
+    }
+  }
+};
+template <int HD>
+struct ColStage {   // HD rows x 64 bf16 (128 B per row) from a [.., HD, Lp] image
+  static constexpr int N = HD / 32;
+  uint4 v[N];
+  __device__ __forceinline__ void load(const bf16_t* base, int Lp, int col0, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch >> 3, c = ch & 7;
+      v[i] = *(const uint4*)(base + (long)r * Lp + col0 + c * 8);
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch >> 3, c = ch & 7;
+      *(uint4*)(lds + r * CT_STRIDE + c * 16) = v[i];
+    }
+  }
+};
+
+__device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
+  union { bf16x8 v; uint32_t u[4]; } r;
+  r.u[0] = pack2bf(a[0], a[1]); r.u[1] = pack2bf(a[2], a[3]);
+  r.u[2] = pack2bf(b[0], b[1]); r.u[3] = pack2bf(b[2], b[3]);
+  return r.v;
+}
+__device__ __forceinline__ bf16x8 read_colfrag(const char* tile, int row, int c0, int c1) {
+  // two 8-byte halves: columns [c0, c0+4) and [c1, c1+4) of row `row`
+  union { bf16x8 v; uint2 h[2]; } r;
+  r.h[0] = *(const uint2*)(tile + row * CT_STRIDE + c0 * 2);
+  r.h[1] = *(const uint2*)(tile + row * CT_STRIDE + c1 * 2);
+  return r.v;
+}
+
+// ============================================================================ forward
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ VT, bf16_t* __restrict__ O,
+                                                       float* __restrict__ LSE, const int* __restrict__ kmask,
+                                                       int Hq, int Hkv, int L, int Lp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + RowTile<HD>::BYTES;
+  int* Ms = (int*)(Vs + ColTile<HD>::BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (Hq / Hkv);
+  const int q0 = qt * 64;
+  const int qrow = q0 + wave * 16 + l15;
+  const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
+  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
+  const bf16_t* Vb = VT + ((long)(b * Hkv + hk) * HD) * Lp;
+  const float sl2 = scale * LOG2E;
+
+  bf16x8 qf[HD / 32];
+  {
+    const int qr = qrow < L ? qrow : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+  }
+  f32x4 o[HD / 16];
+#pragma unroll
+  for (int i = 0; i < HD / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  if (CAUSAL) { const int lim = qt + 1; if (lim < ntiles) ntiles = lim; }
+
+  RowStage<HD> ks_reg; ColStage<HD> vs_reg; int mk_reg = 1;
+  ks_reg.load(Kb, HD, 0, L, tid);
+  vs_reg.load(Vb, Lp, 0, tid);
+  if (kmask && tid < 64) mk_reg = (tid < L) ? kmask[(long)b * L + tid] : 0;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * KV_TILE;
+    ks_reg.store(Ks, tid);
+    vs_reg.store(Vs, tid);
+    if (tid < 64) Ms[tid] = mk_reg;
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      ks_reg.load(Kb, HD, key0 + KV_TILE, L, tid);
+      vs_reg.load(Vb, Lp, key0 + KV_TILE, tid);
+      if (kmask && tid < 64) { const int kk = key0 + KV_TILE + tid; mk_reg = (kk < L) ? kmask[(long)b * L + kk] : 0; }
+    }
+    // ---- S^T = K Q^T
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Ks + (kt * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2);
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- mask + online softmax (query = this lane's column)
+    float mloc = NEG_BIG;
+    bool ok[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
+      const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + g * 4 + r;
+        bool v = key < L;
+        if (CAUSAL) v = v && (key <= qrow);
+        if (kmask) v = v && (mkv[r] != 0);
+        ok[kt][r] = v;
+        if (v) mloc = fmaxf(mloc, s[kt][r]);
+      }
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = exp2f((m_run - m_new) * sl2);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = ok[kt][r] ? exp2f((s[kt][r] - m_new) * sl2) : 0.f;
+        s[kt][r] = p;
+        lsum += p;
+      }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < HD / 16; ++i) { o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha; }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      const bf16x8 pb = pack_p(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const bf16x8 va = read_colfrag(Vs, dt * 16 + l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qrow < L) {
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* orow = O + ((long)b * L + qrow) * ((long)Hq * HD) + (long)h * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      uint2 w;
+      w.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
+      w.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+      *(uint2*)(orow + dt * 16 + g * 4) = w;
+    }
+    if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run * scale + __logf(l_run) : 1.0e30f;
+  }
+}
+
+// ============================================================================ backward: dQ
+// grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT,
+                                                          const bf16_t* __restrict__ dO, long dO_stride,
+                                                          const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                          const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
+                                                          int Hq, int Hkv, int L, int Lp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = Ks + RowTile<HD>::BYTES;
+  char* KTs = Vs + RowTile<HD>::BYTES;
+  int* Ms = (int*)(KTs + ColTile<HD>::BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (Hq / Hkv);
+  const int qrow = qt * 64 + wave * 16 + l15;
+  const int qr = qrow < L ? qrow : L - 1;
+  const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
+  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
+  const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
+  const bf16_t* KTb = KT + ((long)(b * Hkv + hk) * HD) * Lp;
+  const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;   // token-major rows
+  const float sl2 = scale * LOG2E;
+  bf16x8 qf[HD / 32], dof[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) {
+    qf[ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+    dof[ks] = *(const bf16x8*)(dOb + (long)qr * dO_stride + ks * 32 + g * 8);
+  }
+  const float lse2 = LSE[(long)(b * Hq + h) * L + qr] * LOG2E;
+  const float delta = Delta[(long)(b * Hq + h) * L + qr];
+  f32x4 dq[HD / 16];
+#pragma unroll
+  for (int i = 0; i < HD / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  if (CAUSAL) { const int lim = qt + 1; if (lim < ntiles) ntiles = lim; }
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * KV_TILE;
+    {
+      RowStage<HD> a; a.load(Kb, HD, key0, L, tid); a.store(Ks, tid);
+      RowStage<HD> c; c.load(Vb, HD, key0, L, tid); c.store(Vs, tid);
+      ColStage<HD> d; d.load(KTb, Lp, key0, tid); d.store(KTs, tid);
+      if (tid < 64) { const int kk = key0 + tid; Ms[tid] = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const int off = (kt * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2;
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp[kt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
+      const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + kt * 16 + g * 4 + r;
+        bool v = (mkv[r] != 0) && (qrow < L);
+        if (CAUSAL) v = v && (key <= qrow);
+        const float p = v ? exp2f(s[kt][r] * sl2 - lse2) : 0.f;
+        s[kt][r] = p * (dp[kt][r] - delta) * scale;
+      }
+    }
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      const bf16x8 dsb = pack_p(s[2 * kp], s[2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const bf16x8 ka = read_colfrag(KTs, dt * 16 + l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (qrow < L) {
+    bf16_t* drow = dQ + ((long)(b * Hq + h) * L + qrow) * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      uint2 w; w.x = pack2bf(dq[dt][0], dq[dt][1]); w.y = pack2bf(dq[dt][2], dq[dt][3]);
+      *(uint2*)(drow + dt * 16 + g * 4) = w;
+    }
+  }
+}
+
+// ============================================================================ backward: dK, dV
+// grid (key tiles, Hkv, B); loops over the Hq/Hkv query heads of the group and over query tiles.
+//   dV^T[d,key] += dO^T[d,q] P[q,key]      dK^T[d,key] += Q^T[d,q] dS[q,key]
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
+                                                           const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                           const bf16_t* __restrict__ dO, long dO_stride,
+                                                           const bf16_t* __restrict__ dOT,
+                                                           const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                           const int* __restrict__ kmask, bf16_t* __restrict__ dK,
+                                                           bf16_t* __restrict__ dV, int Hq, int Hkv, int L, int Lp,
+                                                           float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = Qs + RowTile<HD>::BYTES;
+  char* QTs = dOs + RowTile<HD>::BYTES;
+  char* dOTs = QTs + ColTile<HD>::BYTES;
+  float* Ls = (float*)(dOTs + ColTile<HD>::BYTES);   // [64] lse * log2e
+  float* Ds = Ls + 64;                               // [64] delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int kt_idx = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int grp = Hq / Hkv;
+  const int krow = kt_idx * 64 + wave * 16 + l15;
+  const int kr = krow < L ? krow : L - 1;
+  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
+  const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
+  const float sl2 = scale * LOG2E;
+  bf16x8 kf[HD / 32], vf[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) {
+    kf[ks] = *(const bf16x8*)(Kb + (long)kr * HD + ks * 32 + g * 8);
+    vf[ks] = *(const bf16x8*)(Vb + (long)kr * HD + ks * 32 + g * 8);
+  }
+  const bool kvalid = (krow < L) && (kmask ? kmask[(long)b * L + kr] != 0 : true);
+  f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+  for (int i = 0; i < HD / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const int nq = (L + 63) / 64;
+  const int qt_begin = CAUSAL ? kt_idx : 0;
+  for (int hh = 0; hh < grp; ++hh) {
+    const int h = hk * grp + hh;
+    const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
+    const bf16_t* QTb = QT + ((long)(b * Hq + h) * HD) * Lp;
+    const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;
+    const bf16_t* dOTb = dOT + ((long)(b * Hq + h) * HD) * Lp;
+    for (int qt = qt_begin; qt < nq; ++qt) {
+      const int q0 = qt * 64;
+      {
+        RowStage<HD> a; a.load(Qb, HD, q0, L, tid); a.store(Qs, tid);
+        RowStage<HD> c; c.load(dOb, dO_stride, q0, L, tid); c.store(dOs, tid);
+        ColStage<HD> d; d.load(QTb, Lp, q0, tid); d.store(QTs, tid);
+        ColStage<HD> e; e.load(dOTb, Lp, q0, tid); e.store(dOTs, tid);
+        if (tid < 64) {
+          const int qq = q0 + tid;
+          const bool v = qq < L;
+          Ls[tid] = v ? LSE[(long)(b * Hq + h) * L + qq] * LOG2E : 1.0e30f;
+          Ds[tid] = v ? Delta[(long)(b * Hq + h) * L + qq] : 0.f;
+        }
+      }
+      __syncthreads();
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int qs = 0; qs < 4; ++qs) {
+        s[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          const int off = (qs * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2;
+          s[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + off), kf[ks], s[qs], 0, 0, 0);
+          dp[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dOs + off), vf[ks], dp[qs], 0, 0, 0);
+        }
+      }
+      f32x4 ds[4];
+#pragma unroll
+      for (int qs = 0; qs < 4; ++qs) {
+        const float4 ls = *(const float4*)(Ls + qs * 16 + g * 4);
+        const float4 dl = *(const float4*)(Ds + qs * 16 + g * 4);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+        const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = q0 + qs * 16 + g * 4 + r;
+          bool v = kvalid && (q < L);
+          if (CAUSAL) v = v && (krow <= q);
+          const float p = v ? exp2f(s[qs][r] * sl2 - lsv[r]) : 0.f;
+          s[qs][r] = p;
+          ds[qs][r] = p * (dp[qs][r] - dlv[r]) * scale;
+        }
+      }
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const bf16x8 pb = pack_p(s[2 * qp], s[2 * qp + 1]);
+        const bf16x8 dsb = pack_p(ds[2 * qp], ds[2 * qp + 1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          const int c0 = (2 * qp) * 16 + g * 4, c1 = (2 * qp + 1) * 16 + g * 4;
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag(dOTs, dt * 16 + l15, c0, c1), pb, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag(QTs, dt * 16 + l15, c0, c1), dsb, dk[dt], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (krow < L) {
+    bf16_t* kro = dK + ((long)(b * Hkv + hk) * L + krow) * HD;
+    bf16_t* vro = dV + ((long)(b * Hkv + hk) * L + krow) * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      uint2 w; w.x = pack2bf(dk[dt][0], dk[dt][1]); w.y = pack2bf(dk[dt][2], dk[dt][3]);
+      *(uint2*)(kro + dt * 16 + g * 4) = w;
+      uint2 u; u.x = pack2bf(dv[dt][0], dv[dt][1]); u.y = pack2bf(dv[dt][2], dv[dt][3]);
+      *(uint2*)(vro + dt * 16 + g * 4) = u;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- C-ABI
+template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + ColTile<HD>::BYTES + 64 * 4; }
+
+extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask,
+                                int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                                hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(L, 64), Hq, B), blk(256);
+#define FWD(HD_, C_)                                                                                              \
+  hipLaunchKernelGGL((attn_fwd_kernel<HD_, C_>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
+                     (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, Hq, Hkv, L, Lp, scale)
+  if (head_dim == 64 && !causal) FWD(64, false);
+  else if (head_dim == 64 && causal) FWD(64, true);
+  else if (head_dim == 128 && causal) FWD(128, true);
+  else if (head_dim == 128 && !causal) FWD(128, false);
+  else return TA_ERR_ARG;
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V,
+                                const void* dO, long dO_stride, const void* dOT, const float* LSE, const float* Delta,
+                                const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp,
+                                int head_dim, int causal, float scale, hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
+  constexpr int HD = 128;
+  const size_t lds_q = 2 * RowTile<HD>::BYTES + ColTile<HD>::BYTES + 64 * 4;
+  const size_t lds_kv = 2 * RowTile<HD>::BYTES + 2 * ColTile<HD>::BYTES + 128 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    attr_done = true;
+  }
+  dim3 gq(ta_cdiv(L, 64), Hq, B), gk(ta_cdiv(L, 64), Hkv, B), blk(256);
+  if (causal) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
+                       (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
+                       kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
+                       (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
+                       kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
+  }
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}

@@ -1,0 +1,284 @@
+// ta355 GEMM:  C[M,N] = epilogue( A[M,K] (bf16) x W[N,K]^T (bf16) ), fp32 accumulate on MFMA.
+//
+// Every linear layer of the hot path is y = x W^T with W stored [out, in] (nn.Linear), so one
+// "NT" kernel serves the whole step: frozen weights additionally keep a transposed bf16 copy so
+// that the dX = dY W backward is NT as well (288 GB of HBM makes the second copy free).
+//
+// Structure (gfx950): 128x128x64 tile, 256 threads = 4 waves in 2x2, each wave 64x64 as 4x4
+// v_mfma_f32_16x16x32_bf16 accumulators.  Tiles are staged HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip), double buffered (2 x 32 KiB), one barrier per
+// K-step.  The LDS image is lane-linear (required by the DMA), so the bank-conflict-free XOR
+// swizzle is applied to the per-lane *source* chunk and undone on the ds_read_b128 side.
+// Operands are swapped in the MFMA (D^T = W_frag x A_frag) so that each lane owns 4 consecutive
+// output columns of one row: 8-byte (bf16) / 16-byte (f32) stores, bias as one float4.
+//
+// A and C rows go through an affine "row map"  row -> (row / rpb) * batch_stride + (row % rpb) * ld
+// which expresses, with no im2col copy:
+//   * Conv1d(k=3) over a zero-padded [B, T+2, C] time-major buffer: ld = stride*C, K = 3*C
+//     (GlmAsrEncoder conv1/conv2, TF:models/glmasr/modeling_glmasr.py:299-300,314-315);
+//   * the projector's frame stacking [B,S,E] -> [B,S/k,k*E] incl. tail truncation
+//     (tiny_audio/projectors.py:79-87).
+#include "common.h"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;
+  const float* bias;   // [N] or null
+  const float* res;    // f32 residual, same row map as C, or null
+  int M, N, K;
+  long lda; int a_rpb; long a_bs;
+  long ldc; int c_rpb; long c_bs; long c_off;
+  int tiles_m, tiles_n, splits;
+  long slab_stride;    // elements between split-K slabs (C is f32 slabs when splits > 1)
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)   // 16 KiB
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int ACT, bool OUT_BF16, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  // ---- XCD-aware, grouped tile order (block b runs on XCD b % 8: give each XCD a contiguous chunk)
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  int t = bid - z * tiles;
+  const int GROUP_M = 8;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int m0 = pm * BM, n0 = pn * BN;
+
+  const int nkt = p.K / BK;
+  const int kt_begin = (int)(((long)nkt * z) / p.splits);
+  const int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+
+  // ---- per-thread DMA source pointers: 4 x 16 B chunks of A and of W per K-step
+  const int lr = tid >> 3;
+  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
+  const char* a_src[4];
+  const char* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = i * 32 + lr;
+    const int gm = min(m0 + r, p.M - 1);
+    const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+    a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
+    const int gn = min(n0 + r, p.N - 1);
+    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+  }
+  char* lds_w = smem + wave * 1024;   // + buf*2*TILE + (A:0 | W:TILE) + i*4096, lane*16 added by the DMA
+
+  // ---- per-lane fragment read offsets (bytes) inside a tile
+  const int swz = l15 >> 1;
+  const int a_rd = (wm * 64 + l15) * 128;
+  const int b_rd = (wn * 64 + l15) * 128;
+  const int koff0 = ((0 + g) ^ swz) << 4;
+  const int koff1 = ((4 + g) ^ swz) << 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int buf) {
+    char* base = lds_w + buf * (2 * TILE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i], base + i * 4096);
+      a_src[i] += BK * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(w_src[i], base + TILE_BYTES + i * 4096);
+      w_src[i] += BK * 2;
+    }
+  };
+
+  if (kt_begin < kt_end) stage(0);
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) stage(cur ^ 1);
+    const char* As = smem + cur * (2 * TILE_BYTES);
+    const char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ko = kk ? koff1 : koff0;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + a_rd + i * 2048 + ko);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(Bs + b_rd + j * 2048 + ko);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row m = .. + l15, columns n .. n+3 (n = .. + g*4)
+  char* Cb = (char*)p.C;
+  if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m >= p.M) continue;
+    const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (ACT == 1) {
+        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+      }
+      if (HAS_RES) {
+        const float4 r = *(const float4*)(p.res + roff + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if (OUT_BF16) {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)(Cb + (roff + n) * 2) = o;
+      } else {
+        *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// out[i] = (add ? add[i] : 0) + sum_z slab[z][i]  (f32 and/or bf16 out; add may alias out); n4 = count / 4
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long slab_stride, const float* add,
+                                     float* out, bf16_t* __restrict__ out_bf, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 s = add ? ((const float4*)add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 v = ((const float4*)(slabs + (long)z * slab_stride))[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (out) ((float4*)out)[i] = s;
+    if (out_bf) {
+      uint2 o; o.x = pack2bf(s.x, s.y); o.y = pack2bf(s.z, s.w);
+      ((uint2*)out_bf)[i] = o;
+    }
+  }
+}
+
+// ---- optional in-situ timing of every GEMM launch (bench.py's roofline leg): HIP events recorded on the
+//      launch stream around the kernel, summed after the fact.  Off by default (zero overhead).
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+template <int ACT, bool OUT_BF16, bool HAS_RES>
+static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  const int grid = a.tiles_m * a.tiles_n * a.splits;
+  ProfRec r;
+  if (g_prof_on) {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return TA_ERR_LAUNCH;
+    r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
+    (void)hipEventRecord(r.a, st);
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+extern "C" int ta_profile_gemm(int enable) { g_prof_on = enable != 0; return TA_OK; }
+// sums (and clears) the recorded launches: total kernel milliseconds, total algorithmic flops (2*M*N*K), launch count
+extern "C" int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launches) {
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return TA_ERR_LAUNCH;
+    ms += t; fl += r.flops;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (long)g_prof.size();
+  g_prof.clear();
+  return TA_OK;
+}
+
+// ----------------------------------------------------------------------------- C-ABI (see include/ta355.h)
+extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K,
+                               long lda, int a_rpb, long a_bs,
+                               long ldc, int c_rpb, long c_bs, long c_off,
+                               const float* bias, const float* residual,
+                               int act, int out_bf16, int splits, float* splitk_ws, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return TA_OK;
+  if ((K % BK) != 0 || (N % 4) != 0 || (lda % 8) != 0 || (a_bs % 8) != 0 || (ldc % 4) != 0 ||
+      (c_off % 4) != 0 || (c_bs % 4) != 0)
+    return TA_ERR_ARG;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = C; a.bias = bias; a.res = residual;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.a_rpb = a_rpb > 0 ? a_rpb : M; a.a_bs = a_bs;
+  a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : M; a.c_bs = c_bs; a.c_off = c_off;
+  a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
+  a.splits = splits > 1 ? splits : 1;
+  if (a.splits > K / BK) a.splits = K / BK;
+  a.slab_stride = (long)M * N;
+  if (a.splits > 1) {
+    // partial slabs are plain [M, N] f32; the epilogue (none) is applied by the reduce.
+    if (!splitk_ws || act != 0 || bias || a.c_rpb != M || ldc != N || c_off != 0) return TA_ERR_ARG;
+    GemmArgs s = a;
+    s.C = splitk_ws; s.res = nullptr; s.bias = nullptr;
+    int rc = launch_gemm<0, false, false>(s, st);
+    if (rc) return rc;
+    const long n4 = (long)M * N / 4;
+    int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)splitk_ws,
+                       a.splits, a.slab_stride, residual, out_bf16 ? nullptr : (float*)C,
+                       out_bf16 ? (bf16_t*)C : nullptr, n4);
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
+  const bool hr = residual != nullptr;
+  if (act == 0) {
+    if (out_bf16) return hr ? launch_gemm<0, true, true>(a, st) : launch_gemm<0, true, false>(a, st);
+    return hr ? launch_gemm<0, false, true>(a, st) : launch_gemm<0, false, false>(a, st);
+  } else if (act == 1) {
+    if (out_bf16) return hr ? launch_gemm<1, true, true>(a, st) : launch_gemm<1, true, false>(a, st);
+    return hr ? launch_gemm<1, false, true>(a, st) : launch_gemm<1, false, false>(a, st);
+  }
+  return TA_ERR_ARG;
+}
+
+extern "C" long ta_gemm_splitk_ws_bytes(int M, int N, int splits) {
+  return splits > 1 ? (long)M * N * 4 * splits : 0;
+}

@@ -1,0 +1,228 @@
+// ta355 row-normalisation kernels (HBM-bound): one 64-lane wave per row, the row held in
+// registers (float4 per lane, up to 5120 columns), wave-shuffle reductions, 16-byte accesses.
+//
+//   layernorm_kernel     nn.LayerNorm of the GLM-ASR encoder  (TF:models/glmasr/modeling_glmasr.py:246-247,305)
+//   rmsnorm_fwd_kernel   Qwen3RMSNorm / LlamaRMSNorm            (TF:models/qwen3/modeling_qwen3.py:50-64;
+//                        tiny_audio/projectors.py:43,50), optionally fused with the projector's erf-GELU
+//   rmsnorm_bwd_kernel   its backward (dx, optional dw, optional GELU' prologue, optional residual add)
+#include "common.h"
+
+#define MAXV_LIMIT 20   // float4 per lane -> rows up to 64*4*20 = 5120 columns
+// MAXV (float4 per lane held in registers) is a template parameter: 4 (H<=1024), 8 (<=2048), 20 (<=5120)
+
+template <int MAXV, bool OUT_BF16, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ yb,
+                                                        float* __restrict__ yf, const float* __restrict__ rowscale,
+                                                        int M, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = H >> 2;
+  const float4* xr = (const float4*)(x + (long)row * H);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, bq = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + bq * bq + cq * cq + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  const float rs = rowscale ? rowscale[row] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 ww = ((const float4*)w)[c], bb = ((const float4*)b)[c];
+      float4 o;
+      o.x = ((v[i].x - mean) * rstd * ww.x + bb.x) * rs;
+      o.y = ((v[i].y - mean) * rstd * ww.y + bb.y) * rs;
+      o.z = ((v[i].z - mean) * rstd * ww.z + bb.z) * rs;
+      o.w = ((v[i].w - mean) * rstd * ww.w + bb.w) * rs;
+      if (OUT_F32) ((float4*)(yf + (long)row * H))[c] = o;
+      if (OUT_BF16) {
+        uint2 p; p.x = pack2bf(o.x, o.y); p.y = pack2bf(o.z, o.w);
+        ((uint2*)(yb + (long)row * H))[c] = p;
+      }
+    }
+  }
+}
+
+// y = w * (x * rstd)   [ACT==1: y = gelu(y)];  x f32 [M,H]
+template <int MAXV, int ACT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ yb, float* __restrict__ yf,
+                                                          float* __restrict__ rstd_out, int M, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = H >> 2;
+  const float4* xr = (const float4*)(x + (long)row * H);
+  float4 v[MAXV];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) { v[i] = xr[c]; q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 ww = ((const float4*)w)[c];
+      float4 o;
+      o.x = v[i].x * rstd * ww.x; o.y = v[i].y * rstd * ww.y;
+      o.z = v[i].z * rstd * ww.z; o.w = v[i].w * rstd * ww.w;
+      if (ACT == 1) { o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w); }
+      if (yf) ((float4*)(yf + (long)row * H))[c] = o;
+      if (yb) {
+        uint2 p; p.x = pack2bf(o.x, o.y); p.y = pack2bf(o.z, o.w);
+        ((uint2*)(yb + (long)row * H))[c] = p;
+      }
+    }
+  }
+}
+
+// Backward of y = act(w * x * rstd):
+//   dn = dy * act'(n)           (ACT==1, n = w*x*rstd recomputed)
+//   dx = rstd * (dn*w - xh * mean(dn*w*xh)),  xh = x*rstd        (+ dres if given)
+//   dw += sum_rows dn * xh      (if dw != null; LDS partials + one atomicAdd per column per block)
+template <int MAXV, int ACT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ rstd_in,
+                                                          const float* __restrict__ w, const float* dres,
+                                                          float* dxf, bf16_t* __restrict__ dxb,
+                                                          float* __restrict__ dw, int M, int H) {
+  extern __shared__ float dw_part[];   // [H] when dw != null
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nv = H >> 2;
+  if (dw) {
+    for (int i = threadIdx.x; i < H; i += 256) dw_part[i] = 0.f;
+    __syncthreads();
+  }
+  // each block handles rows_per_block consecutive groups of 4 rows (grid-stride) so dw atomics stay few
+  for (int row0 = blockIdx.x * 4; row0 < M; row0 += gridDim.x * 4) {
+    const int row = row0 + wv;
+    if (row < M) {
+      const float r = rstd_in[row];
+      const float4* xr = (const float4*)(x + (long)row * H);
+      const float4* dr = (const float4*)(dy + (long)row * H);
+      float4 xh[MAXV], dn[MAXV];
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+          const float4 xv = xr[c], dv = dr[c], ww = ((const float4*)w)[c];
+          xh[i] = make_float4(xv.x * r, xv.y * r, xv.z * r, xv.w * r);
+          float4 d = dv;
+          if (ACT == 1) {
+            d.x *= gelu_erf_grad(xh[i].x * ww.x); d.y *= gelu_erf_grad(xh[i].y * ww.y);
+            d.z *= gelu_erf_grad(xh[i].z * ww.z); d.w *= gelu_erf_grad(xh[i].w * ww.w);
+          }
+          if (dw) {
+            atomicAdd(&dw_part[c * 4 + 0], d.x * xh[i].x); atomicAdd(&dw_part[c * 4 + 1], d.y * xh[i].y);
+            atomicAdd(&dw_part[c * 4 + 2], d.z * xh[i].z); atomicAdd(&dw_part[c * 4 + 3], d.w * xh[i].w);
+          }
+          dn[i] = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
+          dot += dn[i].x * xh[i].x + dn[i].y * xh[i].y + dn[i].z * xh[i].z + dn[i].w * xh[i].w;
+        }
+      }
+      const float mdot = wave_sum(dot) / (float)H;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+          float4 o;
+          o.x = r * (dn[i].x - xh[i].x * mdot); o.y = r * (dn[i].y - xh[i].y * mdot);
+          o.z = r * (dn[i].z - xh[i].z * mdot); o.w = r * (dn[i].w - xh[i].w * mdot);
+          if (dres) {
+            const float4 e = ((const float4*)(dres + (long)row * H))[c];
+            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+          }
+          if (dxf) ((float4*)(dxf + (long)row * H))[c] = o;
+          if (dxb) {
+            uint2 p; p.x = pack2bf(o.x, o.y); p.y = pack2bf(o.z, o.w);
+            ((uint2*)(dxb + (long)row * H))[c] = p;
+          }
+        }
+      }
+    }
+  }
+  if (dw) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 256) atomicAdd(&dw[i], dw_part[i]);
+  }
+}
+
+// ----------------------------------------------------------------------------- C-ABI
+#define DISPATCH_MAXV(H, CALL)            \
+  do {                                    \
+    if ((H) <= 1024) { CALL(4); }         \
+    else if ((H) <= 2048) { CALL(8); }    \
+    else { CALL(20); }                    \
+  } while (0)
+
+extern "C" int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
+                                const float* rowscale, int M, int H, float eps, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT || (!y_bf16 && !y_f32)) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(M, 4)), blk(256);
+#define LN_CALL(V)                                                                                               \
+  if (y_bf16 && y_f32)                                                                                           \
+    hipLaunchKernelGGL((layernorm_kernel<V, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
+  else if (y_bf16)                                                                                               \
+    hipLaunchKernelGGL((layernorm_kernel<V, true, false>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps); \
+  else                                                                                                           \
+    hipLaunchKernelGGL((layernorm_kernel<V, false, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);
+  DISPATCH_MAXV(H, LN_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+extern "C" int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd,
+                              int M, int H, float eps, int act_gelu, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(M, 4)), blk(256);
+#define RF_CALL(V)                                                                                                 \
+  if (act_gelu)                                                                                                    \
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<V, 1>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps); \
+  else                                                                                                             \
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<V, 0>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
+  DISPATCH_MAXV(H, RF_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+extern "C" int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd, const float* w,
+                              const float* dres, float* dx_f32, void* dx_bf16, float* dw_accum,
+                              int M, int H, int act_gelu, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  int blocks = ta_cdiv(M, 4);
+  if (dw_accum && blocks > 512) blocks = 512;
+  const size_t lds = dw_accum ? (size_t)H * 4 : 0;
+#define RB_CALL(V)                                                                                             \
+  if (act_gelu)                                                                                                \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<V, 1>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
+                       dx_f32, (bf16_t*)dx_bf16, dw_accum, M, H);                                              \
+  else                                                                                                         \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<V, 0>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
+                       dx_f32, (bf16_t*)dx_bf16, dw_accum, M, H);
+  DISPATCH_MAXV(H, RB_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}

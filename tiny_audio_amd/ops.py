@@ -1,0 +1,221 @@
+"""Thin torch-tensor wrappers over the primitive kernels of libta355.so.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in the HIP library.
+Every wrapper launches on ``torch.cuda.current_stream()`` and raises ``Ta355Error`` on failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    if _lib.DRY_RUN:          # test instrumentation only (see _lib.DRY_RUN)
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype=None):
+    assert (t.is_cuda or _lib.DRY_RUN) and t.is_contiguous(), "ta355 ops need contiguous CUDA(HIP) tensors"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+    return t
+
+
+def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
+            a_map=None, c_map=None, splits=1):
+    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset)."""
+    _req(A, BF16); _req(W, BF16)
+    N = N or W.shape[0]
+    K = K or W.shape[1]
+    M = M or A.numel() // K
+    lda, a_rpb, a_bs = a_map or (K, 0, 0)
+    ldc, c_rpb, c_bs, c_off = c_map or (N, 0, 0, 0)
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype)
+    ws = None
+    if splits > 1:
+        ws = torch.empty(lib().ta_gemm_splitk_ws_bytes(M, N, splits) // 4, device=A.device, dtype=F32)
+    check(lib().ta_gemm_bf16_nt(ptr(A), ptr(W), ptr(out), M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off,
+                                ptr(bias), ptr(residual), act, 1 if out.dtype == BF16 else 0, splits, ptr(ws),
+                                stream()), "ta_gemm_bf16_nt")
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5, rowscale=None, out_bf16=True, out_f32=False):
+    _req(x, F32)
+    M, H = x.shape
+    yb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
+    yf = torch.empty((M, H), device=x.device, dtype=F32) if out_f32 else None
+    check(lib().ta_layernorm_f32(ptr(x), ptr(w), ptr(b), ptr(yb), ptr(yf), ptr(rowscale), M, H, eps, stream()),
+          "ta_layernorm_f32")
+    return yb, yf
+
+
+def rmsnorm_fwd(x, w, eps=1e-6, act_gelu=False, out_bf16=True, out_f32=False):
+    _req(x, F32)
+    M, H = x.shape
+    yb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
+    yf = torch.empty((M, H), device=x.device, dtype=F32) if out_f32 else None
+    r = torch.empty(M, device=x.device, dtype=F32)
+    check(lib().ta_rmsnorm_fwd(ptr(x), ptr(w), ptr(yb), ptr(yf), ptr(r), M, H, eps, int(act_gelu), stream()),
+          "ta_rmsnorm_fwd")
+    return yb, yf, r
+
+
+def rmsnorm_bwd(dy, x, rstd, w, dres=None, act_gelu=False, want_dw=False, out_bf16=True):
+    _req(dy, F32); _req(x, F32)
+    M, H = x.shape
+    dx = torch.empty((M, H), device=x.device, dtype=F32)
+    dxb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
+    dw = torch.zeros(H, device=x.device, dtype=F32) if want_dw else None
+    check(lib().ta_rmsnorm_bwd(ptr(dy), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), M, H,
+                               int(act_gelu), stream()), "ta_rmsnorm_bwd")
+    return dx, dxb, dw
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def attention_fwd(Q, K, VT, L, causal, scale, kmask=None, want_lse=True):
+    """Q [B,Hq,L,hd], K [B,Hkv,L,hd], VT [B,Hkv,hd,Lp] bf16 -> O [B*L, Hq*hd] bf16, LSE [B,Hq,L]."""
+    B, Hq, _, hd = Q.shape
+    Hkv, Lp = K.shape[1], VT.shape[3]
+    O = torch.empty((B * L, Hq * hd), device=Q.device, dtype=BF16)
+    lse = torch.empty((B, Hq, L), device=Q.device, dtype=F32) if want_lse else None
+    check(lib().ta_attention_fwd(ptr(Q), ptr(K), ptr(VT), ptr(O), ptr(lse), ptr(kmask), B, Hq, Hkv, L, Lp, hd,
+                                 int(causal), scale, stream()), "ta_attention_fwd")
+    return O, lse
+
+
+def attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, causal, scale, kmask=None):
+    B, Hq, _, hd = Q.shape
+    Hkv, Lp = K.shape[1], KT.shape[3]
+    dQ = torch.empty_like(Q); dK = torch.empty_like(K); dV = torch.empty_like(V)
+    check(lib().ta_attention_bwd(ptr(Q), ptr(QT), ptr(K), ptr(KT), ptr(V), ptr(dO), dO.shape[-1], ptr(dOT), ptr(lse),
+                                 ptr(delta), ptr(kmask), ptr(dQ), ptr(dK), ptr(dV), B, Hq, Hkv, L, Lp, hd, int(causal),
+                                 scale, stream()), "ta_attention_bwd")
+    return dQ, dK, dV
+
+
+def lm_qkv_post_fwd(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, eps=1e-6, pos=None):
+    hd, Lp, dev = 128, pad64(L), qkv0.device
+    mk = lambda h: torch.empty((B, h, L, hd), device=dev, dtype=BF16)
+    mkT = lambda h: torch.empty((B, h, hd, Lp), device=dev, dtype=BF16)
+    Q, K, V, QT, KT, VT = mk(Hq), mk(Hkv), mk(Hkv), mkT(Hq), mkT(Hkv), mkT(Hkv)
+    rq = torch.empty((B * L, Hq), device=dev, dtype=F32); rk = torch.empty((B * L, Hkv), device=dev, dtype=F32)
+    check(lib().ta_lm_qkv_post_fwd(ptr(qkv0), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(Q), ptr(K),
+                                   ptr(V), ptr(QT), ptr(KT), ptr(VT), ptr(rq), ptr(rk), B, Hq, Hkv, L, Lp, eps,
+                                   stream()), "ta_lm_qkv_post_fwd")
+    return Q, K, V, QT, KT, VT, rq, rk
+
+
+def lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, pos=None):
+    dqkv = torch.empty_like(qkv0)
+    check(lib().ta_lm_qkv_post_bwd(ptr(dQ), ptr(dK), ptr(dV), ptr(qkv0), ptr(rq), ptr(rk), ptr(qn_w), ptr(kn_w),
+                                   ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv, L, stream()),
+          "ta_lm_qkv_post_bwd")
+    return dqkv
+
+
+def enc_qkv_post(qkv, cosT, sinT, B, H, S):
+    Sp, dev = pad64(S), qkv.device
+    Q = torch.empty((B, H, S, 64), device=dev, dtype=BF16); K = torch.empty_like(Q)
+    VT = torch.empty((B, H, 64, Sp), device=dev, dtype=BF16)
+    check(lib().ta_enc_qkv_post(ptr(qkv), ptr(cosT), ptr(sinT), ptr(Q), ptr(K), ptr(VT), B, H, S, Sp, stream()),
+          "ta_enc_qkv_post")
+    return Q, K, VT
+
+
+def attn_bwd_prep(dO, O, B, Hq, L):
+    Lp, dev = pad64(L), dO.device
+    delta = torch.empty((B, Hq, L), device=dev, dtype=F32)
+    dOT = torch.empty((B, Hq, 128, Lp), device=dev, dtype=BF16)
+    check(lib().ta_attn_bwd_prep(ptr(dO), ptr(O), ptr(delta), ptr(dOT), B, Hq, L, Lp, stream()), "ta_attn_bwd_prep")
+    return delta, dOT
+
+
+def swiglu_fwd(gu, F):
+    M = gu.shape[0]
+    act = torch.empty((M, F), device=gu.device, dtype=BF16)
+    check(lib().ta_swiglu_fwd(ptr(gu), ptr(act), M, F, stream()), "ta_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(dact, gu, F):
+    dgu = torch.empty_like(gu)
+    check(lib().ta_swiglu_bwd(ptr(dact), ptr(gu), ptr(dgu), gu.shape[0], F, stream()), "ta_swiglu_bwd")
+    return dgu
+
+
+def cast_bf16(x):
+    _req(x, F32)
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    check(lib().ta_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()), "ta_cast_f32_bf16")
+    return y
+
+
+def transpose_to_bf16(x, ld_out=None, in_map=None):
+    """x [R, C] (f32 or bf16) -> bf16 [C, ld_out] (zero padded columns)."""
+    R, Cc = x.shape
+    ld_out = ld_out or R
+    ld_in, in_bs, in_rpb = in_map or (Cc, 0, 0)
+    out = torch.empty((Cc, ld_out), device=x.device, dtype=BF16)
+    check(lib().ta_transpose_to_bf16(ptr(x), int(x.dtype == F32), ld_in, in_bs, in_rpb, ptr(out), ld_out, R, Cc,
+                                     stream()), "ta_transpose_to_bf16")
+    return out
+
+
+def audio_index(ids, counts, N, audio_id):
+    B, L = ids.shape
+    src = torch.empty(B * L, device=ids.device, dtype=torch.int32)
+    check(lib().ta_audio_index(ptr(ids), ptr(counts), ptr(src), B, L, N, audio_id, stream()), "ta_audio_index")
+    return src
+
+
+def label_rows(labels):
+    B, L = labels.shape
+    rows = torch.empty(B * L, device=labels.device, dtype=torch.int32)
+    tg = torch.empty(B * L, device=labels.device, dtype=torch.int64)
+    n = torch.zeros(1, device=labels.device, dtype=torch.int32)
+    check(lib().ta_label_rows(ptr(labels), B, L, ptr(rows), ptr(tg), ptr(n), stream()), "ta_label_rows")
+    return rows, tg, n
+
+
+def cross_entropy(logits, targets, V, scale, rows=None, want_dlogits=True, ldd=None):
+    n = targets.shape[0]
+    ldl = logits.shape[1]
+    ldd = ldd or ldl
+    nll = torch.empty(n, device=logits.device, dtype=F32)
+    loss = torch.zeros(1, device=logits.device, dtype=F32)
+    dl = torch.empty((n, ldd), device=logits.device, dtype=BF16) if want_dlogits else None
+    check(lib().ta_cross_entropy(ptr(logits), int(logits.dtype == BF16), ldl, ptr(rows), ptr(targets), n, V, scale,
+                                 ptr(nll), ptr(loss), ptr(dl), ldd, stream()), "ta_cross_entropy")
+    return loss, nll, dl
+
+
+def bernoulli_keep(n, keep_prob, seed, device):
+    keep = torch.empty(n, device=device, dtype=F32)
+    check(lib().ta_bernoulli_keep(ptr(keep), n, keep_prob, seed, stream()), "ta_bernoulli_keep")
+    return keep
+
+
+def grad_sqnorm(g, accum):
+    check(lib().ta_grad_sqnorm(ptr(g), g.numel(), ptr(accum), stream()), "ta_grad_sqnorm")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_norm=0.0, grad_scale=1.0, denom=None):
+    check(lib().ta_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, ptr(sqnorm),
+                              max_norm, grad_scale, ptr(denom), stream()), "ta_adamw_step")
