@@ -274,10 +274,7 @@ def test_cast_transpose():
     assert torch.equal(t[:, :130], x.to(BF16).T.contiguous()) and float(t[:, 130:].float().abs().max()) == 0.0
     xb = rnd(4, 50, 64, seed=2).to(BF16)      # frame-stack row map: rows (b, n) = 4 frames, tail frames dropped
     N = (50 - 4) // 4 + 1
-    t = ops.transpose_to_bf16(xb.reshape(-1, 64)[:1], ld_out=64)  # smoke the bf16 path
     xs = xb[:, :N * 4].reshape(4 * N, 256)
-    fake = torch.empty(4 * N, 256, device=DEV, dtype=BF16)        # shape carrier: R = 4N, C = 256
-    import ctypes as C
     from tiny_audio_amd import _lib
     out = torch.empty(256, 64, device=DEV, dtype=BF16)
     _lib.check(_lib.lib().ta_transpose_to_bf16(ops.ptr(xb), 0, 256, 50 * 64, N, ops.ptr(out), 64, 4 * N, 256, ops.stream()))
@@ -295,11 +292,13 @@ def test_audio_index_and_scatter():
     y = rng.standard_normal((B, N, D)).astype(np.float32)
     emb = rng.standard_normal((V, D)).astype(np.float32)
     ref = OM.masked_scatter_rows(emb[ids], ids == AID, OM.gather_audio_embeds(y, counts))
-    src = ops.audio_index(torch.from_numpy(ids).to(DEV), torch.from_numpy(counts).to(DEV), N, AID)
+    ids_d, counts_d = torch.from_numpy(ids).to(DEV), torch.from_numpy(counts).to(DEV)     # keep every operand alive:
+    emb_d, y_d = torch.from_numpy(emb).to(DEV), torch.from_numpy(y).to(DEV)               # raw pointers hold no refs
+    src = ops.audio_index(ids_d, counts_d, N, AID)
     x0 = torch.empty(B * L, D, device=DEV)
     from tiny_audio_amd import _lib
-    _lib.check(_lib.lib().ta_embed_scatter(ops.ptr(torch.from_numpy(ids).to(DEV)), ops.ptr(src), ops.ptr(torch.from_numpy(emb).to(DEV)),
-                                           ops.ptr(torch.from_numpy(y).to(DEV)), ops.ptr(x0), None, B * L, D, V, ops.stream()))
+    _lib.check(_lib.lib().ta_embed_scatter(ops.ptr(ids_d), ops.ptr(src), ops.ptr(emb_d), ops.ptr(y_d), ops.ptr(x0), None,
+                                           B * L, D, V, ops.stream()))
     np.testing.assert_array_equal(x0.cpu().numpy().reshape(B, L, D), ref)
     dx0 = torch.randn(B * L, D, device=DEV)
     dy = torch.zeros(B * N, D, device=DEV)

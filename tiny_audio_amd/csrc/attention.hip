@@ -427,7 +427,7 @@ extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, vo
   if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(L, 64), Hq, B), blk(256);
 #define FWD(HD_, C_)                                                                                              \
-  hipLaunchKernelGGL((attn_fwd_kernel<HD_, C_>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
+  TA_LAUNCH((attn_fwd_kernel<HD_, C_>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
                      (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, Hq, Hkv, L, Lp, scale)
   if (head_dim == 64 && !causal) FWD(64, false);
   else if (head_dim == 64 && causal) FWD(64, true);
@@ -455,17 +455,17 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
   }
   dim3 gq(ta_cdiv(L, 64), Hq, B), gk(ta_cdiv(L, 64), Hkv, B), blk(256);
   if (causal) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
+    TA_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
                        (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
+    TA_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
                        kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
+    TA_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
                        (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
+    TA_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
                        kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
   }

@@ -12,6 +12,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;   // MFMA 16x16 C/D fra
 #define TA_ERR_ARG 1
 #define TA_ERR_LAUNCH 2
 
+// Launch through this macro: it first clears HIP's sticky "last error" (the host framework may have left a benign
+// one behind, e.g. from a pointer-attribute probe), so that TA_CHECK_LAUNCH reports only OUR launch's status.
+#define TA_LAUNCH(...)                \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 #define TA_CHECK_LAUNCH()                                  \
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \

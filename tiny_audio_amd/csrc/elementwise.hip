@@ -216,20 +216,20 @@ __global__ void bernoulli_keep_kernel(float* __restrict__ keep, long n, float ke
 extern "C" int ta_swiglu_fwd(const void* gu, void* act, long M, int F, hipStream_t st) {
   if (M <= 0) return TA_OK;
   if (F % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_blocks(M * (F / 4))), dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)act, M, F);
+  TA_LAUNCH(swiglu_fwd_kernel, dim3(ew_blocks(M * (F / 4))), dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)act, M, F);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_swiglu_bwd(const void* dact, const void* gu, void* dgu, long M, int F, hipStream_t st) {
   if (M <= 0) return TA_OK;
   if (F % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_blocks(M * (F / 4))), dim3(256), 0, st, (const bf16_t*)dact,
+  TA_LAUNCH(swiglu_bwd_kernel, dim3(ew_blocks(M * (F / 4))), dim3(256), 0, st, (const bf16_t*)dact,
                      (const bf16_t*)gu, (bf16_t*)dgu, M, F);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_cast_f32_bf16(const float* x, void* y, long n, hipStream_t st) {
   if (n <= 0) return TA_OK;
   if (n % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, x, (bf16_t*)y, n / 4);
+  TA_LAUNCH(cast_f32_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, x, (bf16_t*)y, n / 4);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_transpose_to_bf16(const void* in, int in_is_f32, long ld_in, long in_bs, int in_rpb, void* out,
@@ -239,58 +239,58 @@ extern "C" int ta_transpose_to_bf16(const void* in, int in_is_f32, long ld_in, l
   dim3 grid(ta_cdiv(C, 64), ta_cdiv(ld_out, 64));
   if (in_rpb <= 0) in_rpb = R;
   if (in_is_f32)
-    hipLaunchKernelGGL((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, in_bs, in_rpb,
+    TA_LAUNCH((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, in_bs, in_rpb,
                        (bf16_t*)out, ld_out, R, C);
   else
-    hipLaunchKernelGGL((transpose_to_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, in_bs, in_rpb,
+    TA_LAUNCH((transpose_to_bf16_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, in_bs, in_rpb,
                        (bf16_t*)out, ld_out, R, C);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_feats_to_time_major(const float* feats, void* out, int B, int C, int T, hipStream_t st) {
   if (B <= 0 || T <= 0) return TA_OK;
-  hipLaunchKernelGGL(feats_to_tm_kernel, dim3(ta_cdiv(T, 64), ta_cdiv(C, 64), B), dim3(256), 0, st, feats, (bf16_t*)out, C, T);
+  TA_LAUNCH(feats_to_tm_kernel, dim3(ta_cdiv(T, 64), ta_cdiv(C, 64), B), dim3(256), 0, st, feats, (bf16_t*)out, C, T);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_zero_pad_rows(void* buf, int B, int T, int C, hipStream_t st) {
   if (B <= 0) return TA_OK;
-  hipLaunchKernelGGL(zero_pad_rows_kernel, dim3(B), dim3(256), 0, st, (bf16_t*)buf, T, C);
+  TA_LAUNCH(zero_pad_rows_kernel, dim3(B), dim3(256), 0, st, (bf16_t*)buf, T, C);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_audio_index(const long* ids, const long* counts, int* src_row, int B, int L, int N, long audio_id,
                               hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (B > 1024) return TA_ERR_ARG;
-  hipLaunchKernelGGL(audio_index_kernel, dim3(1), dim3(1024), 0, st, ids, counts, src_row, B, L, N, audio_id);
+  TA_LAUNCH(audio_index_kernel, dim3(1), dim3(1024), 0, st, ids, counts, src_row, B, L, N, audio_id);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_embed_scatter(const long* ids, const int* src_row, const float* emb, const float* audio, float* x0,
                                 void* x0_bf16, int n_rows, int D, long vocab, hipStream_t st) {
   if (n_rows <= 0) return TA_OK;
   if (D % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, ids, src_row, emb, audio, x0,
+  TA_LAUNCH(embed_scatter_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, ids, src_row, emb, audio, x0,
                      (bf16_t*)x0_bf16, n_rows, D, vocab);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_audio_grad_gather(const int* src_row, const float* dx0, float* d_audio, int n_rows, int D, hipStream_t st) {
   if (n_rows <= 0) return TA_OK;
   if (D % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(audio_grad_gather_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, src_row, dx0, d_audio, n_rows, D);
+  TA_LAUNCH(audio_grad_gather_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, src_row, dx0, d_audio, n_rows, D);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st) {
   if (n <= 0) return TA_OK;
   if (D % 8) return TA_ERR_ARG;
-  hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(ta_cdiv(n, 4)), dim3(256), 0, st, (const bf16_t*)in, idx, (bf16_t*)out, n, D);
+  TA_LAUNCH(gather_rows_bf16_kernel, dim3(ta_cdiv(n, 4)), dim3(256), 0, st, (const bf16_t*)in, idx, (bf16_t*)out, n, D);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_scatter_rows_f32(const float* in, const int* idx, float* out, int n, int D, hipStream_t st) {
   if (n <= 0) return TA_OK;
   if (D % 4) return TA_ERR_ARG;
-  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(ta_cdiv(n, 4)), dim3(256), 0, st, in, idx, out, n, D);
+  TA_LAUNCH(scatter_rows_f32_kernel, dim3(ta_cdiv(n, 4)), dim3(256), 0, st, in, idx, out, n, D);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_bernoulli_keep(float* keep, long n, float keep_prob, unsigned long long seed, hipStream_t st) {
   if (n <= 0) return TA_OK;
-  hipLaunchKernelGGL(bernoulli_keep_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, keep, n, keep_prob, seed);
+  TA_LAUNCH(bernoulli_keep_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, keep, n, keep_prob, seed);
   TA_CHECK_LAUNCH(); return TA_OK;
 }

@@ -211,7 +211,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
     (void)hipEventRecord(r.a, st);
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   TA_CHECK_LAUNCH();
   return TA_OK;
@@ -262,7 +262,7 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
     if (rc) return rc;
     const long n4 = (long)M * N / 4;
     int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)splitk_ws,
+    TA_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)splitk_ws,
                        a.splits, a.slab_stride, residual, out_bf16 ? nullptr : (float*)C,
                        out_bf16 ? (bf16_t*)C : nullptr, n4);
     TA_CHECK_LAUNCH();

@@ -103,11 +103,11 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
   if (B <= 0) return TA_OK;
   const int T = Ls / HOP;
   if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256)) return TA_ERR_ARG;
-  hipLaunchKernelGGL(logmel_init_kernel, dim3(ta_cdiv(B, 256)), dim3(256), 0, st, clip_max_ws, B);
-  hipLaunchKernelGGL(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
+  TA_LAUNCH(logmel_init_kernel, dim3(ta_cdiv(B, 256)), dim3(256), 0, st, clip_max_ws, B);
+  TA_LAUNCH(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
                      feats, clip_max_ws, T);
   int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_max_ws, lens, mask, n_mels, T);
+  TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_max_ws, lens, mask, n_mels, T);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

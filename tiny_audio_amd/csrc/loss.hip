@@ -123,10 +123,10 @@ extern "C" int ta_cross_entropy(const void* logits, int logits_bf16, long ldl, c
   if (n <= 0) return TA_OK;
   if ((ldl % 4) || (dlogits_bf16 && (ldd % 4))) return TA_ERR_ARG;
   if (logits_bf16)
-    hipLaunchKernelGGL((ce_fwd_bwd_kernel<bf16_t>), dim3(n), dim3(256), 0, st, (const bf16_t*)logits, ldl, rows, targets, V,
+    TA_LAUNCH((ce_fwd_bwd_kernel<bf16_t>), dim3(n), dim3(256), 0, st, (const bf16_t*)logits, ldl, rows, targets, V,
                        scale, nll, loss_accum, (bf16_t*)dlogits_bf16, ldd);
   else
-    hipLaunchKernelGGL((ce_fwd_bwd_kernel<float>), dim3(n), dim3(256), 0, st, (const float*)logits, ldl, rows, targets, V,
+    TA_LAUNCH((ce_fwd_bwd_kernel<float>), dim3(n), dim3(256), 0, st, (const float*)logits, ldl, rows, targets, V,
                        scale, nll, loss_accum, (bf16_t*)dlogits_bf16, ldd);
   TA_CHECK_LAUNCH();
   return TA_OK;
@@ -134,7 +134,7 @@ extern "C" int ta_cross_entropy(const void* logits, int logits_bf16, long ldl, c
 
 extern "C" int ta_label_rows(const long* labels, int B, int L, int* rows, long* targets, int* n_out, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
-  hipLaunchKernelGGL(label_rows_kernel, dim3(1), dim3(1024), 0, st, labels, B, L, rows, targets, n_out);
+  TA_LAUNCH(label_rows_kernel, dim3(1), dim3(1024), 0, st, labels, B, L, rows, targets, n_out);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

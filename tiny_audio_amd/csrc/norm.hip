@@ -182,11 +182,11 @@ extern "C" int ta_layernorm_f32(const float* x, const float* w, const float* b, 
   dim3 grid(ta_cdiv(M, 4)), blk(256);
 #define LN_CALL(V)                                                                                               \
   if (y_bf16 && y_f32)                                                                                           \
-    hipLaunchKernelGGL((layernorm_kernel<V, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
+    TA_LAUNCH((layernorm_kernel<V, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
   else if (y_bf16)                                                                                               \
-    hipLaunchKernelGGL((layernorm_kernel<V, true, false>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps); \
+    TA_LAUNCH((layernorm_kernel<V, true, false>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps); \
   else                                                                                                           \
-    hipLaunchKernelGGL((layernorm_kernel<V, false, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);
+    TA_LAUNCH((layernorm_kernel<V, false, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);
   DISPATCH_MAXV(H, LN_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
@@ -199,9 +199,9 @@ extern "C" int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, floa
   dim3 grid(ta_cdiv(M, 4)), blk(256);
 #define RF_CALL(V)                                                                                                 \
   if (act_gelu)                                                                                                    \
-    hipLaunchKernelGGL((rmsnorm_fwd_kernel<V, 1>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps); \
+    TA_LAUNCH((rmsnorm_fwd_kernel<V, 1>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps); \
   else                                                                                                             \
-    hipLaunchKernelGGL((rmsnorm_fwd_kernel<V, 0>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
+    TA_LAUNCH((rmsnorm_fwd_kernel<V, 0>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
   DISPATCH_MAXV(H, RF_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
@@ -217,10 +217,10 @@ extern "C" int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd
   const size_t lds = dw_accum ? (size_t)H * 4 : 0;
 #define RB_CALL(V)                                                                                             \
   if (act_gelu)                                                                                                \
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<V, 1>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
+    TA_LAUNCH((rmsnorm_bwd_kernel<V, 1>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
                        dx_f32, (bf16_t*)dx_bf16, dw_accum, M, H);                                              \
   else                                                                                                         \
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<V, 0>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
+    TA_LAUNCH((rmsnorm_bwd_kernel<V, 0>), dim3(blocks), dim3(256), lds, st, dy, x, rstd, w, dres,     \
                        dx_f32, (bf16_t*)dx_bf16, dw_accum, M, H);
   DISPATCH_MAXV(H, RB_CALL);
   TA_CHECK_LAUNCH();

@@ -45,7 +45,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 extern "C" int ta_grad_sqnorm(const float* g, long n, float* accum, hipStream_t st) {
   if (n <= 0) return TA_OK;
   long b = (n / 4 + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((int)b), dim3(256), 0, st, g, n, accum);
+  TA_LAUNCH(sqnorm_kernel, dim3((int)b), dim3(256), 0, st, g, n, accum);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
@@ -55,7 +55,7 @@ extern "C" int ta_adamw_step(float* p, const float* g, float* m, float* v, long 
   if (step < 1) return TA_ERR_ARG;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   long b = (n + 255) / 256; if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)b), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+  TA_LAUNCH(adamw_kernel, dim3((int)b), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
                      sqnorm, max_norm, grad_scale, denom);
   TA_CHECK_LAUNCH(); return TA_OK;
 }

@@ -191,7 +191,7 @@ extern "C" int ta_enc_qkv_post(const void* qkv, const float* cosT, const float* 
                                int B, int H, int S, int Sp, hipStream_t st) {
   if (B <= 0 || S <= 0) return TA_OK;
   if (Sp % 64 || Sp < S) return TA_ERR_ARG;
-  hipLaunchKernelGGL(enc_qkv_post_kernel, dim3(Sp / 64, 3 * H, B), dim3(256), 0, st, (const bf16_t*)qkv, cosT, sinT,
+  TA_LAUNCH(enc_qkv_post_kernel, dim3(Sp / 64, 3 * H, B), dim3(256), 0, st, (const bf16_t*)qkv, cosT, sinT,
                      (bf16_t*)Q, (bf16_t*)K, (bf16_t*)VT, H, S, Sp);
   TA_CHECK_LAUNCH();
   return TA_OK;
@@ -203,7 +203,7 @@ extern "C" int ta_lm_qkv_post_fwd(const void* qkv0, const float* qn_w, const flo
                                   hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Lp % 64 || Lp < L) return TA_ERR_ARG;
-  hipLaunchKernelGGL(lm_qkv_post_fwd_kernel, dim3(Lp / 64, Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)qkv0, qn_w,
+  TA_LAUNCH(lm_qkv_post_fwd_kernel, dim3(Lp / 64, Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)qkv0, qn_w,
                      kn_w, cosT, sinT, pos, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, (bf16_t*)QT, (bf16_t*)KT, (bf16_t*)VT, rq,
                      rk, Hq, Hkv, L, Lp, eps);
   TA_CHECK_LAUNCH();
@@ -215,7 +215,7 @@ extern "C" int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV
                                   const float* sinT, const int* pos, void* dqkv, int B, int Hq, int Hkv, int L,
                                   hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
-  hipLaunchKernelGGL(lm_qkv_post_bwd_kernel, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
+  TA_LAUNCH(lm_qkv_post_bwd_kernel, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
                      (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos,
                      (bf16_t*)dqkv, Hq, Hkv, L);
   TA_CHECK_LAUNCH();
@@ -226,7 +226,7 @@ extern "C" int ta_attn_bwd_prep(const void* dO, const void* O, float* Delta, voi
                                 hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Lp % 64 || Lp < L) return TA_ERR_ARG;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(Lp / 64, Hq, B), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
+  TA_LAUNCH(attn_bwd_prep_kernel, dim3(Lp / 64, Hq, B), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                      Delta, (bf16_t*)dOT, Hq, L, Lp);
   TA_CHECK_LAUNCH();
   return TA_OK;
