@@ -161,6 +161,10 @@ def _load():
         if not os.path.exists(SO_PATH):
             raise Ta355Error(f"{SO_PATH} not found: run `python __graft_entry__.py` (build()) first. "
                              "There is no CPU fallback for the ta355 hot path.")
+        # Load torch FIRST: its wheel bundles its own libamdhip64.  If libta355.so were loaded before it, the
+        # process would end up with two HIP runtimes (ours from /opt/rocm, torch's from the wheel) and device
+        # pointers / streams allocated by one would be invalid in the other (launch failures).
+        import torch  # noqa: F401
         handle = C.CDLL(SO_PATH)
         for name, (ret, argtypes) in parse_header().items():
             fn = getattr(handle, name)        # AttributeError if the header declares something not exported
