@@ -14,7 +14,7 @@
 // MFMA k-slot permutation is applied identically to the A operand, read from a [d][key] image of V).
 // That image comes from the producer (qkv_post kernels write V^T / K^T / Q^T / dO^T copies: HBM is
 // plentiful, LDS transposes are not free), so every LDS tile here is a plain row-major copy:
-//   "row tiles"  [64 rows][HD]   stride HD*2+32 B  -> conflict-free ds_read_b128 fragments
+//   "row tiles"  [64 rows][HD]   XOR-swizzled 16-B chunks -> conflict-free ds_read_b128 fragments
 //   "col tiles"  [HD rows][64]   stride 144 B      -> conflict-free ds_read_b64 fragment halves
 #include "common.h"
 
@@ -23,7 +23,15 @@
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
 
-template <int HD> struct RowTile { static constexpr int STRIDE = HD * 2 + 32; static constexpr int BYTES = 64 * STRIDE; };
+// Row tiles are unpadded [64][HD] with the 16-B chunk index XOR-swizzled by the row: conflict-free ds_read_b128
+// fragments under either lane grouping of the instruction (same scheme the GEMM uses; measured 0 conflicts there).
+template <int HD> struct RowTile {
+  static constexpr int STRIDE = HD * 2;
+  static constexpr int BYTES = 64 * STRIDE;
+  static __device__ __forceinline__ int swz(int r) { return HD == 64 ? ((r >> 1) & 7) : (r & 15); }
+  // byte offset of 16-B chunk c of row r
+  static __device__ __forceinline__ int off(int r, int c) { return r * STRIDE + ((c ^ swz(r)) << 4); }
+};
 template <int HD> struct ColTile { static constexpr int BYTES = HD * CT_STRIDE; };
 
 // ---- staging helpers: global -> registers (issued early) -> LDS (written after the barrier)
@@ -45,7 +53,7 @@ struct RowStage {   // 64 rows x HD bf16, 256 threads
     for (int i = 0; i < N; ++i) {
       const int ch = tid + i * 256;
       const int r = ch / (HD / 8), c = ch % (HD / 8);
-      *(uint4*)(lds + r * RowTile<HD>::STRIDE + c * 16) = v[i];
+      *(uint4*)(lds + RowTile<HD>::off(r, c)) = v[i];
     }
   }
 };
@@ -71,6 +79,19 @@ struct ColStage {   // HD rows x 64 bf16 (128 B per row) from a [.., HD, Lp] ima
   }
 };
 
+// XCD-aware block order.  Workgroup b runs on XCD b % 8 and each XCD has a private L2, so all workgroups that
+// stream the SAME K/V (one batch element x one kv head: every query tile of every query head in the GQA group) are
+// given ids with the same residue mod 8:  id = (j * gsz + member) * 8 + xcd,  group = j * 8 + xcd.
+// (Measured before this: 775 MB fetched per encoder-attention launch for 82 MB of K/V -- each of the 8 query tiles
+// of a head ran on a different XCD and pulled its own copy.)  Grid = gsz * round_up(ngroups, 8); tail groups exit.
+__device__ __forceinline__ bool decode_group(int id, int gsz, int ngroups, int& group, int& member) {
+  const int xcd = id & 7, w = id >> 3;
+  member = w % gsz;
+  group = (w / gsz) * 8 + xcd;
+  return group < ngroups;
+}
+static inline int grouped_grid(int gsz, int ngroups) { return gsz * ((ngroups + 7) / 8 * 8); }
+
 __device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
   union { bf16x8 v; uint32_t u[4]; } r;
   r.u[0] = pack2bf(a[0], a[1]); r.u[1] = pack2bf(a[2], a[3]);
@@ -90,14 +111,17 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ VT, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kmask,
-                                                       int Hq, int Hkv, int L, int Lp, float scale) {
+                                                       int B, int Hq, int Hkv, int L, int Lp, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + RowTile<HD>::BYTES;
   int* Ms = (int*)(Vs + ColTile<HD>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int hk = h / (Hq / Hkv);
+  const int nq = (L + 63) / 64, grp = Hq / Hkv;
+  int group, member;
+  if (!decode_group(blockIdx.x, grp * nq, B * Hkv, group, member)) return;
+  const int b = group / Hkv, hk = group % Hkv;
+  const int h = hk * grp + member / nq, qt = member % nq;
   const int q0 = qt * 64;
   const int qrow = q0 + wave * 16 + l15;
   const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
@@ -142,46 +166,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(Ks + (kt * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2);
+        const bf16x8 a = *(const bf16x8*)(Ks + RowTile<HD>::off(kt * 16 + l15, ks * 4 + g));
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[kt], 0, 0, 0);
       }
     }
-    // ---- mask + online softmax (query = this lane's column)
+    // ---- mask + online softmax (query = this lane's column).  A tile is "full" when every key is visible to every
+    //      query row of this wave: then no per-element predicate is evaluated (the common case).
+    const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (!CAUSAL || key0 + KV_TILE - 1 <= q0 + wave * 16);
     float mloc = NEG_BIG;
-    bool ok[4][4];
+    if (full) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
-      const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+      for (int kt = 0; kt < 4; ++kt)
+        mloc = fmaxf(fmaxf(mloc, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + kt * 16 + g * 4 + r;
-        bool v = key < L;
-        if (CAUSAL) v = v && (key <= qrow);
-        if (kmask) v = v && (mkv[r] != 0);
-        ok[kt][r] = v;
-        if (v) mloc = fmaxf(mloc, s[kt][r]);
+      for (int kt = 0; kt < 4; ++kt) {
+        const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
+        const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key0 + kt * 16 + g * 4 + r;
+          bool v = key < L;
+          if (CAUSAL) v = v && (key <= qrow);
+          if (kmask) v = v && (mkv[r] != 0);
+          if (!v) s[kt][r] = -INFINITY;               // exp2(-inf) = 0 below; m_new stays finite (>= NEG_BIG)
+          mloc = fmaxf(mloc, s[kt][r]);
+        }
       }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc);
-    const float alpha = exp2f((m_run - m_new) * sl2);
+    const float mb = m_new * sl2;
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = ok[kt][r] ? exp2f((s[kt][r] - m_new) * sl2) : 0.f;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mb));
         s[kt][r] = p;
         lsum += p;
       }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
+    if (__any(m_new != m_run)) {                       // rescale only when some row's running max moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+      l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < HD / 16; ++i) { o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha; }
+      for (int i = 0; i < HD / 16; ++i) { o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha; }
+      m_run = m_new;
+    }
+    l_run += lsum;
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
@@ -216,15 +251,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dO, long dO_stride,
                                                           const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                           const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
-                                                          int Hq, int Hkv, int L, int Lp, float scale) {
+                                                          int B, int Hq, int Hkv, int L, int Lp, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = Ks + RowTile<HD>::BYTES;
   char* KTs = Vs + RowTile<HD>::BYTES;
   int* Ms = (int*)(KTs + ColTile<HD>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int hk = h / (Hq / Hkv);
+  const int nq = (L + 63) / 64, grp = Hq / Hkv;
+  int group, member;
+  if (!decode_group(blockIdx.x, grp * nq, B * Hkv, group, member)) return;
+  const int b = group / Hkv, hk = group % Hkv;
+  const int h = hk * grp + member / nq, qt = member % nq;
   const int qrow = qt * 64 + wave * 16 + l15;
   const int qr = qrow < L ? qrow : L - 1;
   const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
@@ -262,7 +300,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
-        const int off = (kt * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2;
+        const int off = RowTile<HD>::off(kt * 16 + l15, ks * 4 + g);
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s[kt], 0, 0, 0);
         dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp[kt], 0, 0, 0);
       }
@@ -276,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         const int key = key0 + kt * 16 + g * 4 + r;
         bool v = (mkv[r] != 0) && (qrow < L);
         if (CAUSAL) v = v && (key <= qrow);
-        const float p = v ? exp2f(s[kt][r] * sl2 - lse2) : 0.f;
+        const float p = v ? __builtin_amdgcn_exp2f(s[kt][r] * sl2 - lse2) : 0.f;
         s[kt][r] = p * (dp[kt][r] - delta) * scale;
       }
     }
@@ -311,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ dOT,
                                                            const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                            const int* __restrict__ kmask, bf16_t* __restrict__ dK,
-                                                           bf16_t* __restrict__ dV, int Hq, int Hkv, int L, int Lp,
+                                                           bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
                                                            float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -321,8 +359,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   float* Ls = (float*)(dOTs + ColTile<HD>::BYTES);   // [64] lse * log2e
   float* Ds = Ls + 64;                               // [64] delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int kt_idx = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int grp = Hq / Hkv;
+  int group, kt_idx;
+  if (!decode_group(blockIdx.x, (L + 63) / 64, B * Hkv, group, kt_idx)) return;
+  const int b = group / Hkv, hk = group % Hkv;
   const int krow = kt_idx * 64 + wave * 16 + l15;
   const int kr = krow < L ? krow : L - 1;
   const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
@@ -368,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         dp[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
-          const int off = (qs * 16 + l15) * RowTile<HD>::STRIDE + (ks * 32 + g * 8) * 2;
+          const int off = RowTile<HD>::off(qs * 16 + l15, ks * 4 + g);
           s[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + off), kf[ks], s[qs], 0, 0, 0);
           dp[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dOs + off), vf[ks], dp[qs], 0, 0, 0);
         }
@@ -385,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
           const int q = q0 + qs * 16 + g * 4 + r;
           bool v = kvalid && (q < L);
           if (CAUSAL) v = v && (krow <= q);
-          const float p = v ? exp2f(s[qs][r] * sl2 - lsv[r]) : 0.f;
+          const float p = v ? __builtin_amdgcn_exp2f(s[qs][r] * sl2 - lsv[r]) : 0.f;
           s[qs][r] = p;
           ds[qs][r] = p * (dp[qs][r] - dlv[r]) * scale;
         }
@@ -425,10 +465,10 @@ extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, vo
                                 hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
-  dim3 grid(ta_cdiv(L, 64), Hq, B), blk(256);
+  dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv)), blk(256);
 #define FWD(HD_, C_)                                                                                              \
   TA_LAUNCH((attn_fwd_kernel<HD_, C_>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
-                     (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, Hq, Hkv, L, Lp, scale)
+                     (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, Lp, scale)
   if (head_dim == 64 && !causal) FWD(64, false);
   else if (head_dim == 64 && causal) FWD(64, true);
   else if (head_dim == 128 && causal) FWD(128, true);
@@ -453,21 +493,21 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     attr_done = true;
   }
-  dim3 gq(ta_cdiv(L, 64), Hq, B), gk(ta_cdiv(L, 64), Hkv, B), blk(256);
+  dim3 gq(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv)), gk(grouped_grid(ta_cdiv(L, 64), B * Hkv)), blk(256);
   if (causal) {
     TA_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
-                       (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
+                       (bf16_t*)dQ, B, Hq, Hkv, L, Lp, scale);
     TA_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
-                       kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
+                       kmask, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale);
   } else {
     TA_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
-                       (bf16_t*)dQ, Hq, Hkv, L, Lp, scale);
+                       (bf16_t*)dQ, B, Hq, Hkv, L, Lp, scale);
     TA_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
                        (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
-                       kmask, (bf16_t*)dK, (bf16_t*)dV, Hq, Hkv, L, Lp, scale);
+                       kmask, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale);
   }
   TA_CHECK_LAUNCH();
   return TA_OK;

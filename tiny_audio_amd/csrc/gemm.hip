@@ -36,6 +36,13 @@ struct GemmArgs {
 #define BM 128
 #define BN 128
 #define BK 64
+// per-CU throughput of the 256-row tile variants relative to the 128x128 kernel (two co-resident workgroups),
+// measured with scripts/gemm_bench.py; used only by the launch-time variant choice
+#ifndef TA355_RATE_256x256
+#define TA355_RATE_256x256 0.9      /* simple double buffer: superseded by the ping-pong schedule */
+#define TA355_RATE_256x128 0.5      /* measured slower than 128x128 on every shape */
+#define TA355_RATE_256x256_PP 1.15  /* sq8192: 1306 vs 1113 TF/s; fc1 819 vs 692; enc qkv 833 vs 772 (profiles/r01_b_*) */
+#endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -158,7 +165,209 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
       if (ACT == 1) {
-        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
+      }
+      if (HAS_RES) {
+        const float4 r = *(const float4*)(p.res + roff + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if (OUT_BF16) {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *(uint2*)(Cb + (roff + n) * 2) = o;
+      } else {
+        *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// ============================================================================ v2: 256-row tiles, 8 waves, 1 WG / CU
+// The 128x128 kernel above is bound by the per-CU L2 -> LDS DMA rate: it must stage 32 KB per 2.1 MFLOP tile-step
+// (profiles/r01_a_pmc_summary.md: L2 request volume ~48x the algorithmic bytes).  A 256 x BN2 tile halves
+// (BN2 = 256) or cuts by a quarter (BN2 = 128) the bytes staged per flop.  8 waves as 2 (M) x 4 (N): each wave owns
+// 128 x BN2/4 outputs = 8 x NT accumulator fragments.  Same DMA + source-side swizzle + double buffer as v1; the DMA
+// issue for the next K-tile is interleaved in four places between MFMA groups instead of one burst, because with a
+// single workgroup per CU nothing else hides a burst.
+//
+// PP ("ping-pong"): the two wave groups (wm = 0 / 1; wave w and w+4 share a SIMD) run ONE barrier interval apart,
+// alternating a load interval L(t,s) = {ds_read the 12 fragments of k-step s (+ issue the next tile's DMA when
+// s = 0); wait for them} with a compute interval C(t,s) = {32 MFMAs}.  In every interval one group feeds the
+// matrix pipe while its SIMD partner loads, so the pipe never waits on LDS latency, DMA issue or the barrier:
+//   global barrier #   ..4t | 4t+1 | 4t+2 | 4t+3 | 4t+4 ..
+//   group 0            L(t,0)+DMA(t+1) | C(t,0) | L(t,1) | C(t,1) | L(t+1,0)
+//   group 1            C(t-1,1) | L(t,0)+DMA(t+1) | C(t,0) | L(t,1) | C(t,1)
+// Hazards: every wave drains its own DMA (vmcnt 0) at the end of L(t,1), i.e. before barrier 4t+3 (group 0) /
+// 4t+4 (group 1), and the first read of tile t+1 is after barrier 4t+4; the last reads of tile t-1 (group 1's
+// L(t-1,1)) retire (lgkmcnt 0) before barrier 4t, and the first DMA into that buffer is issued after it.
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool PP>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
+  constexpr int BM2 = 256;
+  constexpr int NT = BN2 / 64;                 // n-fragments per wave
+  constexpr int NA = BM2 / 64, NB = BN2 / 64;  // 16-B DMA chunks per thread per K-tile (A, W)
+  constexpr int A_BYTES = BM2 * 128, STAGE = (BM2 + BN2) * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  int t = bid - z * tiles;
+  const int GROUP_M = 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int m0 = pm * BM2, n0 = pn * BN2;
+
+  const int nkt = p.K / BK;
+  const int kt_begin = (int)(((long)nkt * z) / p.splits);
+  const int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+
+  const int lr = tid >> 3;                                    // 0..63
+  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
+  const char* a_src[NA];
+  const char* w_src[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int gm = min(m0 + i * 64 + lr, p.M - 1);
+    const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+    a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int gn = min(n0 + i * 64 + lr, p.N - 1);
+    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+  }
+  char* lds_w = smem + wave * 1024;
+
+  const int swz = l15 >> 1;
+  const int a_rd = (wm * 128 + l15) * 128;
+  const int b_rd = A_BYTES + (wn * (BN2 / 4) + l15) * 128;
+  const int koff0 = ((0 + g) ^ swz) << 4;
+  const int koff1 = ((4 + g) ^ swz) << 4;
+
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto dma_a = [&](char* base, int i) { glds16(a_src[i], base + i * 8192); a_src[i] += BK * 2; };
+  auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += BK * 2; };
+
+  if (kt_begin < kt_end) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma_a(lds_w, i);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dma_w(lds_w, i);
+  }
+  __syncthreads();
+  if constexpr (PP) {
+    const int lag = __builtin_amdgcn_readfirstlane(wm);     // SGPR: scalar branches around the extra barriers
+    if (lag) __builtin_amdgcn_s_barrier();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_begin) & 1;
+      const bool more = kt + 1 < kt_end;
+      const char* S = smem + cur * STAGE;
+      char* nxt = lds_w + (cur ^ 1) * STAGE;
+      bf16x8 af[8], bfr[NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ko = kk ? koff1 : koff0;
+        // ---- L(t, kk)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
+        if (kk == 0) {
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) dma_a(nxt, i);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) dma_w(nxt, i);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- C(t, kk)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!lag) __builtin_amdgcn_s_barrier();
+  } else {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    const char* S = smem + cur * STAGE;
+    char* nxt = lds_w + (cur ^ 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ko = kk ? koff1 : koff0;
+      bf16x8 af[8], bfr[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (more) {   // quarter of the next tile's DMA ahead of each 4-row MFMA group
+          if (kk == 0) { dma_a(nxt, 2 * h); dma_a(nxt, 2 * h + 1); }
+          else if (NB == 4) { dma_w(nxt, 2 * h); dma_w(nxt, 2 * h + 1); }
+          else { dma_w(nxt, h); }
+        }
+#pragma unroll
+        for (int i = 4 * h; i < 4 * h + 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  }
+
+  char* Cb = (char*)p.C;
+  if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + l15;
+    if (m >= p.M) continue;
+    const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * (BN2 / 4) + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (ACT == 1) {
+        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
       }
       if (HAS_RES) {
         const float4 r = *(const float4*)(p.res + roff + n);
@@ -202,8 +411,31 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
+// Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong.
+// Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
+// come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0|1|2 forces one (experiments).
+#include <cstdlib>
+static int pick_variant(int M, int N, int splits) {
+  static const int forced = [] { const char* e = getenv("TA355_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+  if (forced >= 0 && forced <= 3) return forced;
+  const double rate[4] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP};
+  const int bm[4] = {128, 256, 256, 256}, bn[4] = {128, 256, 128, 256}, slots[4] = {512, 256, 256, 256};
+  int best = 0; double best_t = 1e300;
+  for (int v = 0; v < 4; ++v) {
+    const long tiles = (long)ta_cdiv(M, bm[v]) * ta_cdiv(N, bn[v]) * splits;
+    const double rounds = (double)((tiles + slots[v] - 1) / slots[v]);
+    // a round of variant v costs (tile area / rate) per slot; v1 runs two tiles per CU concurrently
+    const double t = rounds * (double)bm[v] * bn[v] / rate[v] * (v == 0 ? 2.0 : 1.0);
+    if (t < best_t) { best_t = t; best = v; }
+  }
+  return best;
+}
+
 template <int ACT, bool OUT_BF16, bool HAS_RES>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+static int launch_gemm(GemmArgs a, hipStream_t st) {
+  const int variant = pick_variant(a.M, a.N, a.splits);
+  const int bm = variant == 0 ? 128 : 256, bn = (variant == 1 || variant == 3) ? 256 : 128;
+  a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   ProfRec r;
   if (g_prof_on) {
@@ -211,7 +443,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
     (void)hipEventRecord(r.a, st);
   }
-  TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   TA_CHECK_LAUNCH();
   return TA_OK;
