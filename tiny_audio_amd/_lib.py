@@ -100,7 +100,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, "common.h"), HEADER]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", *srcs, "-o", SO_PATH]
+    # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made
+    # the attention kernels shuttle every score / output fragment through v_accvgpr_read/write around the softmax.
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-shared", "-fPIC", *srcs, "-o", SO_PATH]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

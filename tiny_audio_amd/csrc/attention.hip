@@ -15,11 +15,12 @@
 // That image comes from the producer (qkv_post kernels write V^T / K^T / Q^T / dO^T copies: HBM is
 // plentiful, LDS transposes are not free), so every LDS tile here is a plain row-major copy:
 //   "row tiles"  [64 rows][HD]   XOR-swizzled 16-B chunks -> conflict-free ds_read_b128 fragments
-//   "col tiles"  [HD rows][64]   stride 144 B      -> conflict-free ds_read_b64 fragment halves
+//   "col tiles"  [HD rows][64]   8-B granules XOR-swizzled by the row -> conflict-free ds_read_b64 halves
+//                (first version padded rows to 144 B: SQ_LDS_BANK_CONFLICT showed 30 % conflict cycles)
 #include "common.h"
 
 #define KV_TILE 64
-#define CT_STRIDE 144          // bytes, [d][64 keys] tiles
+#define CT_STRIDE 128          // bytes, [d][64 keys] tiles; 8-byte granule index XOR (row & 15)
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
 
@@ -74,7 +75,11 @@ struct ColStage {   // HD rows x 64 bf16 (128 B per row) from a [.., HD, Lp] ima
     for (int i = 0; i < N; ++i) {
       const int ch = tid + i * 256;
       const int r = ch >> 3, c = ch & 7;
-      *(uint4*)(lds + r * CT_STRIDE + c * 16) = v[i];
+      // granule g8 of row r lives at g8 ^ (r & 15): the 16-B chunk moves to c ^ ((r & 15) >> 1) and its two
+      // 8-B halves swap when r is odd
+      const uint4 x = v[i];
+      const uint4 y = (r & 1) ? make_uint4(x.z, x.w, x.x, x.y) : x;
+      *(uint4*)(lds + r * CT_STRIDE + ((c ^ ((r & 15) >> 1)) << 4)) = y;
     }
   }
 };
@@ -101,47 +106,78 @@ __device__ __forceinline__ bf16x8 pack_p(const f32x4& a, const f32x4& b) {
 __device__ __forceinline__ bf16x8 read_colfrag(const char* tile, int row, int c0, int c1) {
   // two 8-byte halves: columns [c0, c0+4) and [c1, c1+4) of row `row`
   union { bf16x8 v; uint2 h[2]; } r;
-  r.h[0] = *(const uint2*)(tile + row * CT_STRIDE + c0 * 2);
-  r.h[1] = *(const uint2*)(tile + row * CT_STRIDE + c1 * 2);
+  r.h[0] = *(const uint2*)(tile + row * CT_STRIDE + (((c0 >> 2) ^ (row & 15)) << 3));
+  r.h[1] = *(const uint2*)(tile + row * CT_STRIDE + (((c1 >> 2) ^ (row & 15)) << 3));
   return r.v;
 }
 
 // ============================================================================ forward
-template <int HD, bool CAUSAL>
+// cross-lane combines over the 4 lane groups (g = lane>>4) that share a query column, on the VALU (no LDS round trip):
+// permlane16_swap(x,x) leaves {own, partner(xor 16)} in the two results, permlane32_swap likewise for xor 32.
+// 3-input max as ONE instruction (fmaxf chains compile to v_max_f32 plus a canonicalising v_max x,x per operand
+// under the kernel's IEEE mode; the scores here are finite or -inf, never NaN)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float group_max(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
+// One workgroup = 128 query rows of one head (4 waves x 2 sub-tiles of 16 rows): every K / V^T fragment read from LDS
+// feeds two MFMAs.  The softmax denominator is NOT summed on the VALU: the V^T image carries 16 extra rows whose
+// first is all ones, so one extra MFMA block per k-step accumulates l = sum_k P[q,k] next to O (and is rescaled
+// with it).  Per score element that leaves: 1 FMA + 1 v_exp + 1/2 v_max3 + 1/2 v_cvt_pk on the VALU.
+template <int HD, bool CAUSAL, int QSUB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ VT, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kmask,
                                                        int B, int Hq, int Hkv, int L, int Lp, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ND = HD / 16;                        // O^T row blocks; block ND is the row-sum block
   char* Ks = smem;
-  char* Vs = smem + RowTile<HD>::BYTES;
-  int* Ms = (int*)(Vs + ColTile<HD>::BYTES);
+  char* Vs = smem + RowTile<HD>::BYTES;              // (HD + 16) rows x 144 B
+  int* Ms = (int*)(Vs + (HD + 16) * CT_STRIDE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int nq = (L + 63) / 64, grp = Hq / Hkv;
+  constexpr int QROWS = 64 * QSUB;
+  const int nq = (L + QROWS - 1) / QROWS, grp = Hq / Hkv;
   int group, member;
   if (!decode_group(blockIdx.x, grp * nq, B * Hkv, group, member)) return;
   const int b = group / Hkv, hk = group % Hkv;
   const int h = hk * grp + member / nq, qt = member % nq;
-  const int q0 = qt * 64;
-  const int qrow = q0 + wave * 16 + l15;
+  const int q0 = qt * QROWS + wave * 16 * QSUB;         // first query row of this wave
   const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
   const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
   const bf16_t* Vb = VT + ((long)(b * Hkv + hk) * HD) * Lp;
   const float sl2 = scale * LOG2E;
 
-  bf16x8 qf[HD / 32];
-  {
-    const int qr = qrow < L ? qrow : L - 1;
-#pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+  // rows HD .. HD+15 of the V^T image: [1 1 1 ...] then zeros (written once, never restaged)
+  for (int i = tid; i < 16 * (CT_STRIDE / 4); i += 256) {
+    const int r = i / (CT_STRIDE / 4);
+    ((uint32_t*)(Vs + HD * CT_STRIDE))[i] = r == 0 ? 0x3f803f80u : 0u;
   }
-  f32x4 o[HD / 16];
+  bf16x8 qf[QSUB][HD / 32];
 #pragma unroll
-  for (int i = 0; i < HD / 16; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = NEG_BIG, l_run = 0.f;
+  for (int sub = 0; sub < QSUB; ++sub) {
+    int qr = q0 + sub * 16 + l15; if (qr > L - 1) qr = L - 1;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf[sub][ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+  }
+  f32x4 o[QSUB][ND + 1];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub)
+#pragma unroll
+    for (int i = 0; i <= ND; ++i) o[sub][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[QSUB];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) m_run[sub] = NEG_BIG;
 
   int ntiles = (L + KV_TILE - 1) / KV_TILE;
-  if (CAUSAL) { const int lim = qt + 1; if (lim < ntiles) ntiles = lim; }
+  if (CAUSAL) { const int lim = (qt * QROWS + QROWS - 1) / KV_TILE + 1; if (lim < ntiles) ntiles = lim; }
 
   RowStage<HD> ks_reg; ColStage<HD> vs_reg; int mk_reg = 1;
   ks_reg.load(Kb, HD, 0, L, tid);
@@ -159,87 +195,93 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       vs_reg.load(Vb, Lp, key0 + KV_TILE, tid);
       if (kmask && tid < 64) { const int kk = key0 + KV_TILE + tid; mk_reg = (kk < L) ? kmask[(long)b * L + kk] : 0; }
     }
-    // ---- S^T = K Q^T
-    f32x4 s[4];
+    // ---- S^T = K Q^T for both query sub-tiles
+    f32x4 s[QSUB][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sub = 0; sub < QSUB; ++sub) s[sub][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
         const bf16x8 a = *(const bf16x8*)(Ks + RowTile<HD>::off(kt * 16 + l15, ks * 4 + g));
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[kt], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          s[sub][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[sub][ks], s[sub][kt], 0, 0, 0);
       }
     }
-    // ---- mask + online softmax (query = this lane's column).  A tile is "full" when every key is visible to every
-    //      query row of this wave: then no per-element predicate is evaluated (the common case).
-    const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (!CAUSAL || key0 + KV_TILE - 1 <= q0 + wave * 16);
-    float mloc = NEG_BIG;
-    if (full) {
+    // ---- online softmax numerators (the denominator rides in the MFMA below)
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        mloc = fmaxf(fmaxf(mloc, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
-    } else {
+    for (int sub = 0; sub < QSUB; ++sub) {
+      const int qrow = q0 + sub * 16 + l15;
+      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (!CAUSAL || key0 + KV_TILE - 1 <= q0 + sub * 16);
+      if (!full) {                                   // wave-uniform; selects, no per-element branches
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
-        const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+        for (int kt = 0; kt < 4; ++kt) {
+          const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
+          const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + kt * 16 + g * 4 + r;
-          bool v = key < L;
-          if (CAUSAL) v = v && (key <= qrow);
-          if (kmask) v = v && (mkv[r] != 0);
-          if (!v) s[kt][r] = -INFINITY;               // exp2(-inf) = 0 below; m_new stays finite (>= NEG_BIG)
-          mloc = fmaxf(mloc, s[kt][r]);
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kt * 16 + g * 4 + r;
+            bool v = key < L;
+            if (CAUSAL) v = v & (key <= qrow);
+            if (kmask) v = v & (mkv[r] != 0);
+            s[sub][kt][r] = v ? s[sub][kt][r] : -INFINITY;
+          }
         }
       }
-    }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float mb = m_new * sl2;
-    float lsum = 0.f;
+      float mloc = max3(s[sub][0][0], s[sub][0][1], s[sub][0][2]);
+      mloc = max3(mloc, s[sub][0][3], s[sub][1][0]);
+      mloc = max3(mloc, s[sub][1][1], s[sub][1][2]);
+      mloc = max3(mloc, s[sub][1][3], s[sub][2][0]);
+      mloc = max3(mloc, s[sub][2][1], s[sub][2][2]);
+      mloc = max3(mloc, s[sub][2][3], s[sub][3][0]);
+      mloc = max3(mloc, s[sub][3][1], s[sub][3][2]);
+      mloc = fmaxf(mloc, s[sub][3][3]);
+      const float m_new = fmaxf(m_run[sub], group_max(mloc));
+      if (__any(m_new != m_run[sub])) {              // rescale only when some row's running max moved
+        const float alpha = __builtin_amdgcn_exp2f((m_run[sub] - m_new) * sl2);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, -mb));
-        s[kt][r] = p;
-        lsum += p;
+        for (int i = 0; i <= ND; ++i) { o[sub][i][0] *= alpha; o[sub][i][1] *= alpha; o[sub][i][2] *= alpha; o[sub][i][3] *= alpha; }
+        m_run[sub] = m_new;
       }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (__any(m_new != m_run)) {                       // rescale only when some row's running max moved
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
-      l_run *= alpha;
+      const float mb = m_new * sl2;
 #pragma unroll
-      for (int i = 0; i < HD / 16; ++i) { o[i][0] *= alpha; o[i][1] *= alpha; o[i][2] *= alpha; o[i][3] *= alpha; }
-      m_run = m_new;
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[sub][kt][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sl2, -mb));
     }
-    l_run += lsum;
-    // ---- O^T += V^T P^T
+    // ---- [O^T ; l] += [V^T ; 1] P^T
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
-      const bf16x8 pb = pack_p(s[2 * kp], s[2 * kp + 1]);
+      bf16x8 pb[QSUB];
 #pragma unroll
-      for (int dt = 0; dt < HD / 16; ++dt) {
+      for (int sub = 0; sub < QSUB; ++sub) pb[sub] = pack_p(s[sub][2 * kp], s[sub][2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt <= ND; ++dt) {
         const bf16x8 va = read_colfrag(Vs, dt * 16 + l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[dt], 0, 0, 0);
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          o[sub][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[sub], o[sub][dt], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  if (qrow < L) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16_t* orow = O + ((long)b * L + qrow) * ((long)Hq * HD) + (long)h * HD;
 #pragma unroll
-    for (int dt = 0; dt < HD / 16; ++dt) {
-      uint2 w;
-      w.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv);
-      w.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-      *(uint2*)(orow + dt * 16 + g * 4) = w;
+  for (int sub = 0; sub < QSUB; ++sub) {
+    const int qrow = q0 + sub * 16 + l15;
+    const float l_run = __shfl(o[sub][ND][0], l15, 64);     // row 0 of the sum block lives in lane group g = 0
+    if (qrow < L) {
+      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      bf16_t* orow = O + ((long)b * L + qrow) * ((long)Hq * HD) + (long)h * HD;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        uint2 w;
+        w.x = pack2bf(o[sub][dt][0] * inv, o[sub][dt][1] * inv);
+        w.y = pack2bf(o[sub][dt][2] * inv, o[sub][dt][3] * inv);
+        *(uint2*)(orow + dt * 16 + g * 4) = w;
+      }
+      if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
     }
-    if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run * scale + __logf(l_run) : 1.0e30f;
   }
 }
 
@@ -458,16 +500,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 }
 
 // ----------------------------------------------------------------------------- C-ABI
-template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + ColTile<HD>::BYTES + 64 * 4; }
+template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + (HD + 16) * CT_STRIDE + 64 * 4; }
 
 extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask,
                                 int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
                                 hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
-  dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv)), blk(256);
+  // encoder (hd 64, S = 500, non-causal): 128 query rows per workgroup; LM (hd 128, short causal L): 64
+  const int qsub = (head_dim == 64) ? 2 : 1;
+  dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64 * qsub), B * Hkv)), blk(256);
 #define FWD(HD_, C_)                                                                                              \
-  TA_LAUNCH((attn_fwd_kernel<HD_, C_>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
+  TA_LAUNCH((attn_fwd_kernel<HD_, C_, (HD_ == 64 ? 2 : 1)>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
                      (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, Lp, scale)
   if (head_dim == 64 && !causal) FWD(64, false);
   else if (head_dim == 64 && causal) FWD(64, true);
