@@ -93,6 +93,35 @@ int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x_bf16, int B
                               const void* tape, float* dW1, float* dg1, float* dW2, float* dg2, void* ws,
                               long ws_bytes, hipStream_t st);
 
+/* ---- shared + sparse MoE projector: replaces MoEAudioProjector.forward/_forward_sparse + autograd backward
+ *      (tiny_audio/projectors.py:185-351): frame-stack -> RMSNorm(kE) -> shared SimpleAdapter + top-2-of-E routed
+ *      SimpleAdapters (fc1+bias -> erf-GELU -> fc2+bias), fp32 softmax router with optional multiplicative jitter,
+ *      balance + z auxiliary loss.  Arrays w1.. hold E+1 device pointers (HOST arrays): routed experts 0..E-1, then
+ *      the shared expert at index E. */
+typedef struct {
+  int enc_dim, k, hidden, llm_dim, num_experts;
+  float eps, aux_coef, z_coef;
+  const float* norm_w;       /* [k*E_enc] */
+  const float* router_w;     /* f32 [E, k*E_enc] */
+  const void* const* w1;     /* bf16 [Hd, kE] */
+  const void* const* w1_t;   /* bf16 [kE, Hd] */
+  const float* const* b1;    /* [Hd] */
+  const void* const* w2;     /* bf16 [D, Hd] */
+  const void* const* w2_t;   /* bf16 [Hd, D] */
+  const float* const* b2;    /* [D] */
+} ta_moe_weights;
+
+long ta_moe_tape_bytes(const ta_moe_weights* w, int B, int S);
+long ta_moe_bwd_workspace_bytes(const ta_moe_weights* w, int B, int S);
+/* noise: [T, E] jitter factors (train mode; the reference draws U(1-0.01, 1+0.01)) or NULL; aux: device scalar out. */
+int ta_moe_projector_forward(const ta_moe_weights* w, const void* x_bf16, int B, int S, const float* noise, int training,
+                             float* y, float* aux, void* tape, hipStream_t st);
+/* gradients of sum(dy * y) + d_aux * aux; dW1/db1/dW2/db2 are HOST arrays of E+1 device pointers (overwritten). */
+int ta_moe_projector_backward(const ta_moe_weights* w, const void* x_bf16, int B, int S, const float* dy, float d_aux,
+                              const float* noise, int training, const void* tape, float* d_norm_w, float* d_router_w,
+                              float* const* dW1, float* const* db1, float* const* dW2, float* const* db2, void* ws,
+                              long ws_bytes, hipStream_t st);
+
 /* ---- frozen Qwen3 LM + shifted CE: replaces model.language_model(inputs_embeds=, attention_mask=, labels=)
  *      together with the embed/masked_scatter glue of ASRModel.forward
  *      (tiny_audio/asr_modeling.py:497-526; TF:models/qwen3/modeling_qwen3.py:367-508; TF:loss/loss_utils.py:33-71)
@@ -144,6 +173,13 @@ int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask,
 int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
                     long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
                     int out_bf16, int splits, float* splitk_ws, hipStream_t st);
+/* Grouped / routed form (MoE experts): a_idx (gather list for A rows), seg {row base, row count} and krange
+ * {first, end} 64-wide K tile are DEVICE int arrays read by the kernel, so routing counts never visit the host.
+ * M is then only the upper bound used to size the grid. */
+int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
+                       long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
+                       int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
+                       const int* krange, hipStream_t st);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */

@@ -73,6 +73,25 @@ def test_full_training_step_plumbing(dry):
         np.testing.assert_allclose(rt[k], w0[k], atol=2e-2 * np.abs(w0[k]).max())      # bf16 storage round trip
 
 
+def test_moe_plumbing(dry):
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=1, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, projector_type="moe")
+    m = ASRModel(cfg, device="cpu", init="random")
+    assert set(m.projector.state_dict()) == set(OW.init_moe_projector(256, 256, 128))       # reference key names
+    assert sum(p.numel() for p in ASRModel(ASRConfig(projector_type="moe"), device="cpu", init="none").projector.parameters()) == 31_493_120
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    m.train()
+    out = m(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+            labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts),
+            label_meta=(torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22))
+    out.loss.backward()
+    for n, p in m.projector.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+    assert "ta_moe_projector_forward" in dry.calls and "ta_moe_projector_backward" in dry.calls
+
+
 def test_primitive_wrappers_marshal(dry):
     from tiny_audio_amd import ops
     bf, f32 = torch.bfloat16, torch.float32

@@ -275,3 +275,83 @@ def test_full_size_properties():
     out4.loss.backward()
     for k, p in m.projector.named_parameters():
         assert float(p.grad.abs().max()) == 0.0, k
+
+
+# ============================================================================ MoE projector (BASELINE configs[3])
+def _moe(cfg_kw, w, **extra):
+    from tiny_audio_amd.projectors import MoEAudioProjector
+    cfg = ASRConfig(projector_type="moe", **cfg_kw, **extra)
+    p = MoEAudioProjector(cfg).to(DEV)
+    p.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return p
+
+
+def test_moe_projector_vs_golden(golden):
+    g = golden("projector_moe.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    w = OW.init_moe_projector(E, D, H)
+    p = _moe(dict(audio_config=S["enc"], text_config=S["lm"], projector_hidden_dim=H), w, router_jitter_noise=0.0)
+    x, dy = R.proj_input()
+    xb = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    p.eval()
+    y = p(xb)
+    assert relmax(npy(y), g["y_eval"]) < 2e-2 and float(p.get_aux_loss()) == 0.0
+    p.train()
+    y = p(xb)
+    aux = p.get_aux_loss()
+    assert relmax(npy(y), g["y_train"]) < 2e-2
+    assert abs(float(aux) - float(g["aux_train"])) < 2e-2 * abs(float(g["aux_train"])) + 1e-7
+    ((y * torch.from_numpy(dy).to(DEV)).sum() + 3.0 * aux).backward()
+    for k, prm in p.named_parameters():
+        ref = g["gt." + k]
+        if np.abs(ref).max() == 0:
+            assert float(prm.grad.abs().max()) == 0.0, k
+        else:
+            assert cosine(npy(prm.grad), ref) > 0.995, (k, cosine(npy(prm.grad), ref))
+
+
+def test_moe_projector_true_width_vs_oracle_with_jitter():
+    E, D, H = 1280, 1024, 1024
+    w = OW.init_moe_projector(E, D, H)
+    p = _moe(dict(audio_config=TRUE_ENC, text_config=TRUE_LM, projector_hidden_dim=H), w)
+    rng = np.random.RandomState(9)
+    x = rng.standard_normal((3, 101, E)).astype(np.float32)                      # 101 frames -> 25 tokens, tail dropped
+    xb = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    noise = rng.uniform(0.99, 1.01, size=(75, 4)).astype(np.float32)
+    p.train()
+    y = p(xb, jitter_noise=torch.from_numpy(noise))
+    aux = p.get_aux_loss()
+    ref, ref_aux, c = OP.moe_forward(npy(xb), w, training=True, jitter_noise=noise)
+    assert y.shape == (3, 25, D)
+    # routing is discrete: with bf16 activations a near-tie may flip an expert for a token; compare token-wise
+    bad = (np.abs(npy(y) - ref).max(-1) > 2e-2 * np.abs(ref).max()).mean()
+    assert bad < 0.03, bad
+    assert abs(float(aux) - float(ref_aux)) < 2e-2 * float(ref_aux)
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    (y * torch.from_numpy(dy).to(DEV)).sum().add(aux).backward()
+    gr = OP.moe_backward(dy, w, c, d_aux=1.0)
+    for k, prm in p.named_parameters():
+        assert cosine(npy(prm.grad), gr[k]) > 0.99, (k, cosine(npy(prm.grad), gr[k]))
+
+
+def test_asr_model_moe_vs_golden(golden):
+    g = golden("asr_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    cfg = ASRConfig(audio_config=S["enc"], text_config=S["lm"], projector_hidden_dim=H, projector_type="moe",
+                    audio_token_id=S["audio_token_id"], router_jitter_noise=0.0)
+    m = ASRModel(cfg, device=DEV, init="none")
+    m.audio_tower.load_state_dict_hf(OW.init_encoder(S["enc"], 0))
+    m.language_model.load_state_dict_hf(OW.init_lm(S["lm"], 1))
+    m.load_state_dict({"projector." + k: torch.from_numpy(v) for k, v in OW.init_moe_projector(E, D, H).items()})
+    ids, att, lab, counts = R.asr_tokens(g["counts"])
+    m.train()
+    out = m(input_ids=torch.from_numpy(ids), input_features=torch.from_numpy(g["input_features"]),
+            attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts))
+    out.loss.backward()
+    assert abs(float(out.loss) - float(g["moe.loss"])) < 5e-3 * float(g["moe.loss"])
+    assert abs(float(out.aux_loss) - float(g["moe.aux"])) < 2e-2 * abs(float(g["moe.aux"])) + 1e-7
+    for k in [k[len("moe.g."):] for k in g.files if k.startswith("moe.g.")]:
+        got = dict(m.projector.named_parameters())[k].grad
+        assert cosine(npy(got), g["moe.g." + k]) > 0.995, k

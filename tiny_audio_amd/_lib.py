@@ -21,7 +21,7 @@ HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
-           "logmel.hip", "optim.hip", "api.hip"]
+           "logmel.hip", "optim.hip", "moe.hip", "api.hip"]
 
 
 class Ta355Error(RuntimeError):
@@ -45,6 +45,14 @@ class EncoderWeights(C.Structure):
 class MlpWeights(C.Structure):
     _fields_ = [("enc_dim", C.c_int), ("k", C.c_int), ("hidden", C.c_int), ("llm_dim", C.c_int), ("eps", C.c_float),
                 ("w1", C.c_void_p), ("w2", C.c_void_p), ("w2_t", C.c_void_p), ("g1", C.c_void_p), ("g2", C.c_void_p)]
+
+
+class MoeWeights(C.Structure):
+    _fields_ = [("enc_dim", C.c_int), ("k", C.c_int), ("hidden", C.c_int), ("llm_dim", C.c_int), ("num_experts", C.c_int),
+                ("eps", C.c_float), ("aux_coef", C.c_float), ("z_coef", C.c_float),
+                ("norm_w", C.c_void_p), ("router_w", C.c_void_p),
+                ("w1", C.POINTER(C.c_void_p)), ("w1_t", C.POINTER(C.c_void_p)), ("b1", C.POINTER(C.c_void_p)),
+                ("w2", C.POINTER(C.c_void_p)), ("w2_t", C.POINTER(C.c_void_p)), ("b2", C.POINTER(C.c_void_p))]
 
 
 class LmLayer(C.Structure):

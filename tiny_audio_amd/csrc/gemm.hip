@@ -31,6 +31,10 @@ struct GemmArgs {
   long ldc; int c_rpb; long c_bs; long c_off;
   int tiles_m, tiles_n, splits;
   long slab_stride;    // elements between split-K slabs (C is f32 slabs when splits > 1)
+  // grouped / routed GEMM (MoE experts) without a host round trip: all three are DEVICE pointers or null
+  const int* a_idx;    // A row of logical row r is a_idx[seg_base + r] (gather); null = seg_base + r
+  const int* seg;      // {row base, row count}: this launch covers rows [base, base+count) of A (via a_idx) and of C
+  const int* krange;   // {first, last+1} K-tile (64-wide): contract only over that slice (per-expert dW over sorted slots)
 };
 
 #define BM 128
@@ -77,8 +81,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int m0 = pm * BM, n0 = pn * BN;
 
   const int nkt = p.K / BK;
-  const int kt_begin = (int)(((long)nkt * z) / p.splits);
-  const int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  int kt_begin = (int)(((long)nkt * z) / p.splits);
+  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  int Mact = p.M, rbase = 0;
+  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }   // block-uniform: before any barrier
 
   // ---- per-thread DMA source pointers: 4 x 16 B chunks of A and of W per K-step
   const int lr = tid >> 3;
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = i * 32 + lr;
-    const int gm = min(m0 + r, p.M - 1);
+    int gm = rbase + min(m0 + r, Mact - 1);
+    if (p.a_idx) gm = p.a_idx[gm];
     const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
     a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
     const int gn = min(n0 + r, p.N - 1);
@@ -152,8 +160,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= p.M) continue;
+    const int ml = m0 + wm * 64 + i * 16 + l15;
+    if (ml >= Mact) continue;
+    const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -231,8 +240,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int m0 = pm * BM2, n0 = pn * BN2;
 
   const int nkt = p.K / BK;
-  const int kt_begin = (int)(((long)nkt * z) / p.splits);
-  const int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  int kt_begin = (int)(((long)nkt * z) / p.splits);
+  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  int Mact = p.M, rbase = 0;
+  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
 
   const int lr = tid >> 3;                                    // 0..63
   const int clog = (tid & 7) ^ ((lr >> 1) & 7);
@@ -240,7 +252,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const char* w_src[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int gm = min(m0 + i * 64 + lr, p.M - 1);
+    int gm = rbase + min(m0 + i * 64 + lr, Mact - 1);
+    if (p.a_idx) gm = p.a_idx[gm];
     const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
     a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
   }
@@ -354,8 +367,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + l15;
-    if (m >= p.M) continue;
+    const int ml = m0 + wm * 128 + i * 16 + l15;
+    if (ml >= Mact) continue;
+    const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -470,12 +484,31 @@ extern "C" int ta_profile_gemm_collect(double* total_ms, double* total_flops, lo
 }
 
 // ----------------------------------------------------------------------------- C-ABI (see include/ta355.h)
+extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K,
+                                  long lda, int a_rpb, long a_bs,
+                                  long ldc, int c_rpb, long c_bs, long c_off,
+                                  const float* bias, const float* residual,
+                                  int act, int out_bf16, int splits, float* splitk_ws,
+                                  const int* a_idx, const int* seg, const int* krange, hipStream_t st);
+
 extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int N, int K,
                                long lda, int a_rpb, long a_bs,
                                long ldc, int c_rpb, long c_bs, long c_off,
                                const float* bias, const float* residual,
                                int act, int out_bf16, int splits, float* splitk_ws, hipStream_t st) {
+  return ta_gemm_bf16_nt_ex(A, W, C, M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, bias, residual, act, out_bf16,
+                            splits, splitk_ws, nullptr, nullptr, nullptr, st);
+}
+
+// M is the UPPER BOUND on rows when `seg` is given (grid sizing); the kernel reads the actual base/count on device.
+extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K,
+                                  long lda, int a_rpb, long a_bs,
+                                  long ldc, int c_rpb, long c_bs, long c_off,
+                                  const float* bias, const float* residual,
+                                  int act, int out_bf16, int splits, float* splitk_ws,
+                                  const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return TA_OK;
+  if ((a_idx || seg || krange) && splits > 1) return TA_ERR_ARG;
   if ((K % BK) != 0 || (N % 4) != 0 || (lda % 8) != 0 || (a_bs % 8) != 0 || (ldc % 4) != 0 ||
       (c_off % 4) != 0 || (c_bs % 4) != 0)
     return TA_ERR_ARG;
@@ -483,7 +516,9 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
   a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = C; a.bias = bias; a.res = residual;
   a.M = M; a.N = N; a.K = K;
   a.lda = lda; a.a_rpb = a_rpb > 0 ? a_rpb : M; a.a_bs = a_bs;
-  a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : M; a.c_bs = c_bs; a.c_off = c_off;
+  a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : (seg ? 0x7fffffff : M); a.c_bs = c_bs; a.c_off = c_off;
+  if (seg && a_rpb <= 0) a.a_rpb = 0x7fffffff;
+  a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
   a.splits = splits > 1 ? splits : 1;
   if (a.splits > K / BK) a.splits = K / BK;

@@ -111,4 +111,152 @@ class MLPAudioProjector(nn.Module):
                                      self)
 
 
-PROJECTOR_CLASSES = {"mlp": MLPAudioProjector}
+# =============================================================================
+# Shared + sparse MoE projector (tiny_audio/projectors.py:185-351)
+# =============================================================================
+class SimpleAdapter(nn.Module):
+    """Parameter holder for a 2-layer GELU adapter (tiny_audio/projectors.py:90-100): fc1 / fc2 with bias."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.fc1 = nn.Linear(input_dim, hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, output_dim)
+
+
+class _MoEProjectorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, noise, mod, *params):
+        B, S, _ = x.shape
+        xb = x.detach()
+        xb = (xb if xb.dtype == BF16 else xb.to(BF16)).contiguous()
+        wts = mod._packed_weights()
+        L_ = _lib.lib()
+        dev = x.device
+        training = bool(mod.training)
+        N = mod.get_output_length(S)
+        tape = torch.empty(L_.ta_moe_tape_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
+        y = torch.empty((B, N, mod.llm_dim), device=dev, dtype=F32)
+        aux = torch.zeros((), device=dev, dtype=F32)
+        nz = None if noise is None else noise.to(device=dev, dtype=F32).contiguous()
+        _lib.check(L_.ta_moe_projector_forward(C.byref(wts), ptr(xb), B, S, ptr(nz), int(training), ptr(y), ptr(aux), ptr(tape),
+                                               stream()), "ta_moe_projector_forward")
+        ctx.mod, ctx.xb, ctx.tape, ctx.dims, ctx.noise, ctx.training = mod, xb, tape, (B, S), nz, training
+        return y, aux
+
+    @staticmethod
+    def backward(ctx, dy, d_aux):
+        mod, (B, S) = ctx.mod, ctx.dims
+        wts = mod._packed_weights()
+        L_ = _lib.lib()
+        dev = dy.device
+        dy = dy.to(F32).contiguous()
+        E = mod.num_experts
+        adapters = list(mod.experts) + [mod.shared_expert]
+        g_norm = torch.empty_like(mod.norm.weight, dtype=F32)
+        g_router = torch.empty_like(mod.router.weight, dtype=F32)
+        gW1 = [torch.empty_like(a.fc1.weight, dtype=F32) for a in adapters]
+        gb1 = [torch.empty_like(a.fc1.bias, dtype=F32) for a in adapters]
+        gW2 = [torch.empty_like(a.fc2.weight, dtype=F32) for a in adapters]
+        gb2 = [torch.empty_like(a.fc2.bias, dtype=F32) for a in adapters]
+        arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
+        ws = torch.empty(L_.ta_moe_bwd_workspace_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
+        # d_aux is the upstream gradient of the auxiliary loss (1.0 when loss = CE + aux); one host read of a scalar
+        da = float(d_aux) if d_aux is not None else 0.0
+        _lib.check(L_.ta_moe_projector_backward(C.byref(wts), ptr(ctx.xb), B, S, ptr(dy), da, ptr(ctx.noise), int(ctx.training),
+                                                ptr(ctx.tape), ptr(g_norm), ptr(g_router), arr(gW1), arr(gb1), arr(gW2),
+                                                arr(gb2), ptr(ws), ws.numel(), stream()), "ta_moe_projector_backward")
+        ctx.tape = None
+        grads = [g_norm, g_router]
+        for i in range(E + 1):
+            grads += [gW1[i], gb1[i], gW2[i], gb2[i]]
+        return (None, None, None, *grads)
+
+
+class MoEAudioProjector(nn.Module):
+    """MoE projector with shared expert (DeepSeek-style): norm -> shared adapter + top-2-of-E routed adapters."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.k = getattr(config, "projector_pool_stride", 4)
+        self.aux_coef = getattr(config, "router_aux_loss_coef", 0.01)
+        self.router_z_loss_coef = getattr(config, "router_z_loss_coef", 1e-4)          # projectors.py:206-211
+        self.router_jitter_noise = getattr(config, "router_jitter_noise", 0.01)
+        self.encoder_dim, self.llm_dim = config.encoder_dim, config.llm_dim
+        in_dim = config.encoder_dim * self.k
+        self.hidden_dim = getattr(config, "projector_hidden_dim", None) or config.llm_dim
+        self.num_experts = getattr(config, "num_experts", 4)
+        self.top_k = getattr(config, "num_experts_per_tok", 2)
+        if self.top_k != 2 or not (2 <= self.num_experts <= 8):
+            raise ValueError("ta355 MoE kernels implement top-2 routing over 2..8 experts (the reference's configuration)")
+        self.norm = _RMSNormWeight(in_dim, eps=1e-6)
+        self.router = nn.Linear(in_dim, self.num_experts, bias=False)
+        self.experts = nn.ModuleList([SimpleAdapter(in_dim, self.hidden_dim, config.llm_dim) for _ in range(self.num_experts)])
+        self.shared_expert = SimpleAdapter(in_dim, self.hidden_dim, config.llm_dim)
+        self._init_weights()
+        self.last_aux_loss = torch.tensor(0.0)
+        self._pack = None
+        self._pack_versions = None
+
+    def _init_weights(self):
+        """projectors.py:242-251: router N(0, .02); fc1 xavier-uniform; fc2 N(0, .01)."""
+        with torch.no_grad():
+            nn.init.normal_(self.router.weight, mean=0.0, std=0.02)
+            for expert in [self.shared_expert, *self.experts]:
+                nn.init.xavier_uniform_(expert.fc1.weight)
+                nn.init.normal_(expert.fc2.weight, mean=0.0, std=0.01)
+
+    def get_output_length(self, input_length):
+        return (input_length - self.k) // self.k + 1
+
+    def get_aux_loss(self):
+        return self.last_aux_loss
+
+    def _param_list(self):
+        ps = [self.norm.weight, self.router.weight]
+        for a in list(self.experts) + [self.shared_expert]:
+            ps += [a.fc1.weight, a.fc1.bias, a.fc2.weight, a.fc2.bias]
+        return ps
+
+    def _packed_weights(self):
+        ps = self._param_list()
+        versions = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._pack is None or versions != self._pack_versions:
+            E = self.num_experts
+            keep = []
+            f32 = lambda p: p.detach().to(F32).contiguous()
+            norm_w, router_w = f32(self.norm.weight), f32(self.router.weight)
+            w1, w1t, b1, w2, w2t, b2 = [], [], [], [], [], []
+            for a in list(self.experts) + [self.shared_expert]:
+                W1, W2 = f32(a.fc1.weight), f32(a.fc2.weight)
+                w1.append(cast_bf16(W1)); w1t.append(transpose_to_bf16(W1))
+                w2.append(cast_bf16(W2)); w2t.append(transpose_to_bf16(W2))
+                b1.append(f32(a.fc1.bias)); b2.append(f32(a.fc2.bias))
+            arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
+            arrays = [arr(w1), arr(w1t), arr(b1), arr(w2), arr(w2t), arr(b2)]
+            wts = _lib.MoeWeights(enc_dim=self.encoder_dim, k=self.k, hidden=self.hidden_dim, llm_dim=self.llm_dim,
+                                  num_experts=E, eps=1e-6, aux_coef=float(self.aux_coef), z_coef=float(self.router_z_loss_coef),
+                                  norm_w=norm_w.data_ptr(), router_w=router_w.data_ptr())
+            for name, a in zip(("w1", "w1_t", "b1", "w2", "w2_t", "b2"), arrays):
+                setattr(wts, name, C.cast(a, C.POINTER(C.c_void_p)))
+            keep = [norm_w, router_w, w1, w1t, b1, w2, w2t, b2, arrays]
+            self._pack = (wts, keep)
+            self._pack_versions = versions
+        return self._pack[0]
+
+    def forward(self, x: torch.Tensor, jitter_noise: torch.Tensor = None) -> torch.Tensor:
+        """x [B, S, encoder_dim] -> [B, N, llm_dim] fp32.  ``jitter_noise`` [B*N, E] injects the multiplicative router
+        noise (tests); in training it is otherwise drawn U(1-eps, 1+eps) as the reference does (projectors.py:294-300)."""
+        if not x.is_cuda and not _lib.DRY_RUN:
+            raise _lib.Ta355Error("MoEAudioProjector runs on the MI355X HIP path only (no CPU fallback)")
+        B, S, _ = x.shape
+        T = B * self.get_output_length(S)
+        noise = jitter_noise
+        if noise is None and self.training and self.router_jitter_noise > 0:
+            noise = torch.empty((T, self.num_experts), device=x.device, dtype=F32).uniform_(
+                1.0 - self.router_jitter_noise, 1.0 + self.router_jitter_noise)
+        y, aux = _MoEProjectorFn.apply(x, noise, self, *self._param_list())
+        self.last_aux_loss = aux
+        return y
+
+
+PROJECTOR_CLASSES = {"mlp": MLPAudioProjector, "moe": MoEAudioProjector}
