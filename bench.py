@@ -39,6 +39,8 @@ def parse():
                     help="'full' additionally materialises outputs.logits [B, L, V] (bf16) every step as the reference does; "
                          "'labelled' computes the loss head only on label positions (identical loss and gradients)")
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
+    ap.add_argument("--projector", choices=["mlp", "moe"], default="mlp",
+                    help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -75,10 +77,9 @@ def main():
     from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
     from oracle import weights as OW
 
-    cfg = ASRConfig(projector_type="mlp", projector_hidden_dim=1024, audio_token_dropout=a.dropout)
-    model = ASRModel(cfg, device=dev, init="random", seed=0)      # identical frozen + projector weights on every rank
-    torch.manual_seed(0)
-    model.projector.linear_1.reset_parameters(); model.projector.linear_2.reset_parameters()
+    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=1024, audio_token_dropout=a.dropout)
+    torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
+    model = ASRModel(cfg, device=dev, init="random", seed=0)
     model.train()
     fe = LogMelFeatureExtractor(128, dev)
     trainer = ASRTrainer(model, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0,
@@ -152,7 +153,7 @@ def main():
                     "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3)}
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0 and world == 1:
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp":
         cpu = cpu_baseline(model, cfg, L)
 
     if rank == 0:
@@ -161,7 +162,9 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
-               "config": {"workload": "configs[1]: MLP projector (H=D=1024) bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
+               "config": {"workload": ("configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
+                                       "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
+                                      " bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
                                       "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,
                           "clips_per_gpu": B, "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
                           "logits": a.logits, "audio_token_dropout": a.dropout,
