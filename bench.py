@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
     ap.add_argument("--projector", choices=["mlp", "moe"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
+    ap.add_argument("--lora", action="store_true",
+                    help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -77,7 +79,8 @@ def main():
     from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
     from oracle import weights as OW
 
-    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=1024, audio_token_dropout=a.dropout)
+    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=1024, audio_token_dropout=a.dropout,
+                    use_lora=a.lora, freeze_projector=a.lora)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
     model.train()
@@ -153,7 +156,7 @@ def main():
                     "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3)}
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp":
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora:
         cpu = cpu_baseline(model, cfg, L)
 
     if rank == 0:
@@ -162,7 +165,8 @@ def main():
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
-               "config": {"workload": ("configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
+               "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
+                                       else "configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
                                       " bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
                                       "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,

@@ -134,7 +134,16 @@ typedef struct {
   const float* ln_post_w;           /* [D] */
   const void *wgu, *wgu_t;          /* bf16 [2F, D] rows = gate | up, [D, 2F] */
   const void *wd, *wd_t;            /* bf16 [D, F], [F, D] */
+  /* LoRA adapters (stage 2, tiny_audio/asr_modeling.py:289-301; all NULL when disabled): fp32 MASTERS, the peft
+   * tensors of the linears that share an input stacked on rows, group g in {qkv, o, gate|up, down}:
+   *   la_g [members*r, in_g] = concat of lora_A_j [r, in];   lb_g [N_g, r] = concat of lora_B_j [out_j, r]. */
+  const float *la_qkv, *lb_qkv, *la_o, *lb_o, *la_gu, *lb_gu, *la_d, *lb_d;
 } ta_lm_layer;
+
+/* gradients of the LoRA masters of one layer (same layouts; written, not accumulated) */
+typedef struct {
+  float *dla_qkv, *dlb_qkv, *dla_o, *dlb_o, *dla_gu, *dlb_gu, *dla_d, *dlb_d;
+} ta_lm_lora_grads;
 
 typedef struct {
   int vocab, vocab_pad, hidden, ffn, n_layers, heads, kv_heads, head_dim, max_pos;
@@ -145,6 +154,8 @@ typedef struct {
   const float* norm_w;
   const float *rope_cos, *rope_sin; /* [max_pos, head_dim/2] */
   const ta_lm_layer* layers;        /* host array */
+  int lora_rank;                    /* 0 = no adapters; else r (8) */
+  float lora_scale;                 /* alpha / r */
 } ta_lm_weights;
 
 long ta_lm_tape_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows);
@@ -158,10 +169,11 @@ int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_r
                        const int* kmask, const int* pos, int B, int L, const int* label_rows,
                        const long* label_targets, int n_label_rows, float loss_scale, float* loss,
                        float* nll_rows, void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st);
-/* d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written); d_embeds optional [B*L, D]. */
+/* d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written; NULL = not wanted, e.g. frozen
+ * projector); d_embeds optional [B*L, D]; lora_grads: host array [n_layers] (required iff w->lora_rank > 0). */
 int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
                    const int* label_rows, int n_label_rows, float* d_audio, long n_audio_rows, float* d_embeds,
-                   const void* tape, void* ws, long ws_bytes, hipStream_t st);
+                   const ta_lm_lora_grads* lora_grads, const void* tape, void* ws, long ws_bytes, hipStream_t st);
 
 /* ============================================================================================
  * Primitive kernels (exported for the parity tests; also what the composites are built from)
@@ -180,6 +192,9 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
                        long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
                        int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
                        const int* krange, hipStream_t st);
+/* K extension (LoRA): arms the NEXT ta_gemm_bf16_nt* call of this host thread to compute
+ * C = epilogue(A W^T + A2 W2^T) with A2 [M, K2] (row stride lda2) and W2 [N, K2], K2 % 64 == 0, in one pass. */
+int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */

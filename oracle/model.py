@@ -67,7 +67,7 @@ def asr_forward(batch, W, cfg, keep_cache=True, frame_keep_mask=None, moe_noise=
     packed = gather_audio_embeds(y, counts)
     x0 = masked_scatter_rows(emb, is_audio, packed)
     logits, lc = qwen3.lm_forward(x0, batch.get("attention_mask"), W["lm"], cfg["lm"],
-                                  keep_cache=keep_cache)
+                                  keep_cache=keep_cache, lora=W.get("lora"), lora_scale=cfg.get("lora_scale", 0.0))
     out = dict(logits=logits, audio_embeds=y, encoder_out=hs, inputs_embeds=x0, aux_loss=aux)
     if batch.get("labels") is not None:
         ce, dlogits, n_tok = qwen3.causal_lm_loss(logits, batch["labels"], num_items_in_batch)
@@ -78,9 +78,11 @@ def asr_forward(batch, W, cfg, keep_cache=True, frame_keep_mask=None, moe_noise=
 
 
 def asr_backward(out, W, cfg):
-    """Gradients of out['loss'] w.r.t. the projector parameters (encoder and LM frozen)."""
+    """Gradients of out['loss'] w.r.t. the projector parameters (encoder and LM frozen); with W['lora'] the adapter
+    gradients are returned under 'lora.<name>' keys as well (stage-2 training, BASELINE configs[4])."""
     c = out["_cache"]
-    dx0 = qwen3.lm_backward_dx(out["_dlogits"], W["lm"], cfg["lm"], c["lc"])
+    lg = {} if W.get("lora") is not None else None
+    dx0 = qwen3.lm_backward_dx(out["_dlogits"], W["lm"], cfg["lm"], c["lc"], W.get("lora"), cfg.get("lora_scale", 0.0), lg)
     idx = np.argwhere(c["is_audio"])
     dpacked = dx0[idx[:, 0], idx[:, 1]]
     B, N, D = c["y_shape"]
@@ -92,6 +94,8 @@ def asr_backward(out, W, cfg):
         grads = proj.mlp_backward(dy, W["projector"], c["pc"])
     else:
         grads = proj.moe_backward(dy, W["projector"], c["pc"], d_aux=1.0)
+    if lg is not None:
+        grads.update({"lora." + k: v for k, v in lg.items()})
     return grads, dx0
 
 

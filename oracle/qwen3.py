@@ -37,8 +37,32 @@ def attn_allowed(att_mask, L):
     return causal[None] & (np.asarray(att_mask) != 0)[:, None, :]
 
 
-def layer_forward(x, w, p, cfg, cos, sin, allowed):
+LORA_TARGETS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")        # tiny_audio/asr_config.py:142-150
+
+
+def _eff(w, lora, name, scale):
+    """Effective weight of a LoRA-adapted linear: W + (alpha/r) B A  (peft LoraLayer: result = base(x) +
+    lora_B(lora_A(dropout(x))) * scaling, dropout 0; wired at tiny_audio/asr_modeling.py:289-301).  peft itself is not
+    installed offline, so this is a restatement of its documented formula."""
+    W = w[name + ".weight"]
+    if lora is None or (name + ".lora_A") not in lora:
+        return W
+    return (W + np.float32(scale) * (lora[name + ".lora_B"] @ lora[name + ".lora_A"])).astype(np.float32)
+
+
+def _lora_grads(grads, lora, name, scale, dW):
+    """dA = s B^T dW, dB = s dW A^T for W_eff = W + s B A."""
+    if grads is None or lora is None or (name + ".lora_A") not in lora:
+        return
+    A, Bm = lora[name + ".lora_A"], lora[name + ".lora_B"]
+    grads[name + ".lora_A"] = (np.float32(scale) * (Bm.T @ dW)).astype(np.float32)
+    grads[name + ".lora_B"] = (np.float32(scale) * (dW @ A.T)).astype(np.float32)
+
+
+def layer_forward(x, w, p, cfg, cos, sin, allowed, lora=None, lora_scale=0.0):
     B, L, D = x.shape
+    w = {**w, **{p + n + ".weight": _eff(w, lora, p + n, lora_scale) for n in LORA_TARGETS}} if lora is not None else w
     hq, hkv, hd, eps = cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["rms_eps"]
     g = hq // hkv
     xn, r_in = rms(x, w[p + "input_layernorm.weight"], eps)
@@ -66,13 +90,16 @@ def layer_forward(x, w, p, cfg, cos, sin, allowed):
     act = silu(gt) * up
     x2 = x1 + act @ w[p + "mlp.down_proj.weight"].T
     cache = dict(x=x, r_in=r_in, xn=xn, q0=q0, k0=k0, rq=rq, rk=rk, q=q, k=k, v=v, P=P, ao=ao,
-                 x1=x1, r_post=r_post, xn2=xn2, gt=gt, up=up)
+                 x1=x1, r_post=r_post, xn2=xn2, gt=gt, up=up, act=act)
     return x2.astype(np.float32), cache
 
 
-def layer_backward_dx(dx2, w, p, cfg, cos, sin, c):
-    """dL/dx for a frozen decoder layer (no weight gradients)."""
+def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, grads=None):
+    """dL/dx for a frozen decoder layer (no base-weight gradients); with ``lora`` also the adapter gradients."""
     B, L, D = dx2.shape
+    w = {**w, **{p + n + ".weight": _eff(w, lora, p + n, lora_scale) for n in LORA_TARGETS}} if lora is not None else w
+    flat = lambda a: a.reshape(-1, a.shape[-1])
+    _lora_grads(grads, lora, p + "mlp.down_proj", lora_scale, flat(dx2).T @ flat(c["act"]))
     hq, hkv, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
     g = hq // hkv
     # MLP
@@ -80,9 +107,12 @@ def layer_backward_dx(dx2, w, p, cfg, cos, sin, c):
     sg = 1.0 / (1.0 + np.exp(-c["gt"]))
     dgt = dact * c["up"] * (sg * (1.0 + c["gt"] * (1.0 - sg)))
     dup = dact * (c["gt"] * sg)
+    _lora_grads(grads, lora, p + "mlp.gate_proj", lora_scale, flat(dgt).T @ flat(c["xn2"]))
+    _lora_grads(grads, lora, p + "mlp.up_proj", lora_scale, flat(dup).T @ flat(c["xn2"]))
     dxn2 = dgt @ w[p + "mlp.gate_proj.weight"] + dup @ w[p + "mlp.up_proj.weight"]
     dx1 = dx2 + rms_bwd_dx(dxn2, c["x1"], c["r_post"], w[p + "post_attention_layernorm.weight"])
     # attention
+    _lora_grads(grads, lora, p + "self_attn.o_proj", lora_scale, flat(dx1).T @ flat(c["ao"]))
     dao = (dx1 @ w[p + "self_attn.o_proj.weight"]).reshape(B, L, hq, hd).transpose(0, 2, 1, 3)
     kr = np.repeat(c["k"], g, axis=1)
     vr = np.repeat(c["v"], g, axis=1)
@@ -102,13 +132,16 @@ def layer_backward_dx(dx2, w, p, cfg, cos, sin, c):
     dq0 = rms_bwd_dx(dqn, c["q0"], c["rq"], w[p + "self_attn.q_norm.weight"]).reshape(B, L, hq * hd)
     dk0 = rms_bwd_dx(dkn, c["k0"], c["rk"], w[p + "self_attn.k_norm.weight"]).reshape(B, L, hkv * hd)
     dv0 = dv.transpose(0, 2, 1, 3).reshape(B, L, hkv * hd)
+    _lora_grads(grads, lora, p + "self_attn.q_proj", lora_scale, flat(dq0).T @ flat(c["xn"]))
+    _lora_grads(grads, lora, p + "self_attn.k_proj", lora_scale, flat(dk0).T @ flat(c["xn"]))
+    _lora_grads(grads, lora, p + "self_attn.v_proj", lora_scale, flat(dv0).T @ flat(c["xn"]))
     dxn = (dq0 @ w[p + "self_attn.q_proj.weight"] + dk0 @ w[p + "self_attn.k_proj.weight"]
            + dv0 @ w[p + "self_attn.v_proj.weight"])
     dx = dx1 + rms_bwd_dx(dxn, c["x"], c["r_in"], w[p + "input_layernorm.weight"])
     return dx.astype(np.float32)
 
 
-def lm_forward(inputs_embeds, att_mask, w, cfg, position_ids=None, keep_cache=True):
+def lm_forward(inputs_embeds, att_mask, w, cfg, position_ids=None, keep_cache=True, lora=None, lora_scale=0.0):
     """inputs_embeds [B, L, D] -> logits [B, L, V] (tied lm_head, :485-487)."""
     B, L, D = inputs_embeds.shape
     pos = np.arange(L) if position_ids is None else np.asarray(position_ids)
@@ -118,7 +151,7 @@ def lm_forward(inputs_embeds, att_mask, w, cfg, position_ids=None, keep_cache=Tr
     x = inputs_embeds.astype(np.float32)
     caches = []
     for i in range(cfg["layers"]):
-        x, c = layer_forward(x, w, f"model.layers.{i}.", cfg, cos, sin, allowed)
+        x, c = layer_forward(x, w, f"model.layers.{i}.", cfg, cos, sin, allowed, lora, lora_scale)
         caches.append(c if keep_cache else None)
     hn, r_f = rms(x, w["model.norm.weight"], cfg["rms_eps"])
     logits = hn @ w["model.embed_tokens.weight"].T
@@ -145,11 +178,11 @@ def causal_lm_loss(logits, labels, num_items_in_batch=None):
     return np.float32(loss), dlogits.reshape(B, L, V).astype(np.float32), int(valid.sum())
 
 
-def lm_backward_dx(dlogits, w, cfg, cache):
-    """d loss / d inputs_embeds through the frozen LM."""
+def lm_backward_dx(dlogits, w, cfg, cache, lora=None, lora_scale=0.0, grads=None):
+    """d loss / d inputs_embeds through the frozen LM (and, with ``lora``/``grads``, the adapter gradients)."""
     dhn = dlogits @ w["model.embed_tokens.weight"]
     dx = rms_bwd_dx(dhn, cache["x_final"], cache["r_f"], w["model.norm.weight"])
     for i in reversed(range(cfg["layers"])):
         dx = layer_backward_dx(dx, w, f"model.layers.{i}.", cfg, cache["cos"], cache["sin"],
-                               cache["layers"][i])
+                               cache["layers"][i], lora, lora_scale, grads)
     return dx

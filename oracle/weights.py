@@ -132,6 +132,23 @@ def init_moe_projector(enc_dim, llm_dim, hidden=None, k=4, num_experts=4, seed=3
     return w
 
 
+def init_lora(cfg, rank=8, seed=4, b_std=0.02):
+    """LoRA adapters on q,k,v,o,gate,up,down of every layer (tiny_audio/asr_config.py:142-150, r=8).  peft initialises
+    lora_A kaiming-uniform and lora_B = 0; B is given small random values here so that parity is non-trivial."""
+    rng = np.random.RandomState(seed)
+    D, F = cfg["hidden"], cfg["ffn"]
+    hq, hkv, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+    dims = {"self_attn.q_proj": (hq * hd, D), "self_attn.k_proj": (hkv * hd, D), "self_attn.v_proj": (hkv * hd, D),
+            "self_attn.o_proj": (D, hq * hd), "mlp.gate_proj": (F, D), "mlp.up_proj": (F, D), "mlp.down_proj": (D, F)}
+    lo = {}
+    for i in range(cfg["layers"]):
+        for n, (o, k) in dims.items():
+            b = 1.0 / np.sqrt(k)
+            lo[f"model.layers.{i}.{n}.lora_A"] = rng.uniform(-b, b, size=(rank, k)).astype(np.float32)
+            lo[f"model.layers.{i}.{n}.lora_B"] = (b_std * rng.standard_normal((o, rank))).astype(np.float32)
+    return lo
+
+
 def synthetic_wave(b: int, n: int = 160000) -> np.ndarray:
     """wav[b] = 0.1*N(0,1), RandomState(1234+b)."""
     return (0.1 * np.random.RandomState(1234 + b).standard_normal(n)).astype(np.float32)

@@ -92,12 +92,63 @@ def test_moe_plumbing(dry):
     assert "ta_moe_projector_forward" in dry.calls and "ta_moe_projector_backward" in dry.calls
 
 
+def test_lora_stage2_plumbing(dry):
+    """Row a11: use_lora + freeze_projector -> exactly the 8 stacked adapter Parameters train; peft-named state dict
+    round-trips through the stacked layout; the C structs carry per-layer pointers into the masters."""
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=3, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, use_lora=True,
+                    freeze_projector=True)
+    m = ASRModel(cfg, device="cpu", init="random")
+    train = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    assert sorted(train) == sorted(f"language_model.lora_{ab}_{g}" for ab in ("la", "lb") for g in ("qkv", "o", "gu", "d"))
+    # the true Qwen3-0.6B adapter has 5,046,272 trainable parameters (SURVEY.md section 8 row a11: "5.05 M")
+    full = ASRModel(ASRConfig(use_lora=True, freeze_projector=True), device="cpu", init="none")
+    assert sum(p.numel() for p in full.language_model.lora_parameters()) == 5_046_272
+    lmod = m.language_model
+    assert float(lmod.lora_lb_qkv.detach().abs().max()) == 0.0 and float(lmod.lora_la_qkv.detach().abs().max()) <= 1 / 16 + 1e-6   # peft init
+    lo = OW.init_lora(lm, rank=8, seed=4)
+    lmod.load_lora_state_dict(lo)
+    back = lmod.export_lora_state_dict(prefix="model.", suffix="")
+    assert set(back) == set(lo)
+    for k in lo:
+        np.testing.assert_array_equal(back[k].numpy(), lo[k])
+    sd = m.state_dict()
+    assert "language_model.base_model.model.model.layers.2.mlp.down_proj.lora_B.weight" in sd
+    m2 = ASRModel(cfg, device="cpu", init="random", seed=5)
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.language_model.lora_lb_gu, lmod.lora_lb_gu) and torch.equal(m2.language_model.lora_la_o, lmod.lora_la_o)
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
+    m.train()
+    out = m(**batch)
+    out.loss.backward()
+    for n, p in train.items():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+    assert all(p.grad is None for p in m.projector.parameters())
+    assert lmod._w.lora_rank == 8 and abs(lmod._w.lora_scale - 4.0) < 1e-6
+    step = lmod.lora_lb_gu[0].numel() * 4
+    assert lmod._layers_arr[2].lb_gu == lmod.lora_lb_gu.data_ptr() + 2 * step
+    tr = ASRTrainer(m, TrainingArguments())
+    assert tr.flat.n == sum(p.numel() for p in train.values())
+    tr.training_step(batch)                                   # masters re-homed into the flat buffer -> pointers rebound
+    assert lmod._layers_arr[1].la_d == lmod.lora_la_d.data_ptr() + lmod.lora_la_d[0].numel() * 4
+    assert lmod.lora_la_d.data_ptr() >= tr.flat.flat_p.data_ptr()
+    with pytest.raises(NotImplementedError):
+        ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16), device="cpu", init="none")
+
+
 def test_primitive_wrappers_marshal(dry):
     from tiny_audio_amd import ops
     bf, f32 = torch.bfloat16, torch.float32
     A, W = torch.zeros(70, 128, dtype=bf), torch.zeros(256, 128, dtype=bf)
     assert ops.gemm_nt(A, W, bias=torch.zeros(256), residual=torch.zeros(70, 256), act=1, out_dtype=f32).shape == (70, 256)
     assert ops.gemm_nt(A, W, out_dtype=f32, splits=2).dtype == f32
+    ops.gemm_nt(A, W, out_dtype=f32, k_ext=(torch.zeros(70, 64, dtype=bf), torch.zeros(256, 64, dtype=bf)))
     x = torch.zeros(10, 256)
     ops.layernorm(x, torch.ones(256), torch.zeros(256), out_f32=True)
     yb, yf, r = ops.rmsnorm_fwd(x, torch.ones(256), act_gelu=True, out_f32=True)

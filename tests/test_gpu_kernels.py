@@ -55,6 +55,23 @@ def test_gemm_epilogues():
     assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=BF16), torch.nn.functional.gelu(ref)) < 1.5e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 64, 256), (1000, 1024, 1024), (6144, 4096, 1024), (4100, 1024, 3072)])
+@pytest.mark.parametrize("variant", [None, "0", "1", "3"])
+def test_gemm_k_extension(M, N, K, variant, monkeypatch):
+    """C = A W^T + A2 W2^T in one launch (one extra 64-wide K tile: the fused LoRA update), every tile variant."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    A2, W2 = rnd(M, 64, seed=3, dtype=BF16), rnd(N, 64, seed=4, scale=0.2, dtype=BF16)
+    res = rnd(M, N, seed=5)
+    ref = A.float() @ W.float().T + A2.float() @ W2.float().T
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32, k_ext=(A2, W2)), ref) < 2e-3
+    assert relerr(ops.gemm_nt(A, W, out_dtype=BF16, k_ext=(A2, W2)), ref) < 1.5e-2
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32, residual=res, k_ext=(A2, W2)), ref + res) < 2e-3
+    # one-shot: the next call is a plain GEMM again
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32), A.float() @ W.float().T) < 2e-3
+
+
 @pytest.mark.parametrize("splits", [2, 5, 16])
 def test_gemm_splitk(splits):
     M, N, K = 200, 256, 64 * 37

@@ -225,11 +225,120 @@ def test_lm_text_only_and_dx_vs_oracle():
     valid = att.astype(bool)
     got = npy(logits).reshape(B, L, -1)[:, :, :TRUE_LM["vocab"]]
     assert logits_close(got[valid], ref_logits[valid])
-    _, d_emb = lm.backward_from_ctx(ctx, 1, want_d_embeds=True)
+    _, d_emb, _ = lm.backward_from_ctx(ctx, 1, want_d_embeds=True)
     ref_dx = OQ.lm_backward_dx(dlogits, wL, TRUE_LM, cache)
     got_dx = npy(d_emb).reshape(B, L, -1)
     assert cosine(got_dx[valid], ref_dx[valid]) > 0.999
     assert relmax(got_dx[valid], ref_dx[valid]) < 5e-2
+
+
+# ============================================================================ LoRA stage 2 (row a11, BASELINE configs[4])
+def _lora_case(cfg, wL, lo, x_ids, att, lab):
+    """HIP LM with adapters vs oracle: loss, logits, d(inputs_embeds), every adapter gradient."""
+    lm = Qwen3MI355X(LMConfig(cfg), DEV).load_state_dict_hf(wL)
+    lm.enable_lora(rank=8, alpha=32).load_lora_state_dict(lo)
+    B, L = x_ids.shape
+    rows, tg, n = ops.label_rows(torch.from_numpy(lab).to(DEV))
+    n = int(n.item())
+    loss, nll, logits, ctx = lm.forward_loss(torch.from_numpy(x_ids).to(DEV), None, None, torch.from_numpy(att).to(DEV).int(),
+                                             rows, tg, n, 1.0 / n, want_logits=True)
+    x0 = wL["model.embed_tokens.weight"][x_ids]
+    ref_logits, cache = OQ.lm_forward(x0, att, wL, cfg, lora=lo, lora_scale=4.0)
+    ref_loss, dlogits, n_ref = OQ.causal_lm_loss(ref_logits, lab)
+    base_logits, _ = OQ.lm_forward(x0, att, wL, cfg)
+    valid = att.astype(bool)
+    got = npy(logits).reshape(B, L, -1)[:, :, :cfg["vocab"]]
+    assert n == n_ref and abs(float(loss) - float(ref_loss)) < 5e-3 * float(ref_loss)
+    assert logits_close(got[valid], ref_logits[valid])
+    # the adapters must actually matter in this case, otherwise the comparison above proves nothing
+    assert np.abs(ref_logits[valid] - base_logits[valid]).max() > 0.3
+    _, d_emb, lg = lm.backward_from_ctx(ctx, 1, want_d_embeds=True, want_d_audio=False)
+    ref_g = {}
+    ref_dx = OQ.lm_backward_dx(dlogits, wL, cfg, cache, lo, 4.0, ref_g)
+    got_dx = npy(d_emb).reshape(B, L, -1)
+    assert cosine(got_dx[valid], ref_dx[valid]) > 0.999
+    # export the packed gradient tensors through the same name mapping as the parameters
+    for p_, g_ in zip(lm.lora_parameters(), lg):
+        p_.data.copy_(g_)
+    got_g = lm.export_lora_state_dict(prefix="model.", suffix="")
+    assert set(got_g) == set(ref_g)
+    for k in ref_g:
+        assert cosine(npy(got_g[k]), ref_g[k]) > 0.998, k
+        assert relmax(npy(got_g[k]), ref_g[k]) < 6e-2, k
+
+
+def test_lora_vs_golden_config(golden):
+    """Reduced config of tests/golden/lora_small.npz (values produced by the reference's Qwen3 + merged adapters)."""
+    g = golden("lora_small.npz")
+    cfg = R.SMALL["lm"]
+    wL, lo = OW.init_lm(cfg, seed=1), OW.init_lora(cfg, rank=8, seed=4)
+    lm = Qwen3MI355X(LMConfig(cfg), DEV).load_state_dict_hf(wL)
+    lm.enable_lora(rank=8, alpha=32).load_lora_state_dict(lo)
+    x, att, lab = R.lm_input()                                    # inputs_embeds-level fixture: feed as "audio" rows
+    B, L, D = x.shape
+    ids = torch.full((B, L), R.SMALL["audio_token_id"], dtype=torch.int64, device=DEV)
+    src = torch.arange(B * L, dtype=torch.int32, device=DEV)
+    rows, tg, n = ops.label_rows(torch.from_numpy(lab).to(DEV))
+    n = int(n.item())
+    audio = torch.from_numpy(x.reshape(B * L, D)).to(DEV)
+    loss, nll, logits, ctx = lm.forward_loss(ids, src, audio, torch.from_numpy(att).to(DEV).int(), rows, tg, n, 1.0 / n,
+                                             want_logits=True)
+    assert abs(float(loss) - float(g["loss"])) < 5e-3 * float(g["loss"])
+    d_audio, _, lg = lm.backward_from_ctx(ctx, B * L)
+    valid = att.astype(bool)
+    assert cosine(npy(d_audio).reshape(B, L, D)[valid], g["dx"][valid]) > 0.999
+    for p_, g_ in zip(lm.lora_parameters(), lg):
+        p_.data.copy_(g_)
+    got = lm.export_lora_state_dict(prefix="model.", suffix="")
+    for k in [k[2:] for k in g.files if k.startswith("g.")]:
+        assert cosine(npy(got[k]), g["g." + k]) > 0.998, k
+
+
+def test_lora_true_width_vs_oracle():
+    wL, lo = OW.init_lm(TRUE_LM, 1), OW.init_lora(TRUE_LM, rank=8, seed=4)
+    rng = np.random.RandomState(8)
+    B, L = 2, 70
+    ids = rng.randint(0, 4900, (B, L)).astype(np.int64)
+    att = np.ones((B, L), np.int64); att[1, 55:] = 0
+    lab = np.full((B, L), -100, np.int64); lab[0, 40:70] = ids[0, 40:70]; lab[1, 30:55] = ids[1, 30:55]
+    _lora_case(TRUE_LM, wL, lo, ids, att, lab)
+
+
+def test_lora_zero_b_is_identity_and_stage2_trains():
+    """peft init (lora_B = 0): the adapted model equals the base model; stage 2 (frozen projector) updates only the
+    adapters, lora_B first (dA = 0 while B = 0), and the loss decreases over a few AdamW steps."""
+    S = R.SMALL
+    wE, wL = OW.init_encoder(S["enc"], 0), OW.init_lm(S["lm"], 1)
+    wP = OW.init_mlp_projector(S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"])
+    kw = dict(audio_token_id=S["audio_token_id"], audio_token_dropout=0.0)
+    base = build_model(S["enc"], S["lm"], S["proj_hidden"], wE, wL, wP, **kw)
+    m = build_model(S["enc"], S["lm"], S["proj_hidden"], wE, wL, wP, use_lora=True, freeze_projector=True, **kw)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert len(names) == 8 and all(n.startswith("language_model.lora_") for n in names)
+    n_true = sum(p.numel() for _, p in m.named_parameters() if p.requires_grad)
+    c = S["lm"]
+    D, F, nq, nkv, hd = c["hidden"], c["ffn"], c["heads"], c["kv_heads"], c["head_dim"]
+    per_layer = 8 * ((D + nq * hd) + 2 * (D + nkv * hd) + (nq * hd + D) + 2 * (D + F) + (F + D))
+    assert n_true == c["layers"] * per_layer                       # exact peft parameter count, no padding
+    feats = torch.from_numpy(R.encoder_input())
+    B = feats.shape[0]
+    counts = np.full(B, m.projector.get_output_length(m.audio_tower.output_length(feats.shape[2])), np.int64)
+    ids, att, lab, counts = R.asr_tokens(counts)
+    tb = dict(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab),
+              audio_token_counts=torch.from_numpy(counts))
+    o0 = base(input_features=feats, **tb)
+    o1 = m(input_features=feats, **tb)
+    assert abs(float(o0.loss.detach()) - float(o1.loss.detach())) < 1e-6
+    assert torch.equal(o0.logits, o1.logits)
+    tr = ASRTrainer(m, TrainingArguments(learning_rate=2e-3, warmup_steps=0, max_steps=8, lr_scheduler_type="constant",
+                                         weight_decay=0.0))
+    a0 = m.language_model.lora_la_qkv.detach().clone()
+    losses = [tr.training_step(dict(input_features=feats, **tb)) for _ in range(1)]
+    assert torch.equal(m.language_model.lora_la_qkv.detach(), a0)  # dA = s B^T dW = 0 on the first step
+    assert float(m.language_model.lora_lb_qkv.detach().abs().max()) > 0
+    losses += [tr.training_step(dict(input_features=feats, **tb)) for _ in range(7)]
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert all(p.grad is None or not p.requires_grad for p in m.projector.parameters())
 
 
 # ============================================================================ size-independent properties at full shapes

@@ -128,6 +128,25 @@ def test_qwen3_small_fwd_loss_dx(golden):
     assert relerr(dx, g["dx"]) < 1e-4
 
 
+def test_qwen3_lora_grads(golden):
+    """Row a11: adapter gradients of the restated LoRA formula vs torch autograd through the reference's Qwen3."""
+    g = golden("lora_small.npz")
+    cfg = R.SMALL["lm"]
+    w, lo = OW.init_lm(cfg, seed=1), OW.init_lora(cfg, rank=8, seed=4)
+    x, att, lab = R.lm_input()
+    logits, cache = OQ.lm_forward(x, att, w, cfg, lora=lo, lora_scale=4.0)
+    loss, dlogits, _ = OQ.causal_lm_loss(logits, lab)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert relerr(logits[0, 30:34], g["logits_row"]) < 5e-5
+    grads = {}
+    dx = OQ.lm_backward_dx(dlogits, w, cfg, cache, lo, 4.0, grads)
+    assert relerr(dx, g["dx"]) < 1e-4
+    keys = [k[2:] for k in g.files if k.startswith("g.")]
+    assert len(keys) == 10
+    for k in keys:
+        assert relerr(grads[k], g["g." + k]) < 2e-4, k
+
+
 # ----------------------------------------------------------------------------- whole model
 def _asr_setup(golden, ptype):
     g = golden("asr_small.npz")

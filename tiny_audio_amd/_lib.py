@@ -21,7 +21,7 @@ HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
-           "logmel.hip", "optim.hip", "moe.hip", "api.hip"]
+           "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "api.hip"]
 
 
 class Ta355Error(RuntimeError):
@@ -57,7 +57,12 @@ class MoeWeights(C.Structure):
 
 class LmLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln_in_w", "wqkv", "wqkv_t", "qn_w", "kn_w", "wo", "wo_t", "ln_post_w",
-                                          "wgu", "wgu_t", "wd", "wd_t")]
+                                          "wgu", "wgu_t", "wd", "wd_t",
+                                          "la_qkv", "lb_qkv", "la_o", "lb_o", "la_gu", "lb_gu", "la_d", "lb_d")]
+
+
+class LmLoraGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dla_qkv", "dlb_qkv", "dla_o", "dlb_o", "dla_gu", "dlb_gu", "dla_d", "dlb_d")]
 
 
 class LmWeights(C.Structure):
@@ -66,7 +71,7 @@ class LmWeights(C.Structure):
                 ("max_pos", C.c_int), ("eps", C.c_float),
                 ("embed_f32", C.c_void_p), ("embed_bf16", C.c_void_p), ("embed_t_bf16", C.c_void_p),
                 ("norm_w", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(LmLayer))]
+                ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float)]
 
 
 # ----------------------------------------------------------------------------- header parsing
@@ -105,7 +110,7 @@ def hipcc_path():
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every kernel source into one shared object (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), HEADER]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), HEADER]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made

@@ -60,10 +60,16 @@ class ASRModel(nn.Module):
             self.audio_tower.random_init(seed)
             self.language_model.random_init(seed + 1)
         if getattr(config, "use_lora", False):
-            raise NotImplementedError("LoRA stage-2 (config 5) is a 'next' row; see DESIGN.md")
+            self._setup_lora(config, seed)
         if getattr(config, "freeze_projector", False):
             self.projector.requires_grad_(False)
         self._drop_seed = 0x5EED + seed
+
+    def _setup_lora(self, config, seed=0):
+        """Stage-2 adapters on the LM (tiny_audio/asr_modeling.py:289-301: LoraConfig(r, lora_alpha,
+        target_modules, lora_dropout, bias="none", task_type="CAUSAL_LM"))."""
+        self.language_model.enable_lora(rank=config.lora_rank, alpha=config.lora_alpha, dropout=config.lora_dropout,
+                                        target_modules=config.lora_target_modules, seed=seed + 2)
 
     def _create_projector(self, config):
         projector_type = getattr(config, "projector_type", "mlp")
@@ -74,11 +80,16 @@ class ASRModel(nn.Module):
 
     # frozen sub-models hold plain device buffers, not Parameters: parameters()/state_dict() are projector-only
     def state_dict(self, *args, **kwargs):
-        return {f"projector.{k}": v for k, v in self.projector.state_dict().items()}
+        sd = {f"projector.{k}": v for k, v in self.projector.state_dict().items()}
+        if self.language_model.lora_rank:       # peft adapter naming under the reference's attribute name
+            sd.update(self.language_model.export_lora_state_dict(prefix="language_model.base_model.model.model."))
+        return sd
 
     def load_state_dict(self, sd, strict=True):
         sub = {k[len("projector."):]: v for k, v in sd.items() if k.startswith("projector.")}
         out = self.projector.load_state_dict(sub, strict=strict)
+        if self.language_model.lora_rank and any(".lora_A" in k for k in sd):
+            self.language_model.load_lora_state_dict(sd)
         if hasattr(self.projector, "_pack_versions"):
             self.projector._pack_versions = None
         return out
@@ -149,7 +160,7 @@ class ASRModel(nn.Module):
         if audio is None:
             audio = torch.zeros((1, self.config.llm_dim), device=dev, dtype=F32)
         loss, nll, logits = FrozenLMLoss.apply(audio, self.language_model, ids, src_row, kmask, rows, targets, n_lab,
-                                               scale, bool(return_logits))
+                                               scale, bool(return_logits), *self.language_model.lora_parameters())
         V = self.config.text_config.vocab_size
         logits = logits.reshape(B, L, -1)[:, :, :V] if return_logits else None
         aux = None

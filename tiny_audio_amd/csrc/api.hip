@@ -2,6 +2,7 @@
 // binding makes one call per reference nn.Module boundary (see include/ta355.h).  Pure kernel launches on
 // the caller's stream: no allocation, no synchronisation, graph-capturable.
 #include "common.h"
+#include "internal.h"
 #include "../../include/ta355.h"
 
 extern "C" int ta_version(void) { return 1; }
@@ -186,9 +187,13 @@ extern "C" int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x,
 
 // ============================================================================ Qwen3 LM
 namespace {
+struct LoraImg { bf16_t *a, *at, *b, *bt; };     // s*Acat [64,in], its transpose [in,64], Bext [N,64], its transpose [64,N]
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
+  // LoRA only: the adapted linears' inputs, the rank-space activations xa = x (s Acat)^T, and the bf16 images
+  bf16_t *xn_s, *xn2_s, *act_s, *xa_qkv, *xa_o, *xa_gu, *xa_d;
+  LoraImg i_qkv, i_o, i_gu, i_d;
 };
 struct LmTape {
   LmLayerTape* L;    // host array (static storage below)
@@ -226,6 +231,17 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
     p.x1 = c.take<float>((size_t)d.M * d.D);
     p.r_post = c.take<float>((size_t)d.M);
     p.gu = c.take<bf16_t>((size_t)d.M * 2 * d.F);
+    if (w->lora_rank > 0) {
+      p.xn_s = c.take<bf16_t>((size_t)d.M * d.D); p.xn2_s = c.take<bf16_t>((size_t)d.M * d.D);
+      p.act_s = c.take<bf16_t>((size_t)d.M * d.F);
+      p.xa_qkv = c.take<bf16_t>((size_t)d.M * 64); p.xa_o = c.take<bf16_t>((size_t)d.M * 64);
+      p.xa_gu = c.take<bf16_t>((size_t)d.M * 64); p.xa_d = c.take<bf16_t>((size_t)d.M * 64);
+      auto img = [&](LoraImg& g, int in, int N) {
+        g.a = c.take<bf16_t>((size_t)64 * in); g.at = c.take<bf16_t>((size_t)64 * in);
+        g.b = c.take<bf16_t>((size_t)64 * N); g.bt = c.take<bf16_t>((size_t)64 * N);
+      };
+      img(p.i_qkv, d.D, d.NQKV); img(p.i_o, d.nq * d.hd, d.D); img(p.i_gu, d.D, 2 * d.F); img(p.i_d, d.F, d.D);
+    }
   }
   t.x_final = c.take<float>((size_t)d.M * d.D);
   t.r_f = c.take<float>((size_t)d.M);
@@ -235,7 +251,7 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
   return t;
 }
 struct LmWs {
-  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv;
+  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB;
   float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
   size_t bytes;
 };
@@ -263,6 +279,7 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dk = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
   s.dv = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
   s.dqkv = c.take<bf16_t>((size_t)d.M * d.NQKV);
+  s.dyB = c.take<bf16_t>((size_t)d.M * 64);
   const int sp = pick_splits(nl, d.D, w->vocab_pad);
   s.skws = c.take<float>((size_t)ta_gemm_splitk_ws_bytes(nl, d.D, sp) / 4 + 4);
   s.bytes = c.total();
@@ -297,20 +314,46 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
   float* x = store[0].x_in;
   // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
   RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
+  const bool lora = w->lora_rank > 0;
+  const int r = w->lora_rank;
+  if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
+  // y = x W^T + xa Bext^T with xa = x (s Acat)^T: one skinny GEMM for xa, then the frozen GEMM runs one extra K-tile
+  auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa) -> int {
+    RC(gemm(x, g.a, xa, M, 64, in, nullptr, nullptr, 0, 1, st));
+    return ta_gemm_set_k_extension(xa, g.b, 64, 64);
+  };
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_lm_layer& Lw = w->layers[l];
     LmLayerTape& p = store[l];
     float* x_next = (l + 1 < w->n_layers) ? store[l + 1].x_in : t.x_final;
-    RC(ta_rmsnorm_fwd(p.x_in, Lw.ln_in_w, s.xn, nullptr, p.r_in, M, d.D, w->eps, 0, st));
-    RC(gemm(s.xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
+    bf16_t* xn = lora ? p.xn_s : s.xn;
+    if (lora) {   // bf16 images of this layer's adapters (kept in the tape for backward)
+      const int NB = 1 << 30, bq = d.nq * d.hd, bk = bq + d.nkv * d.hd;
+      RC(ta_i_lora_pack_a(Lw.la_qkv, w->lora_scale, p.i_qkv.a, p.i_qkv.at, 3 * r, d.D, st));
+      RC(ta_i_lora_pack_b(Lw.lb_qkv, p.i_qkv.b, p.i_qkv.bt, d.NQKV, r, bq, bk, st));
+      RC(ta_i_lora_pack_a(Lw.la_o, w->lora_scale, p.i_o.a, p.i_o.at, r, bq, st));
+      RC(ta_i_lora_pack_b(Lw.lb_o, p.i_o.b, p.i_o.bt, d.D, r, NB, NB, st));
+      RC(ta_i_lora_pack_a(Lw.la_gu, w->lora_scale, p.i_gu.a, p.i_gu.at, 2 * r, d.D, st));
+      RC(ta_i_lora_pack_b(Lw.lb_gu, p.i_gu.b, p.i_gu.bt, 2 * d.F, r, d.F, NB, st));
+      RC(ta_i_lora_pack_a(Lw.la_d, w->lora_scale, p.i_d.a, p.i_d.at, r, d.F, st));
+      RC(ta_i_lora_pack_b(Lw.lb_d, p.i_d.b, p.i_d.bt, d.D, r, NB, NB, st));
+    }
+    RC(ta_rmsnorm_fwd(p.x_in, Lw.ln_in_w, xn, nullptr, p.r_in, M, d.D, w->eps, 0, st));
+    if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
+    RC(gemm(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
                           p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
     RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
     RC(gemm(p.ao, Lw.wo, p.x1, M, d.D, d.nq * d.hd, nullptr, p.x_in, 0, 0, st));
-    RC(ta_rmsnorm_fwd(p.x1, Lw.ln_post_w, s.xn, nullptr, p.r_post, M, d.D, w->eps, 0, st));
-    RC(gemm(s.xn, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, st));
-    RC(ta_swiglu_fwd(p.gu, s.act, M, d.F, st));
-    RC(gemm(s.act, Lw.wd, x_next, M, d.D, d.F, nullptr, p.x1, 0, 0, st));
+    bf16_t* xn2 = lora ? p.xn2_s : s.xn;
+    bf16_t* act = lora ? p.act_s : s.act;
+    RC(ta_rmsnorm_fwd(p.x1, Lw.ln_post_w, xn2, nullptr, p.r_post, M, d.D, w->eps, 0, st));
+    if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu));
+    RC(gemm(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_swiglu_fwd(p.gu, act, M, d.F, st));
+    if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d));
+    RC(gemm(act, Lw.wd, x_next, M, d.D, d.F, nullptr, p.x1, 0, 0, st));
   }
   RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
   if (logits_out)   // the reference's outputs.logits (bf16 under autocast), all positions
@@ -328,9 +371,11 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
 
 extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
                               const int* label_rows, int n_lab, float* d_audio, long n_audio_rows, float* d_embeds,
-                              const void* tape, void* ws, long ws_bytes, hipStream_t st) {
+                              const ta_lm_lora_grads* lora_grads, const void* tape, void* ws, long ws_bytes, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (w->n_layers > MAX_LM_LAYERS) return TA_ERR_ARG;
+  const bool lora = w->lora_rank > 0;
+  if (lora && !lora_grads) return TA_ERR_ARG;
   const LmDims d = lm_dims(w, B, L);
   const int M = (int)d.M;
   LmLayerTape store[MAX_LM_LAYERS];
@@ -339,10 +384,30 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)d.hd);
   if (d_audio && hipMemsetAsync(d_audio, 0, (size_t)n_audio_rows * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+  const int r = w->lora_rank;
+  const int bq = d.nq * d.hd, bk = bq + d.nkv * d.hd;            // member row boundaries inside the fused qkv group
+  auto zero_lora = [&](const ta_lm_lora_grads& g) -> bool {
+    auto z = [&](float* q, size_t n) { return hipMemsetAsync(q, 0, n * 4, st) == hipSuccess; };
+    return z(g.dla_qkv, (size_t)3 * r * d.D) && z(g.dlb_qkv, (size_t)d.NQKV * r) && z(g.dla_o, (size_t)r * bq) &&
+           z(g.dlb_o, (size_t)d.D * r) && z(g.dla_gu, (size_t)2 * r * d.D) && z(g.dlb_gu, (size_t)2 * d.F * r) &&
+           z(g.dla_d, (size_t)r * d.F) && z(g.dlb_d, (size_t)d.D * r);
+  };
+  if (lora) for (int l = 0; l < w->n_layers; ++l) if (!zero_lora(lora_grads[l])) return TA_ERR_LAUNCH;
   if (n_lab <= 0) {
     if (d_embeds && hipMemsetAsync(d_embeds, 0, (size_t)M * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
     return TA_OK;
   }
+  // Adapter backward for one group, given dy [M, N] (bf16), the group's input x [M, in] and xa [M, 64]:
+  //   dyB = dy Bext            (rank space, [M, 64])       dBext = dy^T xa   (block-masked)
+  //   dx  = dy W + dyB (sAcat) (K extension of the dX GEMM) dAcat = s (dyB)^T x
+  // `arm` only prepares the K extension; the caller then issues the frozen dX GEMM.
+  auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
+                      float* dlb, int members, int b0, int b1) -> int {
+    RC(gemm(dy, g.bt, s.dyB, M, 64, N, nullptr, nullptr, 0, 1, st));
+    RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
+    RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
+    return ta_gemm_set_k_extension(s.dyB, g.at, 64, 64);
+  };
   // d hidden (labelled rows) = dlogits x E   (split-K over the vocabulary), scattered back to all positions
   const int sp = pick_splits(n_lab, d.D, w->vocab_pad);
   RC(ta_gemm_bf16_nt(t.dlogits, w->embed_t_bf16, s.dhl, n_lab, d.D, w->vocab_pad, w->vocab_pad, 0, 0, d.D, 0, 0, 0, nullptr,
@@ -356,17 +421,21 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     const ta_lm_layer& Lw = w->layers[l];
     const LmLayerTape& p = store[l];
     // ---- MLP: x2 = x1 + down(silu(gate) * up)
+    if (lora) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
     RC(gemm(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
+    if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
     RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, 0, st));
     RC(ta_rmsnorm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt, s.dxb, nullptr, M, d.D, 0, st));
     // ---- attention: x1 = x + o_proj(attn)
+    if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
     RC(gemm(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
                         B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv, B,
                           d.nq, d.nkv, L, st));
+    if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
     RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, 0, st));
     RC(ta_rmsnorm_bwd(s.dxn, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, s.dxb, nullptr, M, d.D, 0, st));
   }

@@ -35,6 +35,9 @@ struct GemmArgs {
   const int* a_idx;    // A row of logical row r is a_idx[seg_base + r] (gather); null = seg_base + r
   const int* seg;      // {row base, row count}: this launch covers rows [base, base+count) of A (via a_idx) and of C
   const int* krange;   // {first, last+1} K-tile (64-wide): contract only over that slice (per-expert dW over sorted slots)
+  // K extension (LoRA): after the K columns of A / W the contraction continues over K2 more columns taken from
+  // A2 [M, K2] (row stride lda2) and W2 [N, K2]:  C = A W^T + A2 W2^T  in one accumulator pass
+  const bf16_t* A2; const bf16_t* W2; int K2; long lda2;
 };
 
 #define BM 128
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
   if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (p.A2) kt_end = nkt + p.K2 / BK;              // K extension (host guarantees splits == 1, no krange)
   int Mact = p.M, rbase = 0;
   if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }   // block-uniform: before any barrier
 
@@ -117,7 +121,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  int next_tile = kt_begin;
   auto stage = [&](int buf) {
+    if (p.A2 && next_tile == nkt) {                // switch both operands to the extension
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = i * 32 + lr;
+        a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + r, Mact - 1)) * p.lda2 + clog * 8);
+        w_src[i] = (const char*)(p.W2 + (long)min(n0 + r, p.N - 1) * p.K2 + clog * 8);
+      }
+    }
+    ++next_tile;
     char* base = lds_w + buf * (2 * TILE_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
   if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (p.A2) kt_end = nkt + p.K2 / BK;
   int Mact = p.M, rbase = 0;
   if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
 
@@ -278,8 +293,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 
   auto dma_a = [&](char* base, int i) { glds16(a_src[i], base + i * 8192); a_src[i] += BK * 2; };
   auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += BK * 2; };
+  auto ext_switch = [&](int tile) {                 // call before staging K-tile `tile`
+    if (p.A2 && tile == nkt) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + i * 64 + lr, Mact - 1)) * p.lda2 + clog * 8);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        w_src[i] = (const char*)(p.W2 + (long)min(n0 + i * 64 + lr, p.N - 1) * p.K2 + clog * 8);
+    }
+  };
 
   if (kt_begin < kt_end) {
+    ext_switch(kt_begin);
 #pragma unroll
     for (int i = 0; i < NA; ++i) dma_a(lds_w, i);
 #pragma unroll
@@ -305,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
         for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
         if (kk == 0) {
           if (more) {
+            ext_switch(kt + 1);
 #pragma unroll
             for (int i = 0; i < NA; ++i) dma_a(nxt, i);
 #pragma unroll
@@ -348,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (more) {   // quarter of the next tile's DMA ahead of each 4-row MFMA group
+          if (kk == 0 && h == 0) ext_switch(kt + 1);
           if (kk == 0) { dma_a(nxt, 2 * h); dma_a(nxt, 2 * h + 1); }
           else if (NB == 4) { dma_w(nxt, 2 * h); dma_w(nxt, 2 * h + 1); }
           else { dma_w(nxt, h); }
@@ -427,10 +455,11 @@ std::vector<ProfRec> g_prof;
 
 // Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong.
 // Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
-// come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0|1|2 forces one (experiments).
+// come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0..3 forces one (experiments, tests).
 #include <cstdlib>
 static int pick_variant(int M, int N, int splits) {
-  static const int forced = [] { const char* e = getenv("TA355_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+  const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
+  const int forced = (e && *e) ? atoi(e) : -1;
   if (forced >= 0 && forced <= 3) return forced;
   const double rate[4] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP};
   const int bm[4] = {128, 256, 256, 256}, bn[4] = {128, 256, 128, 256}, slots[4] = {512, 256, 256, 256};
@@ -500,6 +529,17 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
                             splits, splitk_ws, nullptr, nullptr, nullptr, st);
 }
 
+static thread_local const void* g_ext_A2 = nullptr;
+static thread_local const void* g_ext_W2 = nullptr;
+static thread_local int g_ext_K2 = 0;
+static thread_local long g_ext_lda2 = 0;
+// C = epilogue(A W^T + A2 W2^T): the K extension is armed for the NEXT ta_gemm_bf16_nt* call on this thread.
+extern "C" int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2) {
+  if (A2 && (K2 <= 0 || K2 % BK || lda2 % 8)) return TA_ERR_ARG;
+  g_ext_A2 = A2; g_ext_W2 = W2; g_ext_K2 = K2; g_ext_lda2 = lda2;
+  return TA_OK;
+}
+
 // M is the UPPER BOUND on rows when `seg` is given (grid sizing); the kernel reads the actual base/count on device.
 extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K,
                                   long lda, int a_rpb, long a_bs,
@@ -507,6 +547,9 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
                                   const float* bias, const float* residual,
                                   int act, int out_bf16, int splits, float* splitk_ws,
                                   const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
+  const void *xA2 = g_ext_A2, *xW2 = g_ext_W2;
+  const int xK2 = g_ext_K2;
+  g_ext_A2 = nullptr; g_ext_W2 = nullptr; g_ext_K2 = 0;          // one-shot: consumed by this call whatever its outcome
   if (M <= 0 || N <= 0 || K <= 0) return TA_OK;
   if ((a_idx || seg || krange) && splits > 1) return TA_ERR_ARG;
   if ((K % BK) != 0 || (N % 4) != 0 || (lda % 8) != 0 || (a_bs % 8) != 0 || (ldc % 4) != 0 ||
@@ -519,6 +562,8 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
   a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : (seg ? 0x7fffffff : M); a.c_bs = c_bs; a.c_off = c_off;
   if (seg && a_rpb <= 0) a.a_rpb = 0x7fffffff;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
+  a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = g_ext_lda2;
+  if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
   a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
   a.splits = splits > 1 ? splits : 1;
   if (a.splits > K / BK) a.splits = K / BK;

@@ -1,0 +1,8 @@
+// Internal (non-exported) helpers shared between translation units of libta355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, hipStream_t st);
+int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, hipStream_t st);
+int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
+                        int r, int b0, int b1, hipStream_t st);

@@ -23,6 +23,11 @@ def _pad128(n):
     return (n + 127) // 128 * 128
 
 
+# LoRA adapters of linears that share an input are stacked into one GROUP (csrc/lora.hip): group -> peft target names
+LORA_GROUPS = (("qkv", ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj")), ("o", ("self_attn.o_proj",)),
+               ("gu", ("mlp.gate_proj", "mlp.up_proj")), ("d", ("mlp.down_proj",)))
+
+
 class Qwen3MI355X(torch.nn.Module):
     def __init__(self, config: LMConfig, device="cuda"):
         super().__init__()
@@ -32,6 +37,100 @@ class Qwen3MI355X(torch.nn.Module):
         self._bufs = {}
         self._w = None
         self._layers_arr = None
+        self.lora_rank = 0
+        self._lora_bound = None
+
+    # ------------------------------------------------------------------ LoRA (stage 2; asr_modeling.py:289-301)
+    def _lora_dims(self):
+        """group -> [(peft target, out_features)], in_features"""
+        c = self.config
+        D, F, nq, nkv, hd = c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        outs = {"self_attn.q_proj": nq * hd, "self_attn.k_proj": nkv * hd, "self_attn.v_proj": nkv * hd,
+                "self_attn.o_proj": D, "mlp.gate_proj": F, "mlp.up_proj": F, "mlp.down_proj": D}
+        ins = {"qkv": D, "o": nq * hd, "gu": D, "d": F}
+        return {g: ([(t, outs[t]) for t in ts], ins[g]) for g, ts in LORA_GROUPS}
+
+    def lora_parameters(self):
+        return [getattr(self, f"lora_{ab}_{g}") for g, _ in LORA_GROUPS for ab in ("la", "lb")] if self.lora_rank else []
+
+    @torch.no_grad()
+    def enable_lora(self, rank=8, alpha=32, dropout=0.0, target_modules=None, seed=0):
+        """peft ``LoraConfig(r, lora_alpha, target_modules=all 7 linears, bias='none')`` on every decoder layer:
+        lora_A ~ kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(in)), lora_B = 0, y += (alpha/r) B A x.  The trainable
+        fp32 masters are 8 Parameters [n_layers, ...] in the stacked group layout of include/ta355.h."""
+        if rank != 8:
+            raise NotImplementedError("the fused adapter tile is built for lora_rank=8 (the reference default)")
+        if dropout:
+            raise NotImplementedError("lora_dropout > 0 is not built (reference default 0.0, asr_config.py:74)")
+        want = {"q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"}
+        if target_modules is not None and set(target_modules) != want:
+            raise NotImplementedError("lora_target_modules must be the reference default (all 7 linears)")
+        Lyr, dev = self.config.num_hidden_layers, self.device_
+        gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
+        for g, (members, fin) in self._lora_dims().items():
+            bound = 1.0 / math.sqrt(fin)
+            a = (torch.rand((Lyr, len(members) * rank, fin), generator=gen, dtype=F32) * 2 - 1) * bound
+            b = torch.zeros((Lyr, sum(o for _, o in members), rank), dtype=F32)
+            setattr(self, f"lora_la_{g}", torch.nn.Parameter(a.to(dev)))
+            setattr(self, f"lora_lb_{g}", torch.nn.Parameter(b.to(dev)))
+        self.lora_rank, self.lora_alpha = rank, alpha
+        self._lora_bound = None
+        if self._w is not None:
+            self._w.lora_rank, self._w.lora_scale = rank, float(alpha) / rank
+        return self
+
+    @torch.no_grad()
+    def load_lora_state_dict(self, sd):
+        """Accepts peft adapter naming (``...model.layers.N.self_attn.q_proj.lora_A[.default].weight``) or the bare
+        ``model.layers.N.<target>.lora_A`` keys of oracle/weights.py:init_lora."""
+        r = self.lora_rank
+        found = {}
+        for k, v in sd.items():
+            k2 = k.replace(".default", "")
+            if k2.endswith(".weight"):
+                k2 = k2[: -len(".weight")]
+            i = k2.find("layers.")
+            if i >= 0 and (k2.endswith(".lora_A") or k2.endswith(".lora_B")):
+                found[k2[i:]] = torch.as_tensor(v).to(dtype=F32)
+        for g, (members, fin) in self._lora_dims().items():
+            la, lb = getattr(self, f"lora_la_{g}"), getattr(self, f"lora_lb_{g}")
+            for i in range(self.config.num_hidden_layers):
+                row = 0
+                for j, (t, o) in enumerate(members):
+                    la.data[i, j * r:(j + 1) * r].copy_(found[f"layers.{i}.{t}.lora_A"])
+                    lb.data[i, row:row + o].copy_(found[f"layers.{i}.{t}.lora_B"])
+                    row += o
+        return self
+
+    def export_lora_state_dict(self, prefix="base_model.model.model.", suffix=".weight"):
+        """peft adapter_model naming by default; ``prefix='model.', suffix=''`` gives the oracle's keys."""
+        r, sd = self.lora_rank, {}
+        for g, (members, fin) in self._lora_dims().items():
+            la, lb = getattr(self, f"lora_la_{g}").detach(), getattr(self, f"lora_lb_{g}").detach()
+            for i in range(self.config.num_hidden_layers):
+                row = 0
+                for j, (t, o) in enumerate(members):
+                    sd[f"{prefix}layers.{i}.{t}.lora_A{suffix}"] = la[i, j * r:(j + 1) * r].clone()
+                    sd[f"{prefix}layers.{i}.{t}.lora_B{suffix}"] = lb[i, row:row + o].clone()
+                    row += o
+        return sd
+
+    def _bind_lora(self):
+        """Point the per-layer struct fields at the current storage of the 8 master Parameters (a flat-buffer
+        optimizer may have re-homed ``.data`` since the last call)."""
+        ps = self.lora_parameters()
+        key = tuple(p.data_ptr() for p in ps)
+        if key == self._lora_bound:
+            return
+        for p in ps:
+            assert p.dtype == F32 and p.is_contiguous()
+        for g, _ in LORA_GROUPS:
+            for ab in ("la", "lb"):
+                p = getattr(self, f"lora_{ab}_{g}")
+                step = p[0].numel() * 4
+                for i in range(self.config.num_hidden_layers):
+                    setattr(self._layers_arr[i], f"{ab}_{g}", p.data_ptr() + i * step)
+        self._lora_bound = key
 
     # ------------------------------------------------------------------ weights
     def _rope_tables(self):
@@ -109,14 +208,17 @@ class Qwen3MI355X(torch.nn.Module):
         arr = (_lib.LmLayer * L)()
         for i in range(L):
             for f, _ in _lib.LmLayer._fields_:
-                setattr(arr[i], f, b[f"layers.{i}.{f}"].data_ptr())
+                if not f.startswith(("la_", "lb_")):
+                    setattr(arr[i], f, b[f"layers.{i}.{f}"].data_ptr())
         w = _lib.LmWeights(vocab=c.vocab_size, vocab_pad=self.vocab_pad, hidden=c.hidden_size, ffn=c.intermediate_size,
                            n_layers=L, heads=c.num_attention_heads, kv_heads=c.num_key_value_heads, head_dim=c.head_dim,
                            max_pos=c.max_position_embeddings, eps=c.rms_norm_eps)
         for f in ("embed_f32", "embed_bf16", "embed_t_bf16", "norm_w", "rope_cos", "rope_sin"):
             setattr(w, f, b[f].data_ptr())
         w.layers = C.cast(arr, C.POINTER(_lib.LmLayer))
-        self._layers_arr, self._w = arr, w
+        if self.lora_rank:
+            w.lora_rank, w.lora_scale = self.lora_rank, float(self.lora_alpha) / self.lora_rank
+        self._layers_arr, self._w, self._lora_bound = arr, w, None
 
     def export_state_dict_hf(self):
         """Back to the reference's parameter names as fp32 numpy (used by bench.py's CPU-baseline leg)."""
@@ -150,6 +252,8 @@ class Qwen3MI355X(torch.nn.Module):
         L_ = _lib.lib()
         B, L = input_ids.shape
         dev = self.device_
+        if self.lora_rank:
+            self._bind_lora()
         tape = torch.empty(L_.ta_lm_tape_bytes(C.byref(self._w), B, L, n_label_rows), device=dev, dtype=torch.uint8)
         ws = torch.empty(L_.ta_lm_workspace_bytes(C.byref(self._w), B, L, n_label_rows), device=dev, dtype=torch.uint8)
         loss = torch.zeros(1, device=dev, dtype=F32)
@@ -163,28 +267,43 @@ class Qwen3MI355X(torch.nn.Module):
                    n_label_rows=n_label_rows)
         return loss, nll, logits, ctx
 
-    def backward_from_ctx(self, ctx, n_audio_rows, want_d_embeds=False):
-        """-> (d_audio f32 [n_audio_rows, D], d_embeds f32 [B*L, D] or None) for d(loss) = 1."""
+    def backward_from_ctx(self, ctx, n_audio_rows, want_d_embeds=False, want_d_audio=True):
+        """-> (d_audio f32 [n_audio_rows, D] or None, d_embeds f32 [B*L, D] or None, LoRA grads (list of 8, the order
+        of ``lora_parameters()``) or None) for d(loss) = 1."""
         D, dev = self.config.hidden_size, self.device_
-        d_audio = torch.empty((n_audio_rows, D), device=dev, dtype=F32)
+        d_audio = torch.empty((n_audio_rows, D), device=dev, dtype=F32) if want_d_audio else None
         d_emb = torch.empty((ctx["B"] * ctx["L"], D), device=dev, dtype=F32) if want_d_embeds else None
+        lg, lg_arr = None, None
+        if self.lora_rank:
+            self._bind_lora()
+            lg = [torch.empty_like(p) for p in self.lora_parameters()]
+            nl = self.config.num_hidden_layers
+            lg_arr = (_lib.LmLoraGrads * nl)()
+            k = 0
+            for g, _ in LORA_GROUPS:
+                for ab in ("la", "lb"):
+                    step = lg[k][0].numel() * 4
+                    for i in range(nl):
+                        setattr(lg_arr[i], f"d{ab}_{g}", lg[k].data_ptr() + i * step)
+                    k += 1
         _lib.check(_lib.lib().ta_lm_backward(C.byref(self._w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
                                              ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
-                                             ptr(d_audio), n_audio_rows, ptr(d_emb), ptr(ctx["tape"]), ptr(ctx["ws"]),
-                                             ctx["ws"].numel(), stream()), "ta_lm_backward")
-        return d_audio, d_emb
+                                             ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr, ptr(ctx["tape"]),
+                                             ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
+        return d_audio, d_emb, lg
 
 
 class FrozenLMLoss(torch.autograd.Function):
-    """loss = CE(frozen_LM(embed(ids) with <audio> rows := audio_embeds)); grad flows to audio_embeds only."""
+    """loss = CE(frozen_LM(embed(ids) with <audio> rows := audio_embeds)); grad flows to audio_embeds and, when
+    adapters are enabled, to the LoRA masters passed as trailing inputs (``*lm.lora_parameters()``)."""
 
     @staticmethod
     def forward(ctx, audio_embeds, lm, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale,
-                want_logits):
+                want_logits, *lora_params):
         a = audio_embeds.detach().to(F32).contiguous()
         loss, nll, logits, c = lm.forward_loss(input_ids, src_row, a, kmask, label_rows, label_targets, n_label_rows,
                                                loss_scale, want_logits)
-        ctx.lm, ctx.c, ctx.n_audio = lm, c, a.shape[0]
+        ctx.lm, ctx.c, ctx.n_audio, ctx.n_lora = lm, c, a.shape[0], len(lora_params)
         ctx.mark_non_differentiable(nll)
         if logits is None:
             logits = torch.empty(0, device=a.device)
@@ -193,6 +312,8 @@ class FrozenLMLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_nll, _g_logits):
-        d_audio, _ = ctx.lm.backward_from_ctx(ctx.c, ctx.n_audio)
+        d_audio, _, lg = ctx.lm.backward_from_ctx(ctx.c, ctx.n_audio, want_d_audio=ctx.needs_input_grad[0])
         ctx.c = None
-        return (d_audio * g_loss,) + (None,) * 9
+        lora = tuple(g * g_loss for g in lg)[: ctx.n_lora] if lg is not None else ()
+        lora = lora + (None,) * (ctx.n_lora - len(lora))
+        return (None if d_audio is None else d_audio * g_loss,) + (None,) * 9 + lora

@@ -34,9 +34,14 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1):
-    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset)."""
+            a_map=None, c_map=None, splits=1, k_ext=None):
+    """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
+    k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile)."""
     _req(A, BF16); _req(W, BF16)
+    if k_ext is not None:
+        A2, W2 = k_ext
+        _req(A2, BF16); _req(W2, BF16)
+        check(lib().ta_gemm_set_k_extension(ptr(A2), ptr(W2), W2.shape[1], A2.shape[1]), "ta_gemm_set_k_extension")
     N = N or W.shape[0]
     K = K or W.shape[1]
     M = M or A.numel() // K
