@@ -319,7 +319,7 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
   if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
   // y = x W^T + xa Bext^T with xa = x (s Acat)^T: one skinny GEMM for xa, then the frozen GEMM runs one extra K-tile
   auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa) -> int {
-    RC(gemm(x, g.a, xa, M, 64, in, nullptr, nullptr, 0, 1, st));
+    RC(ta_i_lora_skinny_nt(x, in, g.a, xa, M, st));
     return ta_gemm_set_k_extension(xa, g.b, 64, 64);
   };
   for (int l = 0; l < w->n_layers; ++l) {
@@ -403,7 +403,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   // `arm` only prepares the K extension; the caller then issues the frozen dX GEMM.
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1) -> int {
-    RC(gemm(dy, g.bt, s.dyB, M, 64, N, nullptr, nullptr, 0, 1, st));
+    RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, st));
     RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
     RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
     return ta_gemm_set_k_extension(s.dyB, g.at, 64, 64);

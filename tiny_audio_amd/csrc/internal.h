@@ -6,3 +6,4 @@ int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R,
 int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, hipStream_t st);
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
                         int r, int b0, int b1, hipStream_t st);
+int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T

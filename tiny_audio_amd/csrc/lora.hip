@@ -33,42 +33,140 @@ __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restric
   outT[(long)j * N + n] = v;
 }
 
-// out[c*so_c + j*so_j] (+)= post * sum_m X[m, c] * Y[m, j]   for j < R (R <= 24), X bf16 [M, C], Y bf16 [M, ldy].
-// Skinny "TN" product for the adapter gradients: dB = dY^T xa and dA = (dY B)^T x.  One thread per column c, the
-// M range is cut into gridDim.y chunks combined with atomics (out must be zeroed).  Only columns j in
-// [jlo(c), jlo(c) + r) are kept when r > 0 (member row boundaries b0, b1: block structure of Bext) and land in
-// out[c*so_c + (j - jlo)*so_j], i.e. directly in the [N, r] master layout.
-__global__ __launch_bounds__(256) void lora_skinny_tn_kernel(const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
-                                                             int ldy, int R, float* __restrict__ out, long so_c, long so_j,
-                                                             int M, float post, int r, int b0, int b1) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int per = (M + gridDim.y - 1) / gridDim.y;
-  const int m0 = blockIdx.y * per, m1 = min(M, m0 + per);
-  if (c >= Cn) return;
-  float acc[24];
+// out[c*so_c + (j - jlo(c))*so_j] += post * sum_m X[m, c] * Y[m, j],  j < R <= 32;  X bf16 [M, C], Y bf16 [M, 64].
+// The adapter gradients  dB = dY^T xa  and  dA = s (dY B)^T x  are "TN" products: the contraction index m is the ROW
+// index of both row-major operands, while an MFMA lane wants 8 consecutive k of one row/column.  Tiles of 32 rows are
+// therefore staged through LDS row-major (coalesced 16-B global loads) and read back transposed (8 ds_read_u16 per
+// operand).  The work is HBM-bound (X is read exactly once, arithmetic is 64 flop/byte), so the transposed reads
+// are free.  D[j, c] = sum_k Yt[j, k] X[k, c]: A operand from Y, B operand from X; lane (i, g) owns c = i,
+// j = 4g + reg of each 16x16 block.  Wave w of the block owns columns [64w, 64w+64) of the 256-column strip.
+// LDS bank mapping: rows are 512 B (X) / 128 B (Y) apart, so the four row groups g of one read would share banks; the
+// 32-B column group index is XOR-ed with g = (row >> 3) & 3 to spread them.
+// With r > 0 only the member block of column c (member boundaries b0, b1; block structure of Bext) is kept and
+// lands at j - jlo, i.e. directly in the [N, r] master layout.  grid (ceil(C/256), chunks of 128 rows); out zeroed.
+typedef __attribute__((ext_vector_type(8))) short lbf16x8;
+typedef __attribute__((ext_vector_type(4))) float lf32x4;
+
+__global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
+                                                           int R, float* __restrict__ out, long so_c, long so_j, int M,
+                                                           float post, int r, int b0, int b1, int rows_per_chunk) {
+  __shared__ __attribute__((aligned(16))) bf16_t sx[32 * 256];
+  __shared__ __attribute__((aligned(16))) bf16_t sy[32 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int c0 = blockIdx.x * 256;
+  const int m_begin = blockIdx.y * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
+  const int jblocks = R > 16 ? 2 : 1;
+  lf32x4 acc[2][4];
 #pragma unroll
-  for (int j = 0; j < 24; ++j) acc[j] = 0.f;
-  for (int m = m0; m < m1; ++m) {
-    const float x = bf2f(X[(long)m * Cn + c]);
-    const uint4* yr = (const uint4*)(Y + (long)m * ldy);       // same address for the whole wave: broadcast loads
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (q * 8 < R) {
-        const uint4 v = yr[q];
-        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    for (int b = 0; b < 4; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 px[4], py;
+  auto fetch = [&](int m0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          acc[q * 8 + 2 * k] = fmaf(x, bf2f(u[k] & 0xffff), acc[q * 8 + 2 * k]);
-          acc[q * 8 + 2 * k + 1] = fmaf(x, bf2f(u[k] >> 16), acc[q * 8 + 2 * k + 1]);
-        }
+    for (int q = 0; q < 4; ++q) {
+      const int id = tid + q * 256, row = id >> 5, ch = id & 31;
+      const int m = m0 + row, c = c0 + ch * 8;
+      px[q] = (m < m_end && c < Cn) ? *(const uint4*)(X + (long)m * Cn + c) : make_uint4(0, 0, 0, 0);
+    }
+    const int row = tid >> 3, ch = tid & 7, m = m0 + row;
+    py = m < m_end ? *(const uint4*)(Y + (long)m * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int id = tid + q * 256, row = id >> 5, ch = id & 31;
+      const int sg = (ch >> 1) ^ ((row >> 3) & 3);
+      *(uint4*)(sx + row * 256 + sg * 16 + (ch & 1) * 8) = px[q];
+    }
+    const int row = tid >> 3, ch = tid & 7;
+    const int sg = (ch >> 1) ^ ((row >> 3) & 3);
+    *(uint4*)(sy + row * 64 + sg * 16 + (ch & 1) * 8) = py;
+  };
+
+  fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+    __syncthreads();                     // previous tile fully consumed
+    stash();
+    __syncthreads();
+    if (m0 + 32 < m_end) fetch(m0 + 32); // next tile's global loads fly while this one is multiplied
+    lbf16x8 a[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+      if (jb < jblocks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[jb][e] = (short)sy[(g * 8 + e) * 64 + ((jb ^ g) * 16) + i];
       }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int cg = wave * 4 + cb;
+      lbf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = (short)sx[(g * 8 + e) * 256 + ((cg ^ g) * 16) + i];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+        if (jb < jblocks) acc[jb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jb], b, acc[jb][cb], 0, 0, 0);
     }
   }
-  int jlo = 0, jhi = R;
-  if (r > 0) { const int mem = c < b0 ? 0 : (c < b1 ? 1 : 2); jlo = mem * r; jhi = jlo + r; }
 #pragma unroll
-  for (int j = 0; j < 24; ++j)
-    if (j >= jlo && j < jhi) atomicAdd(out + (long)c * so_c + (long)(j - jlo) * so_j, acc[j] * post);
+  for (int cb = 0; cb < 4; ++cb) {
+    const int c = c0 + (wave * 4 + cb) * 16 + i;
+    if (c >= Cn) continue;
+    int jlo = 0, jhi = R;
+    if (r > 0) { jlo = (c < b0 ? 0 : (c < b1 ? 1 : 2)) * r; jhi = jlo + r; }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+      if (jb < jblocks) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = jb * 16 + g * 4 + q;
+          if (j >= jlo && j < jhi) unsafeAtomicAdd(out + (long)c * so_c + (long)(j - jlo) * so_j, acc[jb][cb][q] * post);
+        }
+      }
+  }
+}
+
+// out[M, 64] (bf16) = X[M, K] W[64, K]^T : the rank-space projections xa = x (sAcat)^T and dyB = dy Bext.
+// Both operands are K-major, so MFMA fragments load straight from global memory (16 B per lane, no LDS staging).
+// A 128x128 GEMM tile grid would be 48 workgroups here; instead one workgroup owns 32 rows and all 64 columns, its
+// four waves split K (wave w takes k-steps w, w+4, ...) and meet in LDS: 192 workgroups for M = 6144.
+__global__ __launch_bounds__(256) void lora_skinny_nt_kernel(const bf16_t* __restrict__ X, int K, const bf16_t* __restrict__ W,
+                                                             bf16_t* __restrict__ out, int M) {
+  __shared__ float red[4][32][65];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  lf32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
+  const int ra = min(m0 + i, M - 1), rb = min(m0 + 16 + i, M - 1);       // clamped rows are never stored
+  const bf16_t* xa = X + (long)ra * K + g * 8;
+  const bf16_t* xb = X + (long)rb * K + g * 8;
+  const bf16_t* wp = W + (long)i * K + g * 8;
+#pragma unroll 2
+  for (int kk = wave * 32; kk < K; kk += 128) {
+    const lbf16x8 a0 = *(const lbf16x8*)(xa + kk), a1 = *(const lbf16x8*)(xb + kk);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const lbf16x8 b = *(const lbf16x8*)(wp + (long)cb * 16 * K + kk);
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][cb], 0, 0, 0);
+      acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][cb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int rbk = 0; rbk < 2; ++rbk)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wave][rbk * 16 + g * 4 + q][cb * 16 + i] = acc[rbk][cb][q];
+  __syncthreads();
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int row = e >> 6, col = e & 63;
+    if (m0 + row < M)
+      out[(long)(m0 + row) * 64 + col] = f2bf(red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col]);
+  }
 }
 
 int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, hipStream_t st) {
@@ -83,10 +181,18 @@ int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b
 }
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
                         int r, int b0, int b1, hipStream_t st) {
-  if (R > 24 || R % 8) return TA_ERR_ARG;
-  int chunks = M / 256; if (chunks < 1) chunks = 1; if (chunks > 32) chunks = 32;
-  TA_LAUNCH(lora_skinny_tn_kernel, dim3(ta_cdiv(Cn, 256), chunks), dim3(256), 0, st, (const bf16_t*)X, Cn, (const bf16_t*)Y, ldy, R,
-            out, so_c, so_j, M, post, r, b0, b1);
+  if (R > 32 || R <= 0 || ldy != 64 || Cn % 8) return TA_ERR_ARG;
+  if (M <= 0) return TA_OK;
+  const int rows = 128;
+  TA_LAUNCH(lora_tn_mfma_kernel, dim3(ta_cdiv(Cn, 256), ta_cdiv(M, rows)), dim3(256), 0, st, (const bf16_t*)X, Cn, (const bf16_t*)Y,
+            R, out, so_c, so_j, M, post, r, b0, b1, rows);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st) {
+  if (K % 32 || K <= 0) return TA_ERR_ARG;
+  if (M <= 0) return TA_OK;
+  TA_LAUNCH(lora_skinny_nt_kernel, dim3(ta_cdiv(M, 32)), dim3(256), 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
