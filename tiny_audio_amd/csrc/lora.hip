@@ -129,11 +129,15 @@ __global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restr
 
 // out[M, 64] (bf16) = X[M, K] W[64, K]^T : the rank-space projections xa = x (sAcat)^T and dyB = dy Bext.
 // Both operands are K-major, so MFMA fragments load straight from global memory (16 B per lane, no LDS staging).
-// A 128x128 GEMM tile grid would be 48 workgroups here; instead one workgroup owns 32 rows and all 64 columns, its
-// four waves split K (wave w takes k-steps w, w+4, ...) and meet in LDS: 192 workgroups for M = 6144.
-__global__ __launch_bounds__(256) void lora_skinny_nt_kernel(const bf16_t* __restrict__ X, int K, const bf16_t* __restrict__ W,
-                                                             bf16_t* __restrict__ out, int M) {
-  __shared__ float red[4][32][65];
+// A 128x128 GEMM tile grid would be 48 workgroups here; instead one workgroup owns 32 rows and all 64 columns and
+// its EIGHT waves split K (wave w takes k-steps w, w+8, ...), meeting in LDS: 192 workgroups x 8 waves for M = 6144.
+// The kernel is a stream over X (HBM) with W (<= 768 KB) resident in L2; two k-steps are kept in flight per wave so
+// that ~32 KB of X loads are outstanding per CU.
+constexpr int SK_WAVES = 8;
+__global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf16_t* __restrict__ X, int K,
+                                                                       const bf16_t* __restrict__ W,
+                                                                       bf16_t* __restrict__ out, int M) {
+  __shared__ float red[SK_WAVES][32][65];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 32;
   lf32x4 acc[2][4];
@@ -145,15 +149,29 @@ __global__ __launch_bounds__(256) void lora_skinny_nt_kernel(const bf16_t* __res
   const bf16_t* xa = X + (long)ra * K + g * 8;
   const bf16_t* xb = X + (long)rb * K + g * 8;
   const bf16_t* wp = W + (long)i * K + g * 8;
-#pragma unroll 2
-  for (int kk = wave * 32; kk < K; kk += 128) {
-    const lbf16x8 a0 = *(const lbf16x8*)(xa + kk), a1 = *(const lbf16x8*)(xb + kk);
+  constexpr int STEP = SK_WAVES * 32;
+  lbf16x8 a0, a1, b[4], na0, na1, nb[4];
+  int kk = wave * 32;
+  if (kk < K) {
+    a0 = *(const lbf16x8*)(xa + kk); a1 = *(const lbf16x8*)(xb + kk);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) b[cb] = *(const lbf16x8*)(wp + (long)cb * 16 * K + kk);
+  }
+  for (; kk < K; kk += STEP) {
+    const int kn = kk + STEP;
+    if (kn < K) {
+      na0 = *(const lbf16x8*)(xa + kn); na1 = *(const lbf16x8*)(xb + kn);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) nb[cb] = *(const lbf16x8*)(wp + (long)cb * 16 * K + kn);
+    }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const lbf16x8 b = *(const lbf16x8*)(wp + (long)cb * 16 * K + kk);
-      acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][cb], 0, 0, 0);
-      acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][cb], 0, 0, 0);
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[cb], acc[0][cb], 0, 0, 0);
+      acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[1][cb], 0, 0, 0);
     }
+    a0 = na0; a1 = na1;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) b[cb] = nb[cb];
   }
 #pragma unroll
   for (int rbk = 0; rbk < 2; ++rbk)
@@ -162,10 +180,12 @@ __global__ __launch_bounds__(256) void lora_skinny_nt_kernel(const bf16_t* __res
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[wave][rbk * 16 + g * 4 + q][cb * 16 + i] = acc[rbk][cb][q];
   __syncthreads();
-  for (int e = tid; e < 32 * 64; e += 256) {
+  for (int e = tid; e < 32 * 64; e += SK_WAVES * 64) {
     const int row = e >> 6, col = e & 63;
-    if (m0 + row < M)
-      out[(long)(m0 + row) * 64 + col] = f2bf(red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col]);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][col];
+    if (m0 + row < M) out[(long)(m0 + row) * 64 + col] = f2bf(v);
   }
 }
 
@@ -192,7 +212,7 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
 int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st) {
   if (K % 32 || K <= 0) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  TA_LAUNCH(lora_skinny_nt_kernel, dim3(ta_cdiv(M, 32)), dim3(256), 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  TA_LAUNCH(lora_skinny_nt_kernel, dim3(ta_cdiv(M, 32)), dim3(SK_WAVES * 64), 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
