@@ -39,7 +39,11 @@ if only in ("all", "gemm"):
         ("head_fwd", 1152, 151680, 1024, False, 0, False), ("sq4096", 4096, 4096, 4096, True, 0, False),
         ("sq8192", 8192, 8192, 8192, True, 0, False),
     ]
+    variants = sys.argv[sys.argv.index("--variants") + 1].split(",") if "--variants" in sys.argv else [""]
     for name, M, N, K, obf, act, hasres in shapes:
+      for var in variants:
+        os.environ["TA355_GEMM_VARIANT"] = var
+        name_v = name + (":v" + var if var else "")
         A = (torch.randn(M, K, device=DEV) * 1.0).to(BF16)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(BF16)
         out = torch.empty(M, N, device=DEV, dtype=BF16 if obf else F32)
@@ -48,9 +52,10 @@ if only in ("all", "gemm"):
         if hasres:
             out.zero_()
         t = timeit(lambda: ops.gemm_nt(A, W, out=out, bias=bias, residual=resid, act=act))
-        res[name] = round(2.0 * M * N * K / t / 1e12, 1)
-        print(f"{name:12s} M={M:6d} N={N:6d} K={K:5d}  {t * 1e6:8.1f} us  {res[name]:7.1f} TF/s", flush=True)
+        res[name_v] = round(2.0 * M * N * K / t / 1e12, 1)
+        print(f"{name_v:14s} M={M:6d} N={N:6d} K={K:5d}  {t * 1e6:8.1f} us  {res[name_v]:7.1f} TF/s", flush=True)
         del A, W, out
+    os.environ["TA355_GEMM_VARIANT"] = ""
 if only in ("all", "attn"):
     for name, B, Hq, Hkv, L, hd, causal in [("enc_attn", 32, 20, 20, 500, 64, False), ("lm_attn_fwd", 32, 16, 8, 192, 128, True)]:
         Q = torch.randn(B, Hq, L, hd, device=DEV).to(BF16)

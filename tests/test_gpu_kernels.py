@@ -56,7 +56,7 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 64, 256), (1000, 1024, 1024), (6144, 4096, 1024), (4100, 1024, 3072)])
-@pytest.mark.parametrize("variant", [None, "0", "1", "3"])
+@pytest.mark.parametrize("variant", [None, "0", "1", "3", "4"])
 def test_gemm_k_extension(M, N, K, variant, monkeypatch):
     """C = A W^T + A2 W2^T in one launch (one extra 64-wide K tile: the fused LoRA update), every tile variant."""
     if variant is not None:

@@ -49,6 +49,7 @@ struct GemmArgs {
 #define TA355_RATE_256x256 0.9      /* simple double buffer: superseded by the ping-pong schedule */
 #define TA355_RATE_256x128 0.5      /* measured slower than 128x128 on every shape */
 #define TA355_RATE_256x256_PP 1.15  /* sq8192: 1306 vs 1113 TF/s; fc1 819 vs 692; enc qkv 833 vs 772 (profiles/r01_b_*) */
+#define TA355_RATE_256x320_PP 1.2   /* enc qkv 1039 vs 890 TF/s, fc2 1165 vs 889, conv2 1218 vs 863, lm gate|up 910 vs 816 (profiles/r01_e_gemm_variants.txt) */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
 
@@ -453,18 +454,19 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
-// Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong.
+// Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong,
+// 4 = 256x320 ping-pong (N = 1280 / 3840 / 5120 divide exactly: M = 16000 x N = 1280 is 252 tiles = ONE round of 256 CUs).
 // Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
 // come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0..3 forces one (experiments, tests).
 #include <cstdlib>
 static int pick_variant(int M, int N, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 3) return forced;
-  const double rate[4] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP};
-  const int bm[4] = {128, 256, 256, 256}, bn[4] = {128, 256, 128, 256}, slots[4] = {512, 256, 256, 256};
+  if (forced >= 0 && forced <= 4) return forced;
+  const double rate[5] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP};
+  const int bm[5] = {128, 256, 256, 256, 256}, bn[5] = {128, 256, 128, 256, 320}, slots[5] = {512, 256, 256, 256, 256};
   int best = 0; double best_t = 1e300;
-  for (int v = 0; v < 4; ++v) {
+  for (int v = 0; v < 5; ++v) {
     const long tiles = (long)ta_cdiv(M, bm[v]) * ta_cdiv(N, bn[v]) * splits;
     const double rounds = (double)((tiles + slots[v] - 1) / slots[v]);
     // a round of variant v costs (tile area / rate) per slot; v1 runs two tiles per CU concurrently
@@ -477,7 +479,7 @@ static int pick_variant(int M, int N, int splits) {
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int variant = pick_variant(a.M, a.N, a.splits);
-  const int bm = variant == 0 ? 128 : 256, bn = (variant == 1 || variant == 3) ? 256 : 128;
+  const int bm = variant == 0 ? 128 : 256, bn = variant == 4 ? 320 : ((variant == 1 || variant == 3) ? 256 : 128);
   a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   ProfRec r;
@@ -489,6 +491,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   TA_CHECK_LAUNCH();
