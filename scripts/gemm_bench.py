@@ -42,7 +42,8 @@ if only in ("all", "gemm"):
     variants = sys.argv[sys.argv.index("--variants") + 1].split(",") if "--variants" in sys.argv else [""]
     for name, M, N, K, obf, act, hasres in shapes:
       for var in variants:
-        os.environ["TA355_GEMM_VARIANT"] = var
+        os.environ["TA355_GEMM_VARIANT"] = var.split("w")[0]
+        os.environ["TA355_EPI_WIDE"] = "0" if var.endswith("w0") else "1"
         name_v = name + (":v" + var if var else "")
         A = (torch.randn(M, K, device=DEV) * 1.0).to(BF16)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(BF16)

@@ -32,7 +32,7 @@ def cos_sim(a, b):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 1280, 1280), (77, 384, 3840), (2048, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 1280, 1280), (77, 384, 3840), (2048, 1024, 4096), (333, 1284, 128), (515, 5128, 64)])
 @pytest.mark.parametrize("out_bf16", [True, False])
 def test_gemm_plain(M, N, K, out_bf16):
     A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)

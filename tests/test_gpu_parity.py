@@ -328,7 +328,7 @@ def test_lora_zero_b_is_identity_and_stage2_trains():
               audio_token_counts=torch.from_numpy(counts))
     o0 = base(input_features=feats, **tb)
     o1 = m(input_features=feats, **tb)
-    assert abs(float(o0.loss.detach()) - float(o1.loss.detach())) < 1e-6
+    assert abs(float(o0.loss.detach()) - float(o1.loss.detach())) < 1e-5      # CE sum is an atomic reduction: order-dependent ulps
     assert torch.equal(o0.logits, o1.logits)
     tr = ASRTrainer(m, TrainingArguments(learning_rate=2e-3, warmup_steps=0, max_steps=8, lr_scheduler_type="constant",
                                          weight_decay=0.0))

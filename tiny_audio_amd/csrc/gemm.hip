@@ -38,6 +38,7 @@ struct GemmArgs {
   // K extension (LoRA): after the K columns of A / W the contraction continues over K2 more columns taken from
   // A2 [M, K2] (row stride lda2) and W2 [N, K2]:  C = A W^T + A2 W2^T  in one accumulator pass
   const bf16_t* A2; const bf16_t* W2; int K2; long lda2;
+  int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
 };
 
 #define BM 128
@@ -48,8 +49,8 @@ struct GemmArgs {
 #ifndef TA355_RATE_256x256
 #define TA355_RATE_256x256 0.9      /* simple double buffer: superseded by the ping-pong schedule */
 #define TA355_RATE_256x128 0.5      /* measured slower than 128x128 on every shape */
-#define TA355_RATE_256x256_PP 1.15  /* sq8192: 1306 vs 1113 TF/s; fc1 819 vs 692; enc qkv 833 vs 772 (profiles/r01_b_*) */
-#define TA355_RATE_256x320_PP 1.2   /* enc qkv 1039 vs 890 TF/s, fc2 1165 vs 889, conv2 1218 vs 863, lm gate|up 910 vs 816 (profiles/r01_e_gemm_variants.txt) */
+#define TA355_RATE_256x256_PP 1.40  /* per unit tile area vs the 128x128 kernel, fitted on profiles/r01_f_gemm_variants.txt (lm_qkv 56 vs 62 us, sq8192 1330 vs 1050 TF/s) */
+#define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
 
@@ -57,6 +58,53 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+
+// ---- epilogue of one 16-row fragment strip: lane (l15, g) owns row l15 and, in each of the NT 16-column fragments,
+// columns 4g .. 4g+3.  f32 outputs go out as float4 (the four g lanes of a row cover 64 contiguous bytes).  bf16
+// outputs would be 8 B per lane = 32-B runs, which the L2 takes at the same request rate as 64-B ones (measured:
+// the bf16 epilogue cost 14.5 us per round of 256 tiles vs 7.6 us of HBM time), so adjacent fragments are first
+// exchanged between lane rows with v_permlane16_swap: afterwards lane g holds 8 consecutive columns
+// (16 * (j + (g & 1)) + 8 * (g >> 1) ...) and one store covers 64 contiguous bytes per row.
+template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
+__device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide) {
+  uint2 o[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = nb + j * 16 + g * 4;
+    const bool in = n < p.N;
+    f32x4 v = acc[j];
+    if (in) {
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (ACT == 1) {
+        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
+      }
+      if (HAS_RES) {
+        const float4 r = *(const float4*)(p.res + roff + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+    }
+    if (OUT_BF16) {
+      o[j].x = pack2bf(v[0], v[1]);
+      o[j].y = pack2bf(v[2], v[3]);
+      if (in && (!wide || (j == NT - 1 && (NT & 1)))) *(uint2*)(Cb + (roff + n) * 2) = o[j];
+    } else if (in) {
+      *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  if (OUT_BF16 && wide) {
+#pragma unroll
+    for (int j = 0; j + 1 < NT; j += 2) {
+      const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
+      const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
+      const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
+      if (col < p.N) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
+    }
+  }
+}
+__device__ __forceinline__ bool epilogue_wide_ok(const GemmArgs& p) { return p.wide != 0; }
 
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
@@ -173,37 +221,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // ---- epilogue: lane owns row m = .. + l15, columns n .. n+3 (n = .. + g*4)
   char* Cb = (char*)p.C;
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+  const bool wide = epilogue_wide_ok(p);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ml = m0 + wm * 64 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + g * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (ACT == 1) {
-        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
-      }
-      if (HAS_RES) {
-        const float4 r = *(const float4*)(p.res + roff + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      if (OUT_BF16) {
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *(uint2*)(Cb + (roff + n) * 2) = o;
-      } else {
-        *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide);
   }
 }
 
@@ -394,37 +419,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 
   char* Cb = (char*)p.C;
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+  const bool wide = epilogue_wide_ok(p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int ml = m0 + wm * 128 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * (BN2 / 4) + j * 16 + g * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (ACT == 1) {
-        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
-      }
-      if (HAS_RES) {
-        const float4 r = *(const float4*)(p.res + roff + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      if (OUT_BF16) {
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *(uint2*)(Cb + (roff + n) * 2) = o;
-      } else {
-        *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide);
   }
 }
 
@@ -482,6 +484,10 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int bm = variant == 0 ? 128 : 256, bn = variant == 4 ? 320 : ((variant == 1 || variant == 3) ? 256 : 128);
   a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
+  {
+    const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
+    a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
+  }
   ProfRec r;
   if (g_prof_on) {
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return TA_ERR_LAUNCH;
