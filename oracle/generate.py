@@ -1,0 +1,67 @@
+"""Greedy generation, numpy.  TEST INFRASTRUCTURE ONLY.
+
+tiny_audio/asr_modeling.py:562-646 (ASRModel.generate): encode audio, embed the prompt, masked_scatter the
+projector rows into the <audio> positions, then ``language_model.generate(input_ids=, inputs_embeds=,
+attention_mask=, generation_config=)`` and strip the prompt.  The generation config is greedy
+(tiny_audio/asr_config.py:103-111: num_beams 1, do_sample False, repetition_penalty 1.0, no_repeat_ngram_size 0,
+min_new_tokens 0, max_new_tokens 128) with eos = [<|im_end|>, <|endoftext|>] (asr_modeling.py:163-168).
+
+HF greedy search (TF:generation/utils.py ``_sample`` with do_sample=False):
+    next = argmax(logits[:, -1].float());  next = next * unfinished + pad * (1 - unfinished)
+    sequences = cat(sequences, next);  unfinished &= ~isin(next, eos);  stop when unfinished.max() == 0
+    or max_new_tokens reached.
+No KV cache here: the whole sequence is re-run every step (small configs only); the cache is an optimisation that
+does not change the arithmetic.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import encoder as enc
+from . import projectors as proj
+from . import qwen3
+from .model import gather_audio_embeds, masked_scatter_rows
+
+
+def prompt_embeds(batch, W, cfg):
+    """inputs_embeds of the prompt with the audio rows in place (asr_modeling.py:586-629), eval mode."""
+    ids = batch["input_ids"]
+    emb = W["lm"]["model.embed_tokens.weight"][ids]
+    hs = enc.encoder_forward(batch["input_features"], W["encoder"], cfg["enc"])
+    if cfg.get("projector_type", "mlp") == "mlp":
+        y, _ = proj.mlp_forward(hs, W["projector"], cfg.get("k", 4))
+    else:
+        y, _, _ = proj.moe_forward(hs, W["projector"], cfg.get("k", 4), training=False)
+    is_audio = ids == cfg["audio_token_id"]
+    counts = batch.get("audio_token_counts")
+    if counts is None:
+        counts = is_audio.sum(-1)
+    return masked_scatter_rows(emb, is_audio, gather_audio_embeds(y, counts))
+
+
+def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False):
+    """-> generated token ids [B, n_new] (prompt stripped), n_new <= max_new_tokens.  The prompt must be unpadded
+    (attention_mask all ones), which is what ASRModel.generate builds.  ``return_margins`` also returns the
+    top-1 minus top-2 logit gap of every decision (how robust the argmax is to bf16 rounding)."""
+    att = batch.get("attention_mask")
+    assert att is None or bool(np.all(att == 1)), "oracle generate: unpadded prompts only"
+    x = prompt_embeds(batch, W, cfg)
+    B = x.shape[0]
+    embed = W["lm"]["model.embed_tokens.weight"]
+    unfinished = np.ones(B, dtype=bool)
+    out, margins = [], []
+    for _ in range(max_new_tokens):
+        logits, _ = qwen3.lm_forward(x, np.ones(x.shape[:2], np.int64), W["lm"], cfg["lm"], keep_cache=False,
+                                     lora=W.get("lora"), lora_scale=cfg.get("lora_scale", 0.0))
+        last = logits[:, -1].astype(np.float32)
+        nxt = last.argmax(-1)
+        srt = np.sort(last, axis=-1)
+        margins.append(srt[:, -1] - srt[:, -2])
+        nxt = np.where(unfinished, nxt, pad_id)
+        out.append(nxt)
+        unfinished &= ~np.isin(nxt, np.asarray(list(eos_ids), dtype=np.int64))
+        if not unfinished.any():
+            break
+        x = np.concatenate([x, embed[nxt][:, None, :]], axis=1)
+    seq = np.stack(out, axis=1).astype(np.int64)
+    return (seq, np.stack(margins, axis=1)) if return_margins else seq

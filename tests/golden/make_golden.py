@@ -203,13 +203,13 @@ class _StubTokenizer:
         return SMALL["lm"]["vocab"]
 
 
-def build_asr(ptype, pw, **cfg_kw):
+def build_asr(ptype, pw, lm_weights=None, **cfg_kw):
     """ASRModel with the four hub loaders patched."""
     from transformers import WhisperFeatureExtractor
     from tiny_audio.asr_config import ASRConfig
     from tiny_audio import asr_modeling as AM
     enc = build_encoder(SMALL["enc"], OW.init_encoder(SMALL["enc"], seed=0))
-    lm = build_lm(SMALL["lm"], OW.init_lm(SMALL["lm"], seed=1))
+    lm = build_lm(SMALL["lm"], lm_weights if lm_weights is not None else OW.init_lm(SMALL["lm"], seed=1))
 
     def _enc(cls, config, dtype):
         enc.requires_grad_(False); enc.eval(); return enc
@@ -292,6 +292,34 @@ def gen_asr():
          **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters()})
 
 
+# ----------------------------------------------------------------------------- 6b. greedy generation (section 8(f) rank 1)
+def gen_generate():
+    """ASRModel.generate of the reference (HF GenerationMixin greedy search with a DynamicCache) on the reduced
+    model: (a) 12 new tokens without EOS; (b) the same with eos := a token clip 0 reaches before clip 1 does, so
+    clip 0 stops early and is padded while clip 1 runs on."""
+    from transformers import WhisperFeatureExtractor
+    from tests.golden.recipe import gen_waves, gen_prompt, gen_lm_weights
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    fe = WhisperFeatureExtractor(feature_size=128); fe.padding = False
+    a = fe(gen_waves(), sampling_rate=16000, padding="longest", return_attention_mask=True, return_tensors="np")
+    feats, amask = a["input_features"].astype(np.float32), a["attention_mask"].astype(np.int64)
+    n_audio = int(((amask.sum(-1)[0] - 1) // 2 + 1 - 4) // 4 + 1)
+    ids = gen_prompt(n_audio)
+    model = build_asr("mlp", OW.init_mlp_projector(E, D, H), lm_weights=gen_lm_weights())
+    model.eval()
+    kw = dict(input_ids=t(ids), input_features=t(feats), audio_attention_mask=t(amask), attention_mask=torch.ones_like(t(ids)))
+    model.generation_config.eos_token_id = [SMALL["eos_id"], SMALL["pad_id"]]
+    model.generation_config.pad_token_id = SMALL["pad_id"]
+    a_out = model.generate(**kw, max_new_tokens=12).numpy()
+    first = lambda row, tok: int(np.argmax(row == tok)) if (row == tok).any() else 99
+    eos = next(int(tok) for tok in a_out[0] if first(a_out[0], tok) >= 2 and first(a_out[1], tok) > first(a_out[0], tok))
+    model.generation_config.eos_token_id = [eos, SMALL["pad_id"]]
+    b_out = model.generate(**kw, max_new_tokens=12).numpy()
+    save("generate_small.npz", input_features=feats, audio_attention_mask=amask, input_ids=ids, n_audio=np.array(n_audio),
+         tokens_a=a_out, eos_b=np.array(eos), tokens_b=b_out)
+    print("generate:", a_out.tolist(), eos, b_out.tolist())
+
+
 # ----------------------------------------------------------------------------- 7. known answers held by the reference tests
 def gen_known_answers():
     from tiny_audio.asr_config import compute_encoder_output_length
@@ -310,7 +338,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "lora", "asr", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "lora", "asr", "generate", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "generate": gen_generate, "known": gen_known_answers}[w]()

@@ -58,3 +58,28 @@ def asr_tokens(counts):
     """Token stream for the whole-model fixtures (ragged audio-token counts)."""
     return OW.synthetic_tokens(2, list(counts), SMALL["lm"]["vocab"], SMALL["audio_token_id"],
                                SMALL["pad_id"], SMALL["eos_id"], n_text=20, n_suffix=8, ragged=True)
+
+
+def gen_waves():
+    """Two clips of equal length (2.0 s) for the generation fixture: equal audio-token counts, so the prompt is the
+    unpadded [prefix | <audio>*n | suffix] that ASRModel.generate itself builds (asr_modeling.py:588-616)."""
+    return [OW.synthetic_wave(7, 32000), OW.synthetic_wave(8, 32000)]
+
+
+def gen_prompt(n_audio, B=2, n_prefix=3, n_suffix=8):
+    ids = np.concatenate([np.arange(5, 5 + n_prefix), np.full(n_audio, SMALL["audio_token_id"]),
+                          np.arange(40, 40 + n_suffix)]).astype(np.int64)
+    return np.tile(ids[None, :], (B, 1))
+
+
+GEN_BOOST = 16.0
+
+
+def gen_lm_weights():
+    """LM weights of the generation fixture: o_proj / down_proj scaled up so that the block outputs dominate the
+    residual stream -- with the plain init a random tied-embedding LM just repeats its last input token."""
+    w = OW.init_lm(SMALL["lm"], seed=1)
+    for k in w:
+        if k.endswith("o_proj.weight") or k.endswith("down_proj.weight"):
+            w[k] = (w[k] * np.float32(GEN_BOOST)).astype(np.float32)
+    return w

@@ -147,6 +147,27 @@ def test_qwen3_lora_grads(golden):
         assert relerr(grads[k], g["g." + k]) < 2e-4, k
 
 
+def test_greedy_generate(golden):
+    """Section 8(f) rank 1: token-exact against ASRModel.generate of the reference (HF greedy search + KV cache),
+    including EOS stop and pad fill for the clip that finishes first."""
+    from oracle import generate as OG
+    g = golden("generate_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    W = dict(encoder=OW.init_encoder(S["enc"], 0), lm=R.gen_lm_weights(), projector=OW.init_mlp_projector(E, D, H))
+    cfg = dict(enc=S["enc"], lm=S["lm"], projector_type="mlp", k=S["k"], audio_token_id=S["audio_token_id"])
+    wav, lens = OF.pad_batch(R.gen_waves())
+    feats = OF.log_mel(wav, lens)[0]
+    np.testing.assert_allclose(feats, g["input_features"], atol=2e-4)
+    np.testing.assert_array_equal(R.gen_prompt(int(g["n_audio"])), g["input_ids"])
+    batch = dict(input_ids=g["input_ids"], input_features=g["input_features"], attention_mask=np.ones_like(g["input_ids"]))
+    a = OG.greedy_generate(batch, W, cfg, max_new_tokens=12, eos_ids=(S["eos_id"], S["pad_id"]), pad_id=S["pad_id"])
+    np.testing.assert_array_equal(a, g["tokens_a"])
+    b = OG.greedy_generate(batch, W, cfg, max_new_tokens=12, eos_ids=(int(g["eos_b"]), S["pad_id"]), pad_id=S["pad_id"])
+    np.testing.assert_array_equal(b, g["tokens_b"])
+    assert b.shape[1] == 11 and (b[0, 7:] == S["pad_id"]).all()          # clip 0 finished first and is padded
+
+
 # ----------------------------------------------------------------------------- whole model
 def _asr_setup(golden, ptype):
     g = golden("asr_small.npz")
