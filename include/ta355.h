@@ -169,6 +169,34 @@ int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_r
                        const int* kmask, const int* pos, int B, int L, const int* label_rows,
                        const long* label_targets, int n_label_rows, float loss_scale, float* loss,
                        float* nll_rows, void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st);
+/* ---- greedy decoding: ASRModel.generate, tiny_audio/asr_modeling.py:562-646, which
+ * drives HF GenerationMixin greedy search (num_beams 1, do_sample False: tiny_audio/asr_config.py:103-111) with a KV cache.
+ * kcache / vcache: bf16 [n_layers, B, kv_heads, Lmax, head_dim], owned by the caller.  lora_img: scratch of
+ * ta_lm_lora_image_bytes() bytes holding the bf16 adapter images between the prompt pass and the decode steps (NULL
+ * without adapters).
+ * ta_lm_prefill: the prompt pass over [B, L] rows (same inputs as ta_lm_forward_loss); fills cache slots [0, L) and
+ * returns logits f32 [B, vocab_pad] of row last_rows[b] (= b*L + index of clip b's last prompt token). */
+long ta_lm_prefill_workspace_bytes(const ta_lm_weights* w, int B, int L);
+long ta_lm_lora_image_bytes(const ta_lm_weights* w);
+int ta_lm_prefill(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio, const int* kmask,
+                  const int* pos, int B, int L, void* kcache, void* vcache, int Lmax, const int* last_rows, float* logits,
+                  void* lora_img, void* ws, long ws_bytes, hipStream_t st);
+/* One decode step: ids [B] = the tokens emitted last, at RoPE position pos[b]; their K/V go to cache slot *slot_dev;
+ * kmask [B, Lmax] marks the valid slots (including *slot_dev); logits f32 [B, vocab_pad] of the next token.  Every
+ * per-step quantity is read from device memory, so the launch sequence is step-invariant (hipGraph-capturable). */
+long ta_lm_decode_workspace_bytes(const ta_lm_weights* w, int B);
+int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const int* pos, const int* kmask, const int* slot_dev, int B,
+                      void* kcache, void* vcache, int Lmax, float* logits, const void* lora_img, void* ws, long ws_bytes,
+                      hipStream_t st);
+/* out[r] = argmax over the first n columns of row r (lowest index on ties) */
+int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out, hipStream_t st);
+/* HF greedy bookkeeping for step t = *step_dev (TF:generation/utils.py _sample): finished clips emit pad_id, a clip
+ * finishes on any eos id; writes out_seq[b, t], next_ids[b]; advances pos / *slot_dev / kmask for the next decode step
+ * (not on t == 0, whose token comes from the prompt pass); *step_dev += 1; *n_unfinished = clips still running. */
+int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad_id, int* finished, long* next_ids,
+                      long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax, int B,
+                      int* n_unfinished, hipStream_t st);
+
 /* d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written; NULL = not wanted, e.g. frozen
  * projector); d_embeds optional [B*L, D]; lora_grads: host array [n_layers] (required iff w->lora_rank > 0). */
 int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,

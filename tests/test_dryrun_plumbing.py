@@ -142,6 +142,36 @@ def test_lora_stage2_plumbing(dry):
         ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16), device="cpu", init="none")
 
 
+def test_generate_plumbing(dry):
+    """Section 8(f) rank 1: the argument marshalling of prefill / decode step / greedy bookkeeping, the reference's
+    error behaviour, and the trim of surplus columns (nothing is computed under DRY_RUN: every token is 0)."""
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2)
+    for lora in (False, True):
+        cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, pad_token_id=990,
+                        eos_token_id=991, use_lora=lora)
+        m = ASRModel(cfg, device="cpu", init="random")
+        ids = torch.tensor([[5, 6] + [999] * 12 + [7, 8]] * 2)
+        kw = dict(input_ids=ids, input_features=torch.zeros(2, 128, 100), audio_attention_mask=torch.ones(2, 100, dtype=torch.int64),
+                  attention_mask=torch.ones_like(ids))
+        dry.calls.clear()
+        out = m.generate(**kw, max_new_tokens=5, eos_token_id=[])      # (every dry-run token is the pad id)
+        assert out.shape == (2, 5) and out.dtype == torch.int64
+        assert m.generate(**kw, max_new_tokens=5).shape == (2, 1)        # pad is an eos id: trimmed after step 0
+        dry.calls.clear(); m.generate(**kw, max_new_tokens=5, eos_token_id=[])
+        assert dry.calls.count("ta_lm_prefill") == 1 and dry.calls.count("ta_lm_decode_step") == 4
+        assert dry.calls.count("ta_greedy_advance") == 5 and dry.calls.count("ta_argmax_f32") == 5
+    with pytest.raises(ValueError, match="input_features required"):
+        m.generate(input_ids=ids)
+    with pytest.raises(ValueError, match="audio_attention_mask required"):
+        m.generate(input_ids=ids, input_features=torch.zeros(2, 128, 100))
+    with pytest.raises(ValueError, match="input_ids required"):
+        m.generate(input_features=torch.zeros(2, 128, 100), audio_attention_mask=torch.ones(2, 100, dtype=torch.int64))
+    with pytest.raises(NotImplementedError):
+        m.generate(**kw, do_sample=True)
+
+
 def test_primitive_wrappers_marshal(dry):
     from tiny_audio_amd import ops
     bf, f32 = torch.bfloat16, torch.float32

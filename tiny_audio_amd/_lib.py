@@ -21,7 +21,7 @@ HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
-           "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "api.hip"]
+           "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "generate.hip", "api.hip"]
 
 
 class Ta355Error(RuntimeError):
@@ -110,7 +110,7 @@ def hipcc_path():
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every kernel source into one shared object (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), HEADER]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "host_util.h"), HEADER]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made

@@ -64,6 +64,8 @@ class ASRModel(nn.Module):
         if getattr(config, "freeze_projector", False):
             self.projector.requires_grad_(False)
         self._drop_seed = 0x5EED + seed
+        self.tokenizer = kwargs.get("tokenizer")        # optional: only needed when generate() must build the prompt
+        self.system_prompt = getattr(config, "system_prompt", None)
 
     def _setup_lora(self, config, seed=0):
         """Stage-2 adapters on the LM (tiny_audio/asr_modeling.py:289-301: LoraConfig(r, lora_alpha,
@@ -172,3 +174,75 @@ class ASRModel(nn.Module):
                 loss = loss + aux.to(loss.device)                                          # asr_modeling.py:528-531
         return CausalLMOutput(loss=loss, logits=logits, nll=nll[:n_lab] if labels is not None else None,
                               n_label_tokens=n_lab, aux_loss=aux)
+
+    # ------------------------------------------------------------------ generation
+    def _generation_setting(self, name, default, overrides):
+        v = overrides.pop(name, None)
+        if v is None:
+            v = getattr(self.config, name, None)
+        return default if v is None else v
+
+    def _get_num_audio_tokens(self, audio_attention_mask):
+        """tiny_audio/asr_modeling.py:548-560"""
+        lens = self._compute_encoder_output_lengths(audio_attention_mask)
+        return int(self.projector.get_output_length(int(lens.max().item())))
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
+                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 system_prompt: Optional[str] = None, **generate_kwargs) -> torch.Tensor:
+        """Transcription token ids [B, n_new] (prompt stripped), as ASRModel.generate of the reference
+        (tiny_audio/asr_modeling.py:562-646): audio -> encoder -> projector -> <audio> rows of the prompt embeddings ->
+        greedy search on the LM.  Only the reference's own generation config is built (greedy: num_beams 1,
+        do_sample False, repetition_penalty 1.0, no_repeat_ngram_size 0, min_new_tokens 0; asr_config.py:103-111)."""
+        if input_features is None:
+            raise ValueError("input_features required for generation")
+        if audio_attention_mask is None:
+            raise ValueError("audio_attention_mask required for generation")
+        kw = dict(generate_kwargs)
+        max_new = int(self._generation_setting("max_new_tokens", 128, kw))
+        if (int(self._generation_setting("num_beams", 1, kw)) != 1 or bool(self._generation_setting("do_sample", False, kw))
+                or float(self._generation_setting("repetition_penalty", 1.0, kw)) != 1.0
+                or int(self._generation_setting("no_repeat_ngram_size", 0, kw)) != 0
+                or int(self._generation_setting("min_new_tokens", 0, kw)) != 0):
+            raise NotImplementedError("only the reference's greedy generation config is built (asr_config.py:103-111)")
+        eos_ids = kw.pop("eos_token_id", None)
+        if eos_ids is None:       # <|im_end|> and <|endoftext|> (asr_modeling.py:163-167); the latter is Qwen's pad token
+            eos_ids = [self.config.eos_token_id, self.config.pad_token_id]
+        eos_ids = [int(e) for e in (eos_ids if isinstance(eos_ids, (list, tuple)) else [eos_ids]) if e is not None]
+        pad_id = int(kw.pop("pad_token_id", self.config.pad_token_id))
+        dev = self.device_
+        was_training = self.training
+        self.eval()
+        try:
+            feats = input_features.to(dev)
+            B = feats.shape[0]
+            amask = audio_attention_mask.to(dev)
+            enc_len = self._compute_encoder_output_lengths(amask)
+            counts = self.projector.get_output_length(enc_len).to(device=dev, dtype=torch.int64).contiguous()
+            y = self._encode_audio(feats)                                                   # [B, N, D]
+            N = y.shape[1]
+            if input_ids is None:
+                if self.tokenizer is None:
+                    raise ValueError("input_ids required: no tokenizer is attached to build the chat prompt")
+                n_audio = self._get_num_audio_tokens(amask)
+                messages = []
+                sp = system_prompt or self.system_prompt
+                if sp:
+                    messages.append({"role": "system", "content": sp})
+                content = "<audio>" * n_audio + (" " + self.TRANSCRIBE_PROMPT if self.TRANSCRIBE_PROMPT else "")
+                messages.append({"role": "user", "content": content})
+                chat = self.tokenizer.apply_chat_template(messages, tokenize=True, add_generation_prompt=True,
+                                                          return_tensors="pt", enable_thinking=False)
+                input_ids = chat.input_ids if hasattr(chat, "input_ids") else chat
+                if input_ids.dim() == 1:
+                    input_ids = input_ids.unsqueeze(0)
+                if input_ids.shape[0] == 1 and B > 1:
+                    input_ids = input_ids.expand(B, -1)
+                attention_mask = torch.ones_like(input_ids)
+            ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+            src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
+            return self.language_model.greedy_decode(ids, src_row, y.reshape(B * N, -1), attention_mask, max_new, eos_ids,
+                                                     pad_id)
+        finally:
+            self.train(was_training)

@@ -7,32 +7,7 @@
 
 extern "C" int ta_version(void) { return 1; }
 
-namespace {
-struct Carver {
-  char* base; size_t off;
-  explicit Carver(void* b) : base((char*)b), off(0) {}
-  template <typename T> T* take(size_t n) {
-    off = (off + 255) & ~(size_t)255;
-    T* p = base ? (T*)(base + off) : nullptr;
-    off += n * sizeof(T);
-    return p;
-  }
-  size_t total() const { return (off + 255) & ~(size_t)255; }
-};
-inline int pad64(int x) { return (x + 63) / 64 * 64; }
-inline int gemm(const void* A, const void* W, void* C, int M, int N, int K, const float* bias, const float* res, int act,
-                int out_bf16, hipStream_t st) {
-  return ta_gemm_bf16_nt(A, W, C, M, N, K, K, 0, 0, N, 0, 0, 0, bias, res, act, out_bf16, 1, nullptr, st);
-}
-// split-K heuristic: fill the 512 resident workgroup slots (256 CUs x 2) when the tile grid is small
-inline int pick_splits(int M, int N, int K) {
-  const long tiles = (long)ta_cdiv(M, 128) * ta_cdiv(N, 128);
-  int s = 1;
-  while (tiles * s < 512 && K / 64 / (s * 2) >= 8 && s < 64) s *= 2;
-  return s;
-}
-#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
-}  // namespace
+#include "host_util.h"
 
 // ============================================================================ encoder
 namespace {
@@ -187,7 +162,6 @@ extern "C" int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x,
 
 // ============================================================================ Qwen3 LM
 namespace {
-struct LoraImg { bf16_t *a, *at, *b, *bt; };     // s*Acat [64,in], its transpose [in,64], Bext [N,64], its transpose [64,N]
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
@@ -296,24 +270,14 @@ extern "C" long ta_lm_workspace_bytes(const ta_lm_weights* w, int B, int L, int 
   return (long)lm_ws(w, B, L, n_label_rows, nullptr).bytes;
 }
 
-extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio,
-                                  const int* kmask, const int* pos, int B, int L, const int* label_rows,
-                                  const long* label_targets, int n_lab, float loss_scale, float* loss, float* nll_rows,
-                                  void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st) {
-  if (B <= 0 || L <= 0) return TA_OK;
-  if (w->n_layers > MAX_LM_LAYERS || w->head_dim != 128 || w->hidden % 128 || w->ffn % 64 || w->vocab_pad % 128 ||
-      w->vocab > w->vocab_pad || L > w->max_pos)
-    return TA_ERR_ARG;
-  const LmDims d = lm_dims(w, B, L);
+// The decoder layers of Qwen3 (TF:models/qwen3/modeling_qwen3.py:283-324) over B*L token rows.  Training keeps one
+// tape entry per layer; inference (`alias`) reuses entry 0 for every layer.  `ext`: adapter images held outside the
+// tape (generation keeps them across decode steps); kcache/vcache: see ta_lm_prefill.
+static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int L, const int* kmask, const int* pos,
+                             LmLayerTape* store, bool alias, float* x_final, LmWs& s, const ta_i_lora_layer_imgs* ext,
+                             bf16_t* kcache, bf16_t* vcache, int Lmax, hipStream_t st) {
   const int M = (int)d.M;
-  LmLayerTape store[MAX_LM_LAYERS];
-  LmTape t = lm_tape(w, B, L, n_lab, tape, store);
-  LmWs s = lm_ws(w, B, L, n_lab, ws);
-  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
   const float scale = 1.0f / sqrtf((float)d.hd);
-  float* x = store[0].x_in;
-  // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
-  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
   const bool lora = w->lora_rank > 0;
   const int r = w->lora_rank;
   if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
@@ -324,8 +288,9 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
   };
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_lm_layer& Lw = w->layers[l];
-    LmLayerTape& p = store[l];
-    float* x_next = (l + 1 < w->n_layers) ? store[l + 1].x_in : t.x_final;
+    LmLayerTape p = store[alias ? 0 : l];
+    if (ext) { p.i_qkv = ext[l].g[0]; p.i_o = ext[l].g[1]; p.i_gu = ext[l].g[2]; p.i_d = ext[l].g[3]; }
+    float* x_next = (l + 1 < w->n_layers) ? store[alias ? 0 : l + 1].x_in : x_final;
     bf16_t* xn = lora ? p.xn_s : s.xn;
     if (lora) {   // bf16 images of this layer's adapters (kept in the tape for backward)
       const int NB = 1 << 30, bq = d.nq * d.hd, bk = bq + d.nkv * d.hd;
@@ -343,6 +308,12 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
     RC(gemm(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
                           p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
+    if (kcache) {   // greedy decoding: keys / values of the prompt go to the cache [layer, B, Hkv, Lmax, hd]
+      const size_t row = (size_t)L * d.hd * 2, pitch = (size_t)Lmax * d.hd * 2, rows = (size_t)B * d.nkv;
+      if (hipMemcpy2DAsync(kcache + (size_t)l * rows * Lmax * d.hd, pitch, p.k, row, row, rows, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpy2DAsync(vcache + (size_t)l * rows * Lmax * d.hd, pitch, p.v, row, row, rows, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return TA_ERR_LAUNCH;
+    }
     RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
     RC(gemm(p.ao, Lw.wo, p.x1, M, d.D, d.nq * d.hd, nullptr, p.x_in, 0, 0, st));
@@ -355,6 +326,27 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
     if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d));
     RC(gemm(act, Lw.wd, x_next, M, d.D, d.F, nullptr, p.x1, 0, 0, st));
   }
+  return TA_OK;
+}
+
+extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio,
+                                  const int* kmask, const int* pos, int B, int L, const int* label_rows,
+                                  const long* label_targets, int n_lab, float loss_scale, float* loss, float* nll_rows,
+                                  void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (w->n_layers > MAX_LM_LAYERS || w->head_dim != 128 || w->hidden % 128 || w->ffn % 64 || w->vocab_pad % 128 ||
+      w->vocab > w->vocab_pad || L > w->max_pos)
+    return TA_ERR_ARG;
+  const LmDims d = lm_dims(w, B, L);
+  const int M = (int)d.M;
+  LmLayerTape store[MAX_LM_LAYERS];
+  LmTape t = lm_tape(w, B, L, n_lab, tape, store);
+  LmWs s = lm_ws(w, B, L, n_lab, ws);
+  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
+  float* x = store[0].x_in;
+  // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
+  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
+  RC(lm_layers_forward(w, d, B, L, kmask, pos, store, false, t.x_final, s, nullptr, nullptr, nullptr, 0, st));
   RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
   if (logits_out)   // the reference's outputs.logits (bf16 under autocast), all positions
     RC(gemm(t.hn, w->embed_bf16, logits_out, M, w->vocab_pad, d.D, nullptr, nullptr, 0, 1, st));
@@ -366,6 +358,50 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
     RC(ta_cross_entropy(s.logits, 0, w->vocab_pad, nullptr, label_targets, n_lab, w->vocab, loss_scale, nll_rows, loss,
                         t.dlogits, w->vocab_pad, st));
   }
+  return TA_OK;
+}
+
+// ---------------------------------------------------------------------------- greedy decoding: prompt pass
+// (tiny_audio/asr_modeling.py:562-646 -> HF greedy search with a KV cache.)
+namespace {
+struct PrefillWs { ta_lm_weights w1; LmLayerTape layer[1]; LmTape t; LmWs s; size_t tape_bytes, bytes; };
+PrefillWs prefill_ws(const ta_lm_weights* w, int B, int L, void* base) {
+  PrefillWs p;
+  p.w1 = *w; p.w1.n_layers = 1;                                   // one layer's worth of activations, reused by every layer
+  p.t = lm_tape(&p.w1, B, L, 1, base, p.layer);
+  p.tape_bytes = p.t.bytes;
+  p.s = lm_ws(w, B, L, B, base ? (char*)base + p.tape_bytes : nullptr);   // hl / logits sized for B "label" rows
+  p.bytes = p.tape_bytes + p.s.bytes;
+  return p;
+}
+}  // namespace
+extern "C" long ta_lm_prefill_workspace_bytes(const ta_lm_weights* w, int B, int L) {
+  return (long)prefill_ws(w, B, L, nullptr).bytes;
+}
+extern "C" long ta_lm_lora_image_bytes(const ta_lm_weights* w) {
+  return w->lora_rank > 0 ? (long)lora_imgs_carve(w, nullptr, nullptr) : 0;
+}
+extern "C" int ta_lm_prefill(const ta_lm_weights* w, const long* ids, const int* src_row, const float* audio,
+                             const int* kmask, const int* pos, int B, int L, void* kcache, void* vcache, int Lmax,
+                             const int* last_rows, float* logits, void* lora_img, void* ws, long ws_bytes,
+                             hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (w->n_layers > MAX_LM_LAYERS || w->head_dim != 128 || w->hidden % 128 || w->ffn % 64 || w->vocab_pad % 128 ||
+      w->vocab > w->vocab_pad || L > w->max_pos || Lmax < L || !kcache || !vcache || !last_rows || !logits)
+    return TA_ERR_ARG;
+  if (w->lora_rank > 0 && !lora_img) return TA_ERR_ARG;
+  const LmDims d = lm_dims(w, B, L);
+  const int M = (int)d.M;
+  PrefillWs p = prefill_ws(w, B, L, ws);
+  if ((long)p.bytes > ws_bytes) return TA_ERR_ARG;
+  ta_i_lora_layer_imgs imgs[MAX_LM_LAYERS];
+  if (w->lora_rank > 0) lora_imgs_carve(w, lora_img, imgs);
+  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, p.layer[0].x_in, nullptr, M, d.D, w->vocab, st));
+  RC(lm_layers_forward(w, d, B, L, kmask, pos, p.layer, true, p.t.x_final, p.s, w->lora_rank > 0 ? imgs : nullptr,
+                       (bf16_t*)kcache, (bf16_t*)vcache, Lmax, st));
+  RC(ta_rmsnorm_fwd(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, 0, st));
+  RC(ta_gather_rows_bf16(p.t.hn, last_rows, p.s.hl, B, d.D, st));
+  RC(gemm(p.s.hl, w->embed_bf16, logits, B, w->vocab_pad, d.D, nullptr, nullptr, 0, 0, st));
   return TA_OK;
 }
 

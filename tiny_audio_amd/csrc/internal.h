@@ -1,6 +1,11 @@
 // Internal (non-exported) helpers shared between translation units of libta355.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "common.h"
+
+// bf16 images of one adapter group: s*Acat [64,in], its transpose [in,64], Bext [N,64], its transpose [64,N]
+struct LoraImg { bf16_t *a, *at, *b, *bt; };
+struct ta_i_lora_layer_imgs { LoraImg g[4]; };   // qkv, o, gate|up, down
 
 int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, hipStream_t st);
 int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, hipStream_t st);

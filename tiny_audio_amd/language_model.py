@@ -293,6 +293,83 @@ class Qwen3MI355X(torch.nn.Module):
         return d_audio, d_emb, lg
 
 
+    # ------------------------------------------------------------------ greedy decoding
+    @torch.no_grad()
+    def greedy_decode(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
+                      sync_every=8):
+        """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
+        config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
+        emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
+        padded with ``pad_id``).  All per-step state lives on the device; the host only polls the number of
+        unfinished clips every ``sync_every`` steps."""
+        if self._w is None:
+            raise _lib.Ta355Error("LM weights not loaded")
+        L_ = _lib.lib()
+        c, dev = self.config, self.device_
+        B, L = input_ids.shape
+        max_new = int(max_new_tokens)
+        if max_new <= 0:
+            return torch.empty((B, 0), dtype=torch.int64, device=dev)
+        Lmax = L + max_new
+        if Lmax > c.max_position_embeddings:
+            raise ValueError(f"prompt ({L}) + max_new_tokens ({max_new}) exceeds max_position_embeddings")
+        i32, i64 = torch.int32, torch.int64
+        att = torch.ones((B, L), dtype=i32, device=dev) if attention_mask is None else attention_mask.to(device=dev, dtype=i32)
+        kmask = torch.zeros((B, Lmax), dtype=i32, device=dev)
+        kmask[:, :L] = att
+        pos_full = (att.cumsum(-1) - 1).clamp(min=0).to(i32).contiguous()        # HF: position_ids from the mask
+        pos = att.sum(-1).to(i32).contiguous()                                     # position of the first new token
+        idx = torch.arange(L, device=dev, dtype=i32)[None, :].expand(B, L)
+        last = (idx * att).max(dim=-1).values                                      # last valid prompt token of each clip
+        last_rows = (torch.arange(B, device=dev, dtype=i32) * L + last.to(i32)).contiguous()
+        shape = (c.num_hidden_layers, B, c.num_key_value_heads, Lmax, c.head_dim)
+        kc, vc = torch.empty(shape, dtype=BF16, device=dev), torch.empty(shape, dtype=BF16, device=dev)
+        lora_img = None
+        if self.lora_rank:
+            self._bind_lora()
+            lora_img = torch.empty(L_.ta_lm_lora_image_bytes(C.byref(self._w)), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(L_.ta_lm_prefill_workspace_bytes(C.byref(self._w), B, L),
+                             L_.ta_lm_decode_workspace_bytes(C.byref(self._w), B)), dtype=torch.uint8, device=dev)
+        logits = torch.empty((B, self.vocab_pad), dtype=F32, device=dev)
+        amax = torch.zeros(B, dtype=i64, device=dev)
+        finished = torch.zeros(B, dtype=i32, device=dev)
+        next_ids = torch.zeros(B, dtype=i64, device=dev)
+        out_seq = torch.full((B, max_new), int(pad_id), dtype=i64, device=dev)
+        step_dev = torch.zeros(1, dtype=i32, device=dev)
+        slot_dev = torch.full((1,), L, dtype=i32, device=dev)
+        alive = torch.full((1,), B, dtype=i32, device=dev)
+        eos = torch.tensor(list(eos_ids) or [-1], dtype=i64, device=dev)
+        n_eos = len(list(eos_ids))
+        ids = input_ids.to(device=dev, dtype=i64).contiguous()
+        a = None if audio is None else audio.detach().to(F32).contiguous()
+
+        def advance():
+            _lib.check(L_.ta_argmax_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, ptr(amax), stream()), "ta_argmax_f32")
+            _lib.check(L_.ta_greedy_advance(ptr(amax), ptr(eos), n_eos, int(pad_id), ptr(finished), ptr(next_ids), ptr(out_seq),
+                                            max_new, ptr(step_dev), ptr(slot_dev), ptr(pos), ptr(kmask), Lmax, B, ptr(alive),
+                                            stream()), "ta_greedy_advance")
+
+        _lib.check(L_.ta_lm_prefill(C.byref(self._w), ptr(ids), ptr(src_row), ptr(a), ptr(att.contiguous()), ptr(pos_full), B, L,
+                                    ptr(kc), ptr(vc), Lmax, ptr(last_rows), ptr(logits), ptr(lora_img), ptr(ws), ws.numel(),
+                                    stream()), "ta_lm_prefill")
+        advance()
+        for t in range(1, max_new):
+            if t % sync_every == 0 and int(alive.item()) == 0:
+                break
+            _lib.check(L_.ta_lm_decode_step(C.byref(self._w), ptr(next_ids), ptr(pos), ptr(kmask), ptr(slot_dev), B, ptr(kc),
+                                            ptr(vc), Lmax, ptr(logits), ptr(lora_img), ptr(ws), ws.numel(), stream()),
+                       "ta_lm_decode_step")
+            advance()
+        seq = out_seq.cpu()
+        # HF stops right after the step in which the last clip finished: trim the surplus (all-pad) columns
+        n_new = max_new
+        if n_eos:
+            is_eos = torch.isin(seq, torch.tensor(list(eos_ids), dtype=i64))
+            first = torch.where(is_eos.any(-1), is_eos.to(torch.int8).argmax(-1) + 1, torch.full((B,), max_new + 1))
+            n_new = min(max_new, int(first.max()))
+        return out_seq[:, :n_new]
+
+
 class FrozenLMLoss(torch.autograd.Function):
     """loss = CE(frozen_LM(embed(ids) with <audio> rows := audio_embeds)); grad flows to audio_embeds and, when
     adapters are enabled, to the LoRA masters passed as trailing inputs (``*lm.lora_parameters()``)."""
