@@ -175,3 +175,34 @@ def test_dp_allreduce_matches_single_process_global_batch():
         np.testing.assert_allclose(g, lin.weight.grad.reshape(-1).numpy(), rtol=1e-5)    # SUM over ranks
         assert cnt == 9.0 and abs(ls - float(total)) < 1e-3 * float(total)
     # => grads / count == gradient of the global MEAN over all 9 tokens: HF Trainer's sum-CE / num_items semantics
+
+
+# ----------------------------------------------------------------------------- text post-processing + WER (8(f) rank 1)
+def test_text_postprocessing_matches_reference_outputs():
+    import json, os
+    from tiny_audio_amd import eval_text as ET
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "text_post.json")))
+    for src, want in g["truncate"]:
+        assert ET.truncate_repetitions(src) == want, src
+    for src, want in g["truncate_min2"]:
+        assert ET.truncate_repetitions(src, 2) == want, src
+    for src, want in g["think"]:
+        assert ET.strip_think(src) == want, src
+    vocab = {1: "<think>", 2: "</think>", 3: "hello", 4: "there", 9: "<eos>"}
+    text = ET.postprocess_tokens([1, 2, 3, 4, 4, 4, 9, 9], [9], lambda ids: " ".join(vocab[i] for i in ids))
+    assert text == "hello there"
+
+
+def test_word_error_rate_known_answers():
+    from tiny_audio_amd.eval_text import word_error_rate as wer
+    assert wer("the cat sat", "the cat sat") == 0.0
+    assert wer("the cat sat", "the cat") == pytest.approx(1 / 3)               # one deletion
+    assert wer("the cat sat", "the big cat sat") == pytest.approx(1 / 3)       # one insertion
+    assert wer("the cat sat", "a cat sat") == pytest.approx(1 / 3)             # one substitution
+    assert wer("a b c d", "") == 1.0
+    assert wer("a b", "x y z w") == 2.0                                        # WER can exceed 1
+    # corpus level: edits are pooled over the corpus, not averaged per sentence (jiwer.wer on lists)
+    assert wer(["a b c d", "e f"], ["a b c d", "x y"]) == pytest.approx(2 / 6)
+    assert wer("Hello, World", "hello world", normalize=lambda s: s.lower().replace(",", "")) == 0.0
+    with pytest.raises(ValueError):
+        wer(["a"], ["a", "b"])
