@@ -320,6 +320,34 @@ def gen_generate():
     print("generate:", a_out.tolist(), eos, b_out.tolist())
 
 
+# ----------------------------------------------------------------------------- 6c. checkpoint written by the reference (section 8(f) rank 3)
+def gen_ckpt():
+    """What ASRModel.save_pretrained stores for the trainable part: state_dict() -> model.safetensors (HF writes it with
+    safetensors + {"format": "pt"}) and the config as JSON (use_diff=False: the diff needs the hub default config)."""
+    from safetensors.torch import save_file
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    m = build_asr("mlp", OW.init_mlp_projector(E, D, H))
+    out = os.path.join(HERE, "ckpt_small")
+    os.makedirs(out, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in m.state_dict().items()}, os.path.join(out, "model.safetensors"), metadata={"format": "pt"})
+    m.config.vocab_size = m.language_model.config.vocab_size
+    with open(os.path.join(out, "config.json"), "w") as f:
+        f.write(m.config.to_json_string(use_diff=False))
+    print("wrote ckpt_small/")
+
+
+def gen_text_post():
+    """Outputs of the reference's string post-processing (tiny_audio/asr_pipeline.py:271-330) for tests/golden/text_post.json."""
+    import json
+    from tiny_audio.asr_pipeline import _truncate_repetitions, _THINK_TAG_RE
+    old = json.load(open(os.path.join(HERE, "text_post.json")))
+    out = {"truncate": [[c, _truncate_repetitions(c)] for c, _ in old["truncate"]],
+           "truncate_min2": [[c, _truncate_repetitions(c, 2)] for c, _ in old["truncate_min2"]],
+           "think": [[c, _THINK_TAG_RE.sub("", c).strip()] for c, _ in old["think"]]}
+    json.dump(out, open(os.path.join(HERE, "text_post.json"), "w"), ensure_ascii=False, indent=0)
+    print("wrote text_post.json")
+
+
 # ----------------------------------------------------------------------------- 7. known answers held by the reference tests
 def gen_known_answers():
     from tiny_audio.asr_config import compute_encoder_output_length
@@ -338,7 +366,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "lora", "asr", "generate", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "generate": gen_generate, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

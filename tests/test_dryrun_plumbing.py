@@ -172,6 +172,42 @@ def test_generate_plumbing(dry):
         m.generate(**kw, do_sample=True)
 
 
+def test_checkpoint_interchange(dry, tmp_path):
+    """Section 8(f) rank 3: (i) a checkpoint written from the REFERENCE model (tests/golden/ckpt_small: its
+    state_dict() via safetensors + its config.json) loads; (ii) save -> load round trip incl. the PEFT adapter layout."""
+    import json, os
+    from safetensors.torch import load_file
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tests.golden import recipe as R
+    ref_dir = os.path.join(os.path.dirname(__file__), "golden", "ckpt_small")
+    m = ASRModel.from_pretrained(ref_dir, device="cpu", init="none")
+    S = R.SMALL
+    assert m.config.projector_type == "mlp" and m.config.projector_hidden_dim == S["proj_hidden"]
+    assert m.config.text_config.hidden_size == S["lm"]["hidden"] and m.config.audio_config.num_hidden_layers == S["enc"]["layers"]
+    assert m.config.text_config.vocab_size == S["lm"]["vocab"] and m.config.encoder_conv_layers == [[1, 3, 1], [1, 3, 2]]
+    want = OW.init_mlp_projector(S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"])
+    for k, v in m.projector.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), want[k])
+    # (ii) our own save: same file names / key names, then back
+    cfg = type(m.config)(audio_config=S["enc"], text_config=S["lm"], projector_hidden_dim=S["proj_hidden"], audio_token_id=1023,
+                         use_lora=True, freeze_projector=True)
+    a = ASRModel(cfg, device="cpu", init="random", seed=3)
+    a.language_model.load_lora_state_dict(OW.init_lora(S["lm"], rank=8, seed=4))
+    out = tmp_path / "ck"
+    a.save_pretrained(out)
+    assert sorted(os.listdir(out)) == ["adapter_config.json", "adapter_model.safetensors", "config.json", "model.safetensors"]
+    assert set(load_file(str(out / "model.safetensors"))) == set(load_file(os.path.join(ref_dir, "model.safetensors")))
+    ad = load_file(str(out / "adapter_model.safetensors"))
+    assert "base_model.model.model.layers.1.mlp.down_proj.lora_B.weight" in ad and len(ad) == 2 * 7 * S["lm"]["layers"]
+    assert ad["base_model.model.model.layers.0.self_attn.k_proj.lora_A.weight"].shape == (8, S["lm"]["hidden"])
+    ac = json.load(open(out / "adapter_config.json"))
+    assert ac["peft_type"] == "LORA" and ac["r"] == 8 and ac["lora_alpha"] == 32 and ac["task_type"] == "CAUSAL_LM"
+    b = ASRModel.from_pretrained(out, device="cpu", init="random", seed=9)
+    assert b.config.use_lora and b.config.freeze_projector and b.language_model.lora_rank == 8
+    for (k1, v1), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+
+
 def test_primitive_wrappers_marshal(dry):
     from tiny_audio_amd import ops
     bf, f32 = torch.bfloat16, torch.float32

@@ -175,6 +175,19 @@ class ASRModel(nn.Module):
         return CausalLMOutput(loss=loss, logits=logits, nll=nll[:n_lab] if labels is not None else None,
                               n_label_tokens=n_lab, aux_loss=aux)
 
+    # ------------------------------------------------------------------ checkpoints
+    def save_pretrained(self, save_directory, **kwargs):
+        """model.safetensors (projector.*) + config.json (+ PEFT adapter files with LoRA), the reference's layout
+        (tiny_audio/asr_modeling.py:769-852)."""
+        from .checkpoint import save_pretrained
+        save_pretrained(self, str(save_directory))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *args, **kwargs):
+        """tiny_audio/asr_modeling.py:59-131 for a local directory."""
+        from .checkpoint import load_pretrained
+        return load_pretrained(cls, str(pretrained_model_name_or_path), **kwargs)
+
     # ------------------------------------------------------------------ generation (SURVEY.md section 8(f) rank 1)
     def _generation_setting(self, name, default, overrides):
         v = overrides.pop(name, None)

@@ -79,6 +79,10 @@ class Qwen3MI355X(torch.nn.Module):
             self._w.lora_rank, self._w.lora_scale = rank, float(alpha) / rank
         return self
 
+    def _finalize_lora_scale(self):
+        if self._w is not None and self.lora_rank:
+            self._w.lora_rank, self._w.lora_scale = self.lora_rank, float(self.lora_alpha) / self.lora_rank
+
     @torch.no_grad()
     def load_lora_state_dict(self, sd):
         """Accepts peft adapter naming (``...model.layers.N.self_attn.q_proj.lora_A[.default].weight``) or the bare
