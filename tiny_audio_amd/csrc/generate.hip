@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ vc, const int* __restrict__ kmask,
                                                           const int* __restrict__ slot_p, bf16_t* __restrict__ out, int Hq,
                                                           int Hkv, int Lmax, float scale) {
-  extern __shared__ float sm[];                    // [Lmax] scores, then [128] q, [8] partials, [256] output halves
+  extern __shared__ float sm[];                    // [Lmax] scores, then [128] q, [8] partials, [16 x 128] output partials
   float* sc = sm;
   float* qs = sm + Lmax;
   float* red = qs + HD;
@@ -94,25 +94,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   if (lane == 0) red[4 + wave] = sum;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  // threads 0..127 take even keys, 128..255 odd keys, dim d = tid & 127 (coalesced V rows)
-  const int d = tid & 127, par = tid >> 7;
-  float o = 0.f;
-  for (int j = par; j < n; j += 2) o += sc[j] * bf2f(V[(long)j * HD + d]);
-  oh[tid] = o;
+  // 16 key groups x 16 lanes; a lane owns 8 dims (one 16-B load per key row), partial sums meet in LDS
+  const int dc = tid & 15, kg = tid >> 4;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int j = kg; j < n; j += 16) {
+    const float p = sc[j];
+    const uint4 v = *(const uint4*)(V + (long)j * HD + dc * 8);
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] += p * bf2f((bf16_t)(u[e] & 0xffff));
+      o[2 * e + 1] += p * bf2f((bf16_t)(u[e] >> 16));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) oh[kg * HD + dc * 8 + e] = o[e];
   __syncthreads();
-  if (tid < HD) out[((long)b * Hq + h) * HD + tid] = f2bf((oh[tid] + oh[tid + 128]) * inv);
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += oh[k * HD + tid];
+    out[((long)b * Hq + h) * HD + tid] = f2bf(t * inv);
+  }
 }
 
-// row-wise argmax over the first n columns (lowest index wins ties, as torch.argmax on a CPU tensor does)
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld, int n, long* __restrict__ out) {
-  __shared__ float bv[4];
-  __shared__ int bi[4];
+// row-wise argmax over the first n columns (lowest index wins ties, as torch.argmax on a CPU tensor does).
+// One workgroup of 1024 lanes per row, float4 loads: a 151 680-column fp32 row is 37 load rounds.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ x, long ld, int n, long* __restrict__ out) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
   const float* row = x + (long)blockIdx.x * ld;
   float best = -INFINITY; int idx = 0x7fffffff;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    const float v = row[j];
-    if (v > best || (v == best && j < idx)) { best = v; idx = j; }
+  auto take = [&](float v, int j) { if (v > best || (v == best && j < idx)) { best = v; idx = j; } };
+  const bool vec = (((size_t)row) & 15) == 0;
+  const int n4 = vec ? n / 4 : 0;
+  for (int q = threadIdx.x; q < n4; q += 1024) {
+    const float4 v = ((const float4*)row)[q];
+    take(v.x, 4 * q); take(v.y, 4 * q + 1); take(v.z, 4 * q + 2); take(v.w, 4 * q + 3);
   }
+  for (int j = n4 * 4 + threadIdx.x; j < n; j += 1024) take(row[j], j);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
     out[blockIdx.x] = idx == 0x7fffffff ? 0 : idx;
   }
@@ -153,6 +174,101 @@ __global__ void greedy_advance_kernel(const long* __restrict__ amax, const long*
   }
   __syncthreads();
   if (threadIdx.x == 0) { *step_p = t + 1; *slot_p = t > 0 ? slot + 1 : slot; *n_unfinished = alive; }
+}
+
+// out[M, N] = X[M, K] W[N, K]^T (+ A2[M, 64] W2[N, 64]^T) (+ residual) for M <= 32: the decode-step linears.
+// A 128x128 tile grid leaves 8..48 workgroups each walking all of K serially (the step was latency-bound at
+// ~5 ms/token); here a workgroup owns 64 output columns, its eight waves split K, fragments come straight from
+// global memory (both operands are K-major) and the partial sums meet in LDS.  The kernel streams W once: HBM-bound.
+typedef __attribute__((ext_vector_type(8))) short gbf16x8;
+typedef __attribute__((ext_vector_type(4))) float gf32x4;
+template <bool OUT_BF16, int CB>      // CB = 16-column blocks per workgroup (4: wide layers and the LM head; 1: N = hidden)
+__global__ __launch_bounds__(512) void linear_small_m_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                             void* __restrict__ out, const float* __restrict__ res, int M,
+                                                             int N, int K, const bf16_t* __restrict__ A2,
+                                                             const bf16_t* __restrict__ W2) {
+  constexpr int COLS = CB * 16, UN = 4;                                   // UN k-steps of loads in flight per wave
+  __shared__ float red[8][32][COLS + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * COLS;
+  gf32x4 acc[2][CB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CB; ++b) acc[a][b] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+  const int ra = min(i, M - 1), rb = min(16 + i, M - 1);              // clamped rows are never stored
+  const bf16_t* xa = X + (long)ra * K + g * 8;
+  const bf16_t* xb = X + (long)rb * K + g * 8;
+  const bf16_t* wp[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) wp[cb] = W + (long)min(n0 + cb * 16 + i, N - 1) * K + g * 8;
+  const bool two = M > 16;
+  for (int k0 = wave * 32; k0 < K; k0 += 256 * UN) {
+    gbf16x8 a0[UN], a1[UN], b[UN][CB];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int kk = k0 + u * 256;
+      if (kk < K) {
+        a0[u] = *(const gbf16x8*)(xa + kk);
+        a1[u] = two ? *(const gbf16x8*)(xb + kk) : a0[u];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) b[u][cb] = *(const gbf16x8*)(wp[cb] + kk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (k0 + u * 256 < K) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[u], b[u][cb], acc[0][cb], 0, 0, 0);
+          if (two) acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[u], b[u][cb], acc[1][cb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (A2 && wave < 2) {                                                   // the adapter's 64-wide K tile: waves 0, 1
+    const int kk = wave * 32 + g * 8;
+    const gbf16x8 a0 = *(const gbf16x8*)(A2 + (long)ra * 64 + kk), a1 = *(const gbf16x8*)(A2 + (long)rb * 64 + kk);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const gbf16x8 b = *(const gbf16x8*)(W2 + (long)min(n0 + cb * 16 + i, N - 1) * 64 + kk);
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][cb], 0, 0, 0);
+      acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][cb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int rbk = 0; rbk < 2; ++rbk)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wave][rbk * 16 + g * 4 + q][cb * 16 + i] = acc[rbk][cb][q];
+  __syncthreads();
+  for (int e = tid; e < M * COLS; e += 512) {
+    const int row = e / COLS, col = e % COLS, n = n0 + col;
+    if (n >= N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w][row][col];
+    if (res) v += res[(long)row * N + n];
+    if (OUT_BF16) ((bf16_t*)out)[(long)row * N + n] = f2bf(v);
+    else ((float*)out)[(long)row * N + n] = v;
+  }
+}
+
+int linear_small_m(const bf16_t* X, const bf16_t* W, void* out, int M, int N, int K, const float* res, bool out_bf16,
+                   const bf16_t* A2, const bf16_t* W2, hipStream_t st) {
+  if (M > 32 || K % 32) return TA_ERR_ARG;
+  const bool narrow = N <= 2048;           // few columns: 16 per workgroup keeps >= 64 workgroups streaming
+  const dim3 grid(ta_cdiv(N, narrow ? 16 : 64));
+  if (out_bf16) {
+    if (narrow) TA_LAUNCH((linear_small_m_kernel<true, 1>), grid, dim3(512), 0, st, X, W, out, res, M, N, K, A2, W2);
+    else TA_LAUNCH((linear_small_m_kernel<true, 4>), grid, dim3(512), 0, st, X, W, out, res, M, N, K, A2, W2);
+  } else {
+    if (narrow) TA_LAUNCH((linear_small_m_kernel<false, 1>), grid, dim3(512), 0, st, X, W, out, res, M, N, K, A2, W2);
+    else TA_LAUNCH((linear_small_m_kernel<false, 4>), grid, dim3(512), 0, st, X, W, out, res, M, N, K, A2, W2);
+  }
+  TA_CHECK_LAUNCH();
+  return TA_OK;
 }
 
 struct DecodeWs {
@@ -193,11 +309,21 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
   if (lora) lora_imgs_carve(w, (void*)lora_img, imgs);
   const float scale = 1.0f / sqrtf((float)HD);
   const size_t layer_elems = (size_t)B * Hkv * Lmax * HD;
-  const size_t smem = ((size_t)Lmax + HD + 8 + 256) * sizeof(float);
+  const size_t smem = ((size_t)Lmax + HD + 8 + 16 * HD) * sizeof(float);
   if (smem > 64 * 1024) return TA_ERR_ARG;          // Lmax up to ~16000 cache slots
-  auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g) -> int {
-    RC(ta_i_lora_skinny_nt(x, in, g.a, s.xa, B, st));
-    return ta_gemm_set_k_extension(s.xa, g.b, 64, 64);
+  // one adapted linear: y = x W^T (+ xa Bext^T, xa = x (s Acat)^T) (+ residual); small batches take the K-split
+  // streaming kernel, larger ones the tile GEMM with its K extension
+  const bool small = B <= 32;
+  auto linear = [&](const bf16_t* x, const void* Wm, void* y, int N, int K, const float* res, bool out_bf16,
+                    const LoraImg* g) -> int {
+    const bf16_t *a2 = nullptr, *w2 = nullptr;
+    if (g) {
+      RC(ta_i_lora_skinny_nt(x, K, g->a, s.xa, B, st));
+      a2 = s.xa; w2 = g->b;
+    }
+    if (small) return linear_small_m(x, (const bf16_t*)Wm, y, B, N, K, res, out_bf16, a2, w2, st);
+    if (g) RC(ta_gemm_set_k_extension(a2, w2, 64, 64));
+    return gemm(x, Wm, y, B, N, K, nullptr, res, 0, out_bf16 ? 1 : 0, st);
   };
   RC(ta_embed_scatter(ids, nullptr, w->embed_f32, nullptr, s.x, nullptr, B, D, w->vocab, st));
   for (int l = 0; l < w->n_layers; ++l) {
@@ -205,31 +331,27 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
     bf16_t* kc = (bf16_t*)kcache + (size_t)l * layer_elems;
     bf16_t* vc = (bf16_t*)vcache + (size_t)l * layer_elems;
     RC(ta_rmsnorm_fwd(s.x, Lw.ln_in_w, s.xn, nullptr, s.r, B, D, w->eps, 0, st));
-    if (lora) RC(lora_fwd(s.xn, D, imgs[l].g[0]));
-    RC(gemm(s.xn, Lw.wqkv, s.qkv0, B, NQKV, D, nullptr, nullptr, 0, 1, st));
+    RC(linear(s.xn, Lw.wqkv, s.qkv0, NQKV, D, nullptr, true, lora ? &imgs[l].g[0] : nullptr));
     TA_LAUNCH(lm_qkv_post_decode_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, s.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos,
               w->rope_sin, pos, slot_dev, s.q, kc, vc, Hq, Hkv, Lmax, w->eps);
     TA_CHECK_LAUNCH();
     TA_LAUNCH(attn_decode_kernel, dim3(Hq, B), dim3(256), smem, st, s.q, kc, vc, kmask, slot_dev, s.ao, Hq, Hkv, Lmax, scale);
     TA_CHECK_LAUNCH();
-    if (lora) RC(lora_fwd(s.ao, bq, imgs[l].g[1]));
-    RC(gemm(s.ao, Lw.wo, s.x1, B, D, bq, nullptr, s.x, 0, 0, st));
+    RC(linear(s.ao, Lw.wo, s.x1, D, bq, s.x, false, lora ? &imgs[l].g[1] : nullptr));
     RC(ta_rmsnorm_fwd(s.x1, Lw.ln_post_w, s.xn, nullptr, s.r, B, D, w->eps, 0, st));
-    if (lora) RC(lora_fwd(s.xn, D, imgs[l].g[2]));
-    RC(gemm(s.xn, Lw.wgu, s.gu, B, 2 * F, D, nullptr, nullptr, 0, 1, st));
+    RC(linear(s.xn, Lw.wgu, s.gu, 2 * F, D, nullptr, true, lora ? &imgs[l].g[2] : nullptr));
     RC(ta_swiglu_fwd(s.gu, s.act, B, F, st));
-    if (lora) RC(lora_fwd(s.act, F, imgs[l].g[3]));
-    RC(gemm(s.act, Lw.wd, s.x, B, D, F, nullptr, s.x1, 0, 0, st));
+    RC(linear(s.act, Lw.wd, s.x, D, F, s.x1, false, lora ? &imgs[l].g[3] : nullptr));
   }
   RC(ta_rmsnorm_fwd(s.x, w->norm_w, s.hn, nullptr, s.r, B, D, w->eps, 0, st));
-  RC(gemm(s.hn, w->embed_bf16, logits, B, w->vocab_pad, D, nullptr, nullptr, 0, 0, st));
+  RC(linear(s.hn, w->embed_bf16, logits, w->vocab_pad, D, nullptr, false, nullptr));
   return TA_OK;
 }
 
 extern "C" int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out, hipStream_t st) {
   if (rows <= 0) return TA_OK;
   if (n <= 0) return TA_ERR_ARG;
-  TA_LAUNCH(argmax_rows_kernel, dim3(rows), dim3(256), 0, st, x, ld, n, out);
+  TA_LAUNCH(argmax_rows_kernel, dim3(rows), dim3(1024), 0, st, x, ld, n, out);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -300,7 +301,7 @@ class Qwen3MI355X(torch.nn.Module):
     # ------------------------------------------------------------------ greedy decoding
     @torch.no_grad()
     def greedy_decode(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
-                      sync_every=8):
+                      sync_every=8, use_graph=True):
         """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
         config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
         emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
@@ -357,13 +358,31 @@ class Qwen3MI355X(torch.nn.Module):
                                     ptr(kc), ptr(vc), Lmax, ptr(last_rows), ptr(logits), ptr(lora_img), ptr(ws), ws.numel(),
                                     stream()), "ta_lm_prefill")
         advance()
-        for t in range(1, max_new):
-            if t % sync_every == 0 and int(alive.item()) == 0:
-                break
+
+        def step():
             _lib.check(L_.ta_lm_decode_step(C.byref(self._w), ptr(next_ids), ptr(pos), ptr(kmask), ptr(slot_dev), B, ptr(kc),
                                             ptr(vc), Lmax, ptr(logits), ptr(lora_img), ptr(ws), ws.numel(), stream()),
                        "ta_lm_decode_step")
             advance()
+
+        # A decode step is ~340 tiny launches whose arguments never change (all per-step state is device-resident):
+        # run the first one eagerly, capture the second into a hipGraph, replay it for the rest.
+        graph = None
+        want_graph = (use_graph and dev.type == "cuda" and not _lib.DRY_RUN and max_new > 3
+                      and os.environ.get("TA355_DECODE_GRAPH", "1") != "0")
+        for t in range(1, max_new):
+            if t % sync_every == 0 and int(alive.item()) == 0:
+                break
+            if graph is not None:
+                graph.replay()
+            elif want_graph and t == 2:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step()
+                graph.replay()                      # capture records, it does not run
+            else:
+                step()
         seq = out_seq.cpu()
         # HF stops right after the step in which the last clip finished: trim the surplus (all-pad) columns
         n_new = max_new
