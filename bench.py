@@ -137,23 +137,28 @@ def main():
     value = world * B * 10.0 * a.steps / dt
 
     roofline = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
+        # EVERY rank runs the two extra (untimed) steps -- they contain the gradient all-reduce -- but only rank 0
+        # records: HIP events around each GEMM launch on the launch stream (csrc/gemm.hip: ta_profile_gemm).
         import ctypes as C
         lib = _lib.lib()
-        lib.ta_profile_gemm(1)
+        if rank == 0:
+            lib.ta_profile_gemm(1)
         for _ in range(2):
             step()
-        torch.cuda.synchronize()
-        lib.ta_profile_gemm(0)
-        tms, tfl, nl = C.c_double(), C.c_double(), C.c_long()
-        lib.ta_profile_gemm_collect(C.byref(tms), C.byref(tfl), C.byref(nl))
-        achieved = tfl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
-        roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogue variants)", "bound": "mfma",
-                    "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": nl.value // 2, "avg_launch_us": round(tms.value * 1e3 / max(nl.value, 1), 2),
-                    "gemm_ms_per_step": round(tms.value / 2, 3),
-                    "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3)}
+        barrier()
+        if rank == 0:
+            lib.ta_profile_gemm(0)
+            tms, tfl, nl = C.c_double(), C.c_double(), C.c_long()
+            lib.ta_profile_gemm_collect(C.byref(tms), C.byref(tfl), C.byref(nl))
+            achieved = tfl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
+            roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all tile / epilogue variants)", "bound": "mfma",
+                        "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": nl.value // 2, "avg_launch_us": round(tms.value * 1e3 / max(nl.value, 1), 2),
+                        "gemm_ms_per_step": round(tms.value / 2, 3),
+                        "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3),
+                        "hbm_kernels": hbm_kernel_rates(B, L, cfg, fe, wav, lens)}
 
     cpu = None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora:
@@ -178,6 +183,38 @@ def main():
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
+    """Achieved GB/s of the HBM-bound kernels of the step (north_star: feature / norm kernels against the HBM
+    roofline), each timed over 20 launches with events on the launch stream; bytes are ALGORITHMIC."""
+    import torch
+    from tiny_audio_amd import ops
+    dev = wav.device
+    PEAK = 8000.0
+
+    def rate(fn, nbytes, reps=20):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(b) / reps * 1e3
+        return {"avg_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1), "peak": PEAK, "unit": "GB/s",
+                "frac": round(nbytes / us / 1e3 / PEAK, 4), "algorithmic_mb": round(nbytes / 1e6, 2)}
+
+    Me, H = B * 500, cfg.audio_config.hidden_size
+    Ml, D, F = B * L, cfg.text_config.hidden_size, cfg.text_config.intermediate_size
+    xe = torch.randn(Me, H, device=dev); we, be = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    xl = torch.randn(Ml, D, device=dev); wl = torch.ones(D, device=dev)
+    gu = torch.randn(Ml, 2 * F, device=dev).to(torch.bfloat16)
+    out = {"layernorm_kernel (encoder, f32 in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 6),
+           "rmsnorm_fwd_kernel (LM, f32 in -> bf16 out)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 6),
+           "swiglu_fwd_kernel (LM, bf16 gate|up -> bf16)": rate(lambda: ops.swiglu_fwd(gu, F), Ml * F * 6),
+           "logmel (f32 wav -> f32 [128, 1000]; exact-f32 DFT, VALU-bound)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000), reps=5)}
+    return out
 
 
 def cpu_baseline(model, cfg, L):
