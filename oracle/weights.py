@@ -132,6 +132,32 @@ def init_moe_projector(enc_dim, llm_dim, hidden=None, k=4, num_experts=4, seed=3
     return w
 
 
+def init_qformer_projector(enc_dim, llm_dim, hidden=None, layers=2, ffn=None, nq=3, seed=5):
+    """tiny_audio/projectors.py:359-420: query ~ N(0, 1); Blip2QFormerModel weights N(0, 0.02) (initializer_range),
+    LayerNorm 1 / 0 (perturbed here so that the affine gradients are exercised), final Linear default-uniform."""
+    rng = np.random.RandomState(seed)
+    H = hidden or enc_dim
+    F = ffn or 4 * H
+    n = lambda *s: (0.02 * rng.standard_normal(s)).astype(np.float32)
+    w = {"query": rng.standard_normal((1, nq, H)).astype(np.float32),
+         "qformer.layernorm.weight": _vec(rng, H, 1.0, 0.05), "qformer.layernorm.bias": _vec(rng, H, 0.0, 0.05)}
+    if enc_dim != H:
+        w["encoder_proj.weight"] = rng.uniform(-1, 1, size=(H, enc_dim)).astype(np.float32) / np.float32(np.sqrt(enc_dim))
+    for i in range(layers):
+        p = f"qformer.encoder.layer.{i}."
+        for att in ("attention.", "crossattention."):
+            for m in ("query", "key", "value"):
+                w[p + att + f"attention.{m}.weight"] = n(H, H); w[p + att + f"attention.{m}.bias"] = n(H)
+            w[p + att + "output.dense.weight"] = n(H, H); w[p + att + "output.dense.bias"] = n(H)
+            w[p + att + "output.LayerNorm.weight"] = _vec(rng, H, 1.0, 0.05); w[p + att + "output.LayerNorm.bias"] = _vec(rng, H, 0.0, 0.05)
+        w[p + "intermediate_query.dense.weight"] = n(F, H); w[p + "intermediate_query.dense.bias"] = n(F)
+        w[p + "output_query.dense.weight"] = n(H, F); w[p + "output_query.dense.bias"] = n(H)
+        w[p + "output_query.LayerNorm.weight"] = _vec(rng, H, 1.0, 0.05); w[p + "output_query.LayerNorm.bias"] = _vec(rng, H, 0.0, 0.05)
+    w["linear.weight"] = rng.uniform(-1, 1, size=(llm_dim, H)).astype(np.float32) / np.float32(np.sqrt(H))
+    w["linear.bias"] = rng.uniform(-1, 1, size=llm_dim).astype(np.float32) / np.float32(np.sqrt(H))
+    return w
+
+
 def init_lora(cfg, rank=8, seed=4, b_std=0.02):
     """LoRA adapters on q,k,v,o,gate,up,down of every layer (tiny_audio/asr_config.py:142-150, r=8).  peft initialises
     lora_A kaiming-uniform and lora_B = 0; B is given small random values here so that parity is non-trivial."""

@@ -292,6 +292,32 @@ def gen_asr():
          **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters()})
 
 
+# ----------------------------------------------------------------------------- 3b. QFormer projector (section 8(f) rank 4)
+def gen_qformer():
+    """QFormerAudioProjector of the reference (eval mode: its 0.1 dropouts are RNG) with seeded weights: output and
+    the gradient of every parameter for a fixed upstream gradient."""
+    from tiny_audio.projectors import QFormerAudioProjector
+    from tests.golden.recipe import QF, qformer_input
+    E, D = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"]
+    cfg = SimpleNamespace(encoder_dim=E, llm_dim=D, qformer_window_size=QF["window"], downsample_rate=QF["downsample"],
+                          qformer_hidden_size=None, qformer_num_layers=QF["layers"], qformer_num_heads=QF["heads"],
+                          qformer_intermediate_size=QF["ffn"])
+    m = QFormerAudioProjector(cfg).float()
+    wq = OW.init_qformer_projector(E, D, layers=QF["layers"], ffn=QF["ffn"])
+    missing, unexpected = m.load_state_dict({k: t(v) for k, v in wq.items()}, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.eval()
+    x, dy = qformer_input()
+    assert m.get_output_length(x.shape[1]) == dy.shape[1]
+    y = m(t(x))
+    (y * t(dy)).sum().backward()
+    mats = ("layer.0.attention.attention.query.weight", "layer.0.crossattention.attention.key.weight",
+            "layer.1.crossattention.attention.value.weight", "layer.1.attention.output.dense.weight",
+            "layer.1.output_query.dense.weight", "layer.0.intermediate_query.dense.weight", "linear.weight")
+    save("projector_qformer.npz", y=y.detach().numpy(), n_params=np.array(sum(p.numel() for p in m.parameters())),
+         **{"g." + k: p.grad.numpy() for k, p in m.named_parameters() if p.ndim != 2 or k.endswith(mats)})
+
+
 # ----------------------------------------------------------------------------- 6b. greedy generation (section 8(f) rank 1)
 def gen_generate():
     """ASRModel.generate of the reference (HF GenerationMixin greedy search with a DynamicCache) on the reduced
@@ -366,7 +392,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "qformer": gen_qformer, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

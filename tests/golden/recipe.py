@@ -83,3 +83,15 @@ def gen_lm_weights():
         if k.endswith("o_proj.weight") or k.endswith("down_proj.weight"):
             w[k] = (w[k] * np.float32(GEN_BOOST)).astype(np.float32)
     return w
+
+
+QF = dict(heads=4, layers=2, window=15, downsample=5, eps=1e-12, ffn=512)       # reduced QFormer (hidden = encoder dim 256)
+
+
+def qformer_input(B=2, S=50, seed=31):
+    """S = 50 is not a multiple of the window (15): the last window is zero padded, as for the real S = 500."""
+    E, D = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"]
+    x = np.random.RandomState(seed).standard_normal((B, S, E)).astype(np.float32)
+    n_out = (S + 14) // 15 * 3
+    dy = np.random.RandomState(seed + 1).standard_normal((B, n_out, D)).astype(np.float32)
+    return x, dy

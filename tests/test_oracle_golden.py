@@ -147,6 +147,31 @@ def test_qwen3_lora_grads(golden):
         assert relerr(grads[k], g["g." + k]) < 2e-4, k
 
 
+def test_qformer_projector(golden):
+    """Section 8(f) rank 4: QFormer projector forward + every parameter gradient vs the reference module (eval mode)."""
+    from oracle import qformer as OQF
+    g = golden("projector_qformer.npz")
+    E, D = R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"]
+    w = OW.init_qformer_projector(E, D, layers=R.QF["layers"], ffn=R.QF["ffn"])
+    assert sum(v.size for v in w.values()) == int(g["n_params"])
+    x, dy = R.qformer_input()
+    y, c = OQF.qformer_forward(x, w, R.QF)
+    assert y.shape == dy.shape == (2, OQF.output_length(50), D) and OQF.output_length(500) == 102
+    assert relerr(y, g["y"]) < 2e-5
+    grads = OQF.qformer_backward(dy, w, R.QF, c)
+    keys = [k[2:] for k in g.files if k.startswith("g.")]
+    assert set(w) == set(grads) and set(keys) <= set(w) and len(keys) > 40
+    for k in keys:
+        if k.endswith("key.bias"):               # softmax is invariant to a per-query constant: the gradient is exactly 0
+            assert np.abs(grads[k]).max() < 1e-6 and np.abs(g["g." + k]).max() < 1e-6, k
+        else:
+            assert relerr(grads[k], g["g." + k]) < 2e-4, k
+    # dropout algebra: all-ones keep masks are the identity; a zero mask on the last FFN output kills that branch
+    ones = {k: np.float32(1.0) for k in ("emb", "l0.sa", "l0.sa_p", "l0.ca", "l0.ca_p", "l0.ffn", "l1.ffn")}
+    y1, _ = OQF.qformer_forward(x, w, R.QF, keeps=ones)
+    np.testing.assert_allclose(y1, y, atol=1e-6)
+
+
 def test_greedy_generate(golden):
     """Section 8(f) rank 1: token-exact against ASRModel.generate of the reference (HF greedy search + KV cache),
     including EOS stop and pad fill for the clip that finishes first."""
