@@ -39,7 +39,7 @@ def parse():
                     help="'full' additionally materialises outputs.logits [B, L, V] (bf16) every step as the reference does; "
                          "'labelled' computes the loss head only on label positions (identical loss and gradients)")
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
-    ap.add_argument("--projector", choices=["mlp", "moe"], default="mlp",
+    ap.add_argument("--projector", choices=["mlp", "moe", "qformer"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
     ap.add_argument("--lora", action="store_true",
                     help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
@@ -93,7 +93,8 @@ def main():
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     wav = 0.1 * torch.randn(B, 160000, device=dev, generator=g)
     lens = torch.full((B,), 160000, device=dev, dtype=torch.int64)
-    ids, att, lab, counts = OW.synthetic_tokens(B, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    n_audio = int(model.projector.get_output_length(500))         # 125 for the frame-stacking projectors, 102 for the QFormer
+    ids, att, lab, counts = OW.synthetic_tokens(B, n_audio, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
     ids_d, att_d, lab_d = (torch.from_numpy(x).to(dev) for x in (ids, att, lab))
     counts_d = torch.from_numpy(counts).to(dev)
     from tiny_audio_amd import ops
@@ -172,6 +173,7 @@ def main():
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
                "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
                                        else "configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
+                                       "QFormer projector (2 layers, 16 heads, windows of 15 -> 3 queries, 102 audio tokens)" if a.projector == "qformer" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
                                       " bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
                                       "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,

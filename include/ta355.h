@@ -169,6 +169,29 @@ int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_r
                        const int* kmask, const int* pos, int B, int L, const int* label_rows,
                        const long* label_targets, int n_label_rows, float loss_scale, float* loss,
                        float* nll_rows, void* logits_out, void* tape, void* ws, long ws_bytes, hipStream_t st);
+/* ---- primitives of the trainable transformer-style projectors (QFormer / MOSA, SURVEY.md section 8(f) rank 4;
+ * tiny_audio/projectors.py:88-182,359-475 over TF:models/blip_2/modeling_blip_2.py Blip2QFormer*).  The linears are
+ * ta_gemm_bf16_nt; these are the pieces around them. */
+int ta_gelu_fwd(const void* h_bf16, void* a_bf16, long n, hipStream_t st);                     /* nn.GELU (erf) */
+int ta_gelu_bwd(const void* da_bf16, const void* h_bf16, void* dh_bf16, long n, hipStream_t st);
+int ta_colsum(const void* x, int is_f32, int R, int C, float* out, hipStream_t st);           /* out[c] = sum_r x[r,c]: bias grads */
+/* y = LayerNorm(z * keep + res[row % res_rows]) (keep: dropout mask already divided by 1-p, or NULL; res optional);
+ * saves xhat [M,H] and rstd [M] for ta_layernorm_bwd.  Blip2QFormerSelfOutput / Output: dense -> dropout -> +res -> LN. */
+int ta_layernorm_res_fwd(const float* z, const float* keep, const float* res, long res_rows, const float* gamma,
+                         const float* beta, float eps, float* xhat, float* rstd, float* y_f32, void* y_bf16, int M, int H,
+                         hipStream_t st);
+/* du (f32, gradient of the LN input = residual branch) and dz = du * keep (bf16, dense branch) are optional;
+ * dgamma / dbeta are ACCUMULATED. */
+int ta_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* keep, float* du,
+                     void* dz_bf16, float* dgamma, float* dbeta, int M, int H, hipStream_t st);
+/* Windowed multi-head attention (Blip2QFormerMultiHeadAttention, eager): EB windows, Q bf16 [EB*Lq, heads*hd],
+ * K / V bf16 [EB*Lk, heads*hd]; P f32 [EB, heads, Lq, Lk] = softmax probabilities (saved); keep = attention-probs
+ * dropout mask / (1-p) or NULL; O bf16 [EB*Lq, heads*hd]. */
+int ta_attn_small_fwd(const void* Q, const void* K, const void* V, int EB, int heads, int hd, int Lq, int Lk, float scale,
+                      const float* keep, float* P, void* O, hipStream_t st);
+int ta_attn_small_bwd(const void* dO, const void* Q, const void* K, const void* V, const float* P, const float* keep,
+                      float scale, void* dQ, void* dK, void* dV, int EB, int heads, int hd, int Lq, int Lk, hipStream_t st);
+
 /* ---- greedy decoding: ASRModel.generate, tiny_audio/asr_modeling.py:562-646, which
  * drives HF GenerationMixin greedy search (num_beams 1, do_sample False: tiny_audio/asr_config.py:103-111) with a KV cache.
  * kcache / vcache: bf16 [n_layers, B, kv_heads, Lmax, head_dim], owned by the caller.  lora_img: scratch of

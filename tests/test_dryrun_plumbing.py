@@ -142,6 +142,37 @@ def test_lora_stage2_plumbing(dry):
         ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16), device="cpu", init="none")
 
 
+def test_qformer_plumbing(dry):
+    """Section 8(f) rank 4: the QFormer projector inside ASRModel -- reference parameter names / count, 102 audio tokens for
+    500 encoder frames, one full forward + backward + optimizer step through the primitive wrappers."""
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    full = ASRModel(ASRConfig(projector_type="qformer"), device="cpu", init="none")
+    assert sum(p.numel() for p in full.projector.parameters()) == 53_795_584
+    assert set(full.projector.state_dict()) == set(OW.init_qformer_projector(1280, 1024))
+    assert full.projector.get_output_length(500) == 102 and full.projector.get_output_length(torch.tensor([500, 15, 16])).tolist() == [102, 3, 6]
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=1, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_type="qformer", qformer_num_heads=4, qformer_intermediate_size=512,
+                    audio_token_id=999)
+    m = ASRModel(cfg, device="cpu", init="random")
+    n_tok = m.projector.get_output_length(50)                       # T = 100 mel frames -> S = 50 -> 4 windows -> 12 tokens
+    assert n_tok == 12
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts),
+                 label_meta=(torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22))
+    m.train()
+    tr = ASRTrainer(m, TrainingArguments())
+    tr.training_step(batch)
+    assert tr.global_step == 1
+    for must in ("ta_layernorm_res_fwd", "ta_layernorm_bwd", "ta_attn_small_fwd", "ta_attn_small_bwd", "ta_gelu_fwd", "ta_gelu_bwd",
+                 "ta_colsum", "ta_bernoulli_keep"):
+        assert must in dry.calls, must
+    for n, p in m.projector.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+
+
 def test_generate_plumbing(dry):
     """Section 8(f) rank 1: the argument marshalling of prefill / decode step / greedy bookkeeping, the reference's
     error behaviour, and the trim of surplus columns (nothing is computed under DRY_RUN: every token is 0)."""

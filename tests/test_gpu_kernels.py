@@ -396,3 +396,58 @@ def test_logmel_vs_oracle(golden):
     out = fe([R.OW.synthetic_wave(3, 16000 + 77)], sampling_rate=16000)
     np.testing.assert_array_equal(out["attention_mask"].cpu().numpy(), g["mask_odd"])
     assert np.abs(out["input_features"].cpu().numpy() - g["feats_odd"]).max() < 5e-4
+
+
+# ----------------------------------------------------------------------------- trainable-projector primitives (nn_prims.hip)
+def test_gelu_colsum():
+    h = rnd(300, 512, seed=1, dtype=BF16)
+    a = ops.gelu_fwd(h)
+    assert relerr(a, torch.nn.functional.gelu(h.float())) < 1e-2
+    da = rnd(300, 512, seed=2, dtype=BF16)
+    hf = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hf).backward(da.float())
+    assert relerr(ops.gelu_bwd(da, h), hf.grad) < 1.5e-2
+    x = rnd(5000, 300, seed=3)
+    assert relerr(ops.colsum(x), x.sum(0)) < 1e-5
+    assert relerr(ops.colsum(x.to(BF16)), x.to(BF16).float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("H", [256, 1280])
+def test_layernorm_res_fwd_bwd(H):
+    M = 333
+    z, res = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    keep = (torch.rand(M, H, generator=torch.Generator().manual_seed(3)) < 0.9).float().to(DEV) / 0.9
+    gamma, beta = 1 + 0.1 * rnd(H, seed=4), 0.1 * rnd(H, seed=5)
+    for kp, rs in ((None, None), (keep, res)):
+        zt = z.clone().requires_grad_(True); gt = gamma.clone().requires_grad_(True); bt = beta.clone().requires_grad_(True)
+        u = zt * (kp if kp is not None else 1.0) + (rs if rs is not None else 0.0)
+        ref = torch.nn.functional.layer_norm(u, (H,), gt, bt, 1e-12)
+        yf, yb, xhat, rstd = ops.layernorm_res_fwd(z, gamma, beta, 1e-12, res=rs, keep=kp)
+        assert relerr(yf, ref) < 1e-5 and relerr(yb, ref) < 1e-2
+        dy = rnd(M, H, seed=6)
+        ref.backward(dy)
+        dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        du, dz = ops.layernorm_bwd(dy, xhat, rstd, gamma, dg, db, keep=kp)
+        assert relerr(dz, zt.grad) < 1e-2                                   # bf16 output
+        assert relerr(dg, gt.grad) < 1e-4 and relerr(db, bt.grad) < 1e-4
+        if rs is not None:
+            assert relerr(du * kp, zt.grad) < 1e-4
+
+
+@pytest.mark.parametrize("heads,hd,Lq,Lk", [(16, 80, 3, 15), (16, 80, 3, 3), (4, 64, 3, 15)])
+def test_attn_small_fwd_bwd(heads, hd, Lq, Lk):
+    EB, H = 37, heads * hd
+    q, k, v = rnd(EB * Lq, H, seed=1, dtype=BF16), rnd(EB * Lk, H, seed=2, dtype=BF16), rnd(EB * Lk, H, seed=3, dtype=BF16)
+    keep = (torch.rand(EB, heads, Lq, Lk, generator=torch.Generator().manual_seed(4)) < 0.9).float().to(DEV) / 0.9
+    scale = hd ** -0.5
+    for kp in (None, keep):
+        qt, kt, vt = (t.float().requires_grad_(True) for t in (q, k, v))
+        sh = lambda t, L: t.reshape(EB, L, heads, hd).transpose(1, 2)
+        pr = torch.softmax(sh(qt, Lq) @ sh(kt, Lk).transpose(-1, -2) * scale, -1)
+        o_ref = ((pr * kp if kp is not None else pr) @ sh(vt, Lk)).transpose(1, 2).reshape(EB * Lq, H)
+        O, P = ops.attn_small_fwd(q, k, v, EB, heads, Lq, Lk, scale, kp)
+        assert relerr(P, pr) < 1e-4 and relerr(O, o_ref) < 1e-2
+        do = rnd(EB * Lq, H, seed=5, dtype=BF16)
+        o_ref.backward(do.float())
+        dQ, dK, dV = ops.attn_small_bwd(do, q, k, v, P, EB, heads, Lq, Lk, scale, kp)
+        assert relerr(dQ, qt.grad) < 1.5e-2 and relerr(dK, kt.grad) < 1.5e-2 and relerr(dV, vt.grad) < 1.5e-2

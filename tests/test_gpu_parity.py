@@ -341,6 +341,65 @@ def test_lora_zero_b_is_identity_and_stage2_trains():
     assert all(p.grad is None or not p.requires_grad for p in m.projector.parameters())
 
 
+# ============================================================================ QFormer projector (section 8(f) rank 4)
+def _qformer_case(E, D, cfgq, x, dy, hidden_kw, keeps_np=None):
+    from oracle import qformer as OQF
+    from tiny_audio_amd.qformer_projector import QFormerAudioProjector
+    w = OW.init_qformer_projector(E, D, layers=cfgq["layers"], ffn=cfgq["ffn"])
+    cfg = ASRConfig(audio_config=dict(hidden=E, ffn=2 * E, layers=1, heads=E // 64), text_config=dict(hidden=D, ffn=2 * D, layers=1, heads=4, kv_heads=2, vocab=512),
+                    projector_type="qformer", qformer_num_heads=cfgq["heads"], qformer_num_layers=cfgq["layers"],
+                    qformer_intermediate_size=cfgq["ffn"], **hidden_kw)
+    m = QFormerAudioProjector(cfg).to(DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m.eval()
+    keeps_t = None if keeps_np is None else {k: torch.from_numpy(np.broadcast_to(v, v.shape).copy()).to(DEV) for k, v in keeps_np.items()}
+    y = m(torch.from_numpy(x).to(DEV), keeps=keeps_t or {})
+    ref, c = OQF.qformer_forward(x, w, cfgq, keeps=keeps_np)
+    assert y.shape == ref.shape and relmax(npy(y), ref) < 2e-2 and cosine(npy(y), ref) > 0.9995
+    (y * torch.from_numpy(dy).to(DEV)).sum().backward()
+    grads = OQF.qformer_backward(dy, w, cfgq, c)
+    for k, p_ in m.named_parameters():
+        if k.endswith("key.bias"):                     # mathematically zero (softmax shift invariance): compare to the scale of its siblings
+            assert np.abs(npy(p_.grad)).max() < 2e-2 * np.abs(grads[k.replace("key.bias", "value.bias")]).max(), k
+        else:
+            assert cosine(npy(p_.grad), grads[k]) > 0.995, k
+            assert relmax(npy(p_.grad), grads[k]) < 8e-2, k
+    return m
+
+
+def test_qformer_projector_vs_golden_config(golden):
+    g = golden("projector_qformer.npz")
+    x, dy = R.qformer_input()
+    E, D = R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"]
+    m = _qformer_case(E, D, R.QF, x, dy, {})
+    assert relmax(npy(m(torch.from_numpy(x).to(DEV), keeps={})), g["y"]) < 2e-2
+    for k in [k[2:] for k in g.files if k.startswith("g.") and not k.endswith("key.bias")]:
+        assert cosine(npy(dict(m.named_parameters())[k].grad), g["g." + k]) > 0.995, k
+
+
+def test_qformer_projector_true_width_with_dropout_masks():
+    """True widths (hidden 1280, 16 heads of 80, FFN 5120, S = 500 -> 34 windows -> 102 tokens per clip), one layer, with
+    injected dropout keep masks at every site (the train-mode algebra); then the train-mode RNG path just has to run
+    and give a different, finite output."""
+    from oracle import qformer as OQF
+    cfgq = dict(heads=16, layers=1, window=15, downsample=5, eps=1e-12, ffn=5120)
+    rng = np.random.RandomState(2)
+    B, S = 1, 500
+    x = rng.standard_normal((B, S, 1280)).astype(np.float32)
+    dy = rng.standard_normal((B, 102, 1024)).astype(np.float32)
+    EB, M = 34, 102
+    mk = lambda *s: ((rng.rand(*s) < 0.9) / 0.9).astype(np.float32)
+    keeps = {"emb": mk(M, 1280).reshape(EB, 3, 1280), "l0.sa": mk(M, 1280).reshape(EB, 3, 1280), "l0.ca": mk(M, 1280).reshape(EB, 3, 1280),
+             "l0.ffn": mk(M, 1280).reshape(EB, 3, 1280), "l0.sa_p": mk(EB, 16, 3, 3), "l0.ca_p": mk(EB, 16, 3, 15)}
+    m = _qformer_case(1280, 1024, cfgq, x, dy, {}, keeps_np=keeps)
+    assert m.get_output_length(500) == 102 == OQF.output_length(500)
+    m.train()
+    y1, y2 = m(torch.from_numpy(x).to(DEV)), m(torch.from_numpy(x).to(DEV))
+    assert torch.isfinite(y1).all() and not torch.equal(y1, y2)
+    m.eval()
+    assert torch.equal(m(torch.from_numpy(x).to(DEV)), m(torch.from_numpy(x).to(DEV)))
+
+
 # ============================================================================ greedy generation (section 8(f) rank 1)
 def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12):
     """Greedy parity that is robust to bf16 near-ties: feed the HIP path's OWN tokens to the fp32 oracle and require

@@ -224,3 +224,68 @@ def grad_sqnorm(g, accum):
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_norm=0.0, grad_scale=1.0, denom=None):
     check(lib().ta_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, ptr(sqnorm),
                               max_norm, grad_scale, ptr(denom), stream()), "ta_adamw_step")
+
+
+# ----------------------------------------------------------------------------- trainable-projector primitives (nn_prims.hip)
+def gelu_fwd(h):
+    _req(h, BF16)
+    a = torch.empty_like(h)
+    check(lib().ta_gelu_fwd(ptr(h), ptr(a), h.numel(), stream()), "ta_gelu_fwd")
+    return a
+
+
+def gelu_bwd(da, h):
+    _req(da, BF16); _req(h, BF16)
+    dh = torch.empty_like(h)
+    check(lib().ta_gelu_bwd(ptr(da), ptr(h), ptr(dh), h.numel(), stream()), "ta_gelu_bwd")
+    return dh
+
+
+def colsum(x):
+    """[R, C] (f32 or bf16) -> f32 [C]"""
+    R, Cc = x.shape
+    out = torch.empty(Cc, device=x.device, dtype=F32)
+    check(lib().ta_colsum(ptr(x), int(x.dtype == F32), R, Cc, ptr(out), stream()), "ta_colsum")
+    return out
+
+
+def layernorm_res_fwd(z, gamma, beta, eps, res=None, keep=None, res_rows=0):
+    """-> (y f32, y bf16, xhat, rstd)"""
+    _req(z, F32)
+    M, H = z.shape
+    yf = torch.empty_like(z)
+    yb = torch.empty((M, H), device=z.device, dtype=BF16)
+    xhat, rstd = torch.empty_like(z), torch.empty(M, device=z.device, dtype=F32)
+    check(lib().ta_layernorm_res_fwd(ptr(z), ptr(keep), ptr(res), res_rows, ptr(gamma), ptr(beta), eps, ptr(xhat), ptr(rstd),
+                                     ptr(yf), ptr(yb), M, H, stream()), "ta_layernorm_res_fwd")
+    return yf, yb, xhat, rstd
+
+
+def layernorm_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, keep=None, want_du=True, want_dz=True):
+    """-> (du f32 or None, dz bf16 or None); dgamma / dbeta accumulate."""
+    _req(dy, F32)
+    M, H = dy.shape
+    du = torch.empty_like(dy) if want_du else None
+    dz = torch.empty((M, H), device=dy.device, dtype=BF16) if want_dz else None
+    check(lib().ta_layernorm_bwd(ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), ptr(keep), ptr(du), ptr(dz), ptr(dgamma),
+                                 ptr(dbeta), M, H, stream()), "ta_layernorm_bwd")
+    return du, dz
+
+
+def attn_small_fwd(Q, K, V, EB, heads, Lq, Lk, scale, keep=None):
+    _req(Q, BF16); _req(K, BF16); _req(V, BF16)
+    H = Q.shape[-1]
+    P = torch.empty((EB, heads, Lq, Lk), device=Q.device, dtype=F32)
+    O = torch.empty((EB * Lq, H), device=Q.device, dtype=BF16)
+    check(lib().ta_attn_small_fwd(ptr(Q), ptr(K), ptr(V), EB, heads, H // heads, Lq, Lk, scale, ptr(keep), ptr(P), ptr(O),
+                                  stream()), "ta_attn_small_fwd")
+    return O, P
+
+
+def attn_small_bwd(dO, Q, K, V, P, EB, heads, Lq, Lk, scale, keep=None):
+    _req(dO, BF16)
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    H = Q.shape[-1]
+    check(lib().ta_attn_small_bwd(ptr(dO), ptr(Q), ptr(K), ptr(V), ptr(P), ptr(keep), scale, ptr(dQ), ptr(dK), ptr(dV), EB,
+                                  heads, H // heads, Lq, Lk, stream()), "ta_attn_small_bwd")
+    return dQ, dK, dV

@@ -259,4 +259,6 @@ class MoEAudioProjector(nn.Module):
         return y
 
 
-PROJECTOR_CLASSES = {"mlp": MLPAudioProjector, "moe": MoEAudioProjector}
+from .qformer_projector import QFormerAudioProjector  # noqa: E402
+
+PROJECTOR_CLASSES = {"mlp": MLPAudioProjector, "moe": MoEAudioProjector, "qformer": QFormerAudioProjector}
