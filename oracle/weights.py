@@ -132,6 +132,20 @@ def init_moe_projector(enc_dim, llm_dim, hidden=None, k=4, num_experts=4, seed=3
     return w
 
 
+def init_mosa_projector(enc_dim, llm_dim, num_experts=4, adapter_hidden=4096, router_hidden=512, seed=6):
+    """tiny_audio/projectors.py:100-150 (torch default inits: uniform(+-1/sqrt(fan_in)) weights and biases)."""
+    rng = np.random.RandomState(seed)
+    u = lambda fan_in, *s: (rng.uniform(-1, 1, size=s) / np.sqrt(fan_in)).astype(np.float32)
+    w = {"downsampler.0.weight": u(3 * enc_dim, enc_dim, enc_dim, 3), "downsampler.0.bias": u(3 * enc_dim, enc_dim),
+         "downsampler.2.weight": u(3 * enc_dim, llm_dim, enc_dim, 3), "downsampler.2.bias": u(3 * enc_dim, llm_dim),
+         "router.0.weight": u(llm_dim, router_hidden, llm_dim), "router.0.bias": u(llm_dim, router_hidden),
+         "router.2.weight": u(router_hidden, num_experts, router_hidden), "router.2.bias": u(router_hidden, num_experts)}
+    for e in range(num_experts):
+        w[f"experts.{e}.fc1.weight"] = u(llm_dim, adapter_hidden, llm_dim); w[f"experts.{e}.fc1.bias"] = u(llm_dim, adapter_hidden)
+        w[f"experts.{e}.fc2.weight"] = u(adapter_hidden, llm_dim, adapter_hidden); w[f"experts.{e}.fc2.bias"] = u(adapter_hidden, llm_dim)
+    return w
+
+
 def init_qformer_projector(enc_dim, llm_dim, hidden=None, layers=2, ffn=None, nq=3, seed=5):
     """tiny_audio/projectors.py:359-420: query ~ N(0, 1); Blip2QFormerModel weights N(0, 0.02) (initializer_range),
     LayerNorm 1 / 0 (perturbed here so that the affine gradients are exercised), final Linear default-uniform."""

@@ -318,6 +318,27 @@ def gen_qformer():
          **{"g." + k: p.grad.numpy() for k, p in m.named_parameters() if p.ndim != 2 or k.endswith(mats)})
 
 
+# ----------------------------------------------------------------------------- 3c. MOSA projector (section 8(f) rank 4)
+def gen_mosa():
+    from tiny_audio.projectors import MOSAProjector
+    E, D = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"]
+    m = MOSAProjector(SimpleNamespace(encoder_dim=E, llm_dim=D, num_experts=4)).float()
+    w = OW.init_mosa_projector(E, D)
+    m.load_state_dict({k: t(v) for k, v in w.items()})
+    x, _ = proj_input()                                            # [2, 50, E]
+    n = m.get_output_length(x.shape[1])
+    dy = np.random.RandomState(41).standard_normal((x.shape[0], n, D)).astype(np.float32)
+    y = m(t(x))
+    (y * t(dy)).sum().backward()
+    keep = lambda k, p_: p_.ndim == 1 or k.startswith(("router.", "downsampler.2"))
+    P = dict(m.named_parameters())
+    save("projector_mosa.npz", y=y.detach().numpy(), dy=dy, n_params=np.array(sum(p_.numel() for p_ in m.parameters())),
+         rows64_experts_2_fc1_weight=P["experts.2.fc1.weight"].grad.numpy()[:64],
+         cols64_experts_1_fc2_weight=P["experts.1.fc2.weight"].grad.numpy()[:, :64],
+         rows32_downsampler_0_weight=P["downsampler.0.weight"].grad.numpy()[:32],
+         **{"g." + k: p_.grad.numpy() for k, p_ in P.items() if keep(k, p_)})
+
+
 # ----------------------------------------------------------------------------- 6b. greedy generation (section 8(f) rank 1)
 def gen_generate():
     """ASRModel.generate of the reference (HF GenerationMixin greedy search with a DynamicCache) on the reduced
@@ -392,7 +413,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "qformer": gen_qformer, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

@@ -172,6 +172,26 @@ def test_qformer_projector(golden):
     np.testing.assert_allclose(y1, y, atol=1e-6)
 
 
+def test_mosa_projector(golden):
+    """Section 8(f) rank 4: MOSA projector forward + parameter gradients vs the reference module."""
+    from oracle import mosa as OMS
+    g = golden("projector_mosa.npz")
+    E, D = R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"]
+    w = OW.init_mosa_projector(E, D)
+    assert sum(v.size for v in w.values()) == int(g["n_params"])
+    x, _ = R.proj_input()
+    y, c = OMS.mosa_forward(x, w)
+    assert y.shape == g["y"].shape == (2, OMS.output_length(50), D) and OMS.output_length(500) == 125
+    assert relerr(y, g["y"]) < 2e-5
+    grads = OMS.mosa_backward(g["dy"], w, c)
+    assert set(grads) == set(w)
+    for k in [k[2:] for k in g.files if k.startswith("g.")]:
+        assert relerr(grads[k], g["g." + k]) < 3e-4, k
+    assert relerr(grads["experts.2.fc1.weight"][:64], g["rows64_experts_2_fc1_weight"]) < 3e-4      # slices keep the fixture small
+    assert relerr(grads["experts.1.fc2.weight"][:, :64], g["cols64_experts_1_fc2_weight"]) < 3e-4
+    assert relerr(grads["downsampler.0.weight"][:32], g["rows32_downsampler_0_weight"]) < 3e-4
+
+
 def test_greedy_generate(golden):
     """Section 8(f) rank 1: token-exact against ASRModel.generate of the reference (HF greedy search + KV cache),
     including EOS stop and pad fill for the clip that finishes first."""
