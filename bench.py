@@ -39,7 +39,7 @@ def parse():
                     help="'full' additionally materialises outputs.logits [B, L, V] (bf16) every step as the reference does; "
                          "'labelled' computes the loss head only on label positions (identical loss and gradients)")
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
-    ap.add_argument("--projector", choices=["mlp", "moe", "qformer"], default="mlp",
+    ap.add_argument("--projector", choices=["mlp", "moe", "qformer", "mosa"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
     ap.add_argument("--lora", action="store_true",
                     help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
@@ -174,6 +174,7 @@ def main():
                "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
                                        else "configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
                                        "QFormer projector (2 layers, 16 heads, windows of 15 -> 3 queries, 102 audio tokens)" if a.projector == "qformer" else
+                                       "MOSA projector (2 stride-2 convs, 4 dense experts of width 4096)" if a.projector == "mosa" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
                                       " bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
                                       "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,

@@ -175,6 +175,13 @@ int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const int* src_r
 int ta_gelu_fwd(const void* h_bf16, void* a_bf16, long n, hipStream_t st);                     /* nn.GELU (erf) */
 int ta_gelu_bwd(const void* da_bf16, const void* h_bf16, void* dh_bf16, long n, hipStream_t st);
 int ta_colsum(const void* x, int is_f32, int R, int C, float* out, hipStream_t st);           /* out[c] = sum_r x[r,c]: bias grads */
+int ta_relu_fwd(const void* h_bf16, void* a_bf16, long n, hipStream_t st);                     /* MOSA router (projectors.py:136-140) */
+int ta_relu_bwd(const void* da_bf16, const void* h_bf16, void* dh_bf16, long n, hipStream_t st);
+/* MOSA dense mixture (projectors.py:158-166): rw = softmax(logits [M,E]); out = sum_e rw[:,e] * o[e] with o f32 [E, M, D].
+ * Backward: do_bf16 [E, M, D] = dout * rw[:,e]; dlogits [M,E] = softmax backward of drw[e] = <dout, o[e]>. */
+int ta_mix_fwd(const float* logits, const float* o, float* rw, float* out, int M, int D, int E, hipStream_t st);
+int ta_mix_bwd(const float* dout, const float* o, const float* rw, void* do_bf16, float* dlogits, int M, int D, int E,
+               hipStream_t st);
 /* y = LayerNorm(z * keep + res[row % res_rows]) (keep: dropout mask already divided by 1-p, or NULL; res optional);
  * saves xhat [M,H] and rstd [M] for ta_layernorm_bwd.  Blip2QFormerSelfOutput / Output: dense -> dropout -> +res -> LN. */
 int ta_layernorm_res_fwd(const float* z, const float* keep, const float* res, long res_rows, const float* gamma,

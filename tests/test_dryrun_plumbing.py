@@ -173,6 +173,27 @@ def test_qformer_plumbing(dry):
         assert p.grad is not None and p.grad.shape == p.shape, n
 
 
+def test_mosa_plumbing(dry):
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    full = ASRModel(ASRConfig(projector_type="mosa"), device="cpu", init="none")
+    assert sum(p.numel() for p in full.projector.parameters()) == 42_951_428
+    assert set(full.projector.state_dict()) == set(OW.init_mosa_projector(1280, 1024)) and full.projector.get_output_length(500) == 125
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=1, heads=4, kv_heads=2)
+    m = ASRModel(ASRConfig(audio_config=enc, text_config=lm, projector_type="mosa", audio_token_id=999), device="cpu", init="random")
+    n_tok = m.projector.get_output_length(50)
+    ids, att, lab, counts = OW.synthetic_tokens(2, [n_tok, n_tok], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    m.train()
+    out = m(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+            labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts),
+            label_meta=(torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22))
+    out.loss.backward()
+    for n, p in m.projector.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+    for must in ("ta_mix_fwd", "ta_mix_bwd", "ta_relu_fwd", "ta_relu_bwd", "ta_gelu_bwd", "ta_colsum"):
+        assert must in dry.calls, must
+
+
 def test_generate_plumbing(dry):
     """Section 8(f) rank 1: the argument marshalling of prefill / decode step / greedy bookkeeping, the reference's
     error behaviour, and the trim of surplus columns (nothing is computed under DRY_RUN: every token is 0)."""

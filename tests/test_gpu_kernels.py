@@ -451,3 +451,20 @@ def test_attn_small_fwd_bwd(heads, hd, Lq, Lk):
         o_ref.backward(do.float())
         dQ, dK, dV = ops.attn_small_bwd(do, q, k, v, P, EB, heads, Lq, Lk, scale, kp)
         assert relerr(dQ, qt.grad) < 1.5e-2 and relerr(dK, kt.grad) < 1.5e-2 and relerr(dV, vt.grad) < 1.5e-2
+
+
+def test_relu_and_mix():
+    h = rnd(200, 512, seed=1, dtype=BF16)
+    assert torch.equal(ops.relu_fwd(h), torch.relu(h))
+    da = rnd(200, 512, seed=2, dtype=BF16)
+    assert torch.equal(ops.relu_bwd(da, h), torch.where(h.float() > 0, da, torch.zeros_like(da)))
+    M, D, E = 333, 1024, 4
+    lg, o, dout = rnd(M, E, seed=3), rnd(E, M, D, seed=4), rnd(M, D, seed=5)
+    lt, ot = lg.clone().requires_grad_(True), o.clone().requires_grad_(True)
+    p = torch.softmax(lt, -1)
+    ref = (ot * p.t()[:, :, None]).sum(0)
+    rw, out = ops.mix_fwd(lg, o)
+    assert relerr(rw, p.detach()) < 1e-5 and relerr(out, ref.detach()) < 1e-5
+    ref.backward(dout)
+    dob, dlg = ops.mix_bwd(dout, o, rw)
+    assert relerr(dob, ot.grad) < 1e-2 and relerr(dlg, lt.grad) < 1e-4

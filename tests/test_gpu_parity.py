@@ -400,6 +400,47 @@ def test_qformer_projector_true_width_with_dropout_masks():
     assert torch.equal(m(torch.from_numpy(x).to(DEV)), m(torch.from_numpy(x).to(DEV)))
 
 
+# ============================================================================ MOSA projector (section 8(f) rank 4)
+def _mosa_case(E, D, x, dy):
+    from oracle import mosa as OMS
+    from tiny_audio_amd.mosa_projector import MOSAProjector
+    w = OW.init_mosa_projector(E, D)
+    cfg = ASRConfig(audio_config=dict(hidden=E, ffn=2 * E, layers=1, heads=E // 64), text_config=dict(hidden=D, ffn=2 * D, layers=1, heads=4, kv_heads=2, vocab=512),
+                    projector_type="mosa")
+    m = MOSAProjector(cfg).to(DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    y = m(torch.from_numpy(x).to(DEV))
+    ref, c = OMS.mosa_forward(x, w)
+    assert y.shape == ref.shape and relmax(npy(y), ref) < 2e-2 and cosine(npy(y), ref) > 0.9995
+    (y * torch.from_numpy(dy).to(DEV)).sum().backward()
+    grads = OMS.mosa_backward(dy, w, c)
+    for k, p_ in m.named_parameters():
+        assert cosine(npy(p_.grad), grads[k]) > 0.995, k
+        # the router's ReLU has a kink at 0: pre-activations within bf16 rounding of 0 switch sides, which moves single
+        # entries of the first router layer's gradient by a whole token's contribution (the direction is unaffected)
+        assert relmax(npy(p_.grad), grads[k]) < (0.3 if k.startswith("router.0") else 8e-2), k
+    return m
+
+
+def test_mosa_projector_vs_golden_config(golden):
+    g = golden("projector_mosa.npz")
+    x, _ = R.proj_input()
+    m = _mosa_case(R.SMALL["enc"]["hidden"], R.SMALL["lm"]["hidden"], x, g["dy"])
+    P = dict(m.named_parameters())
+    assert relmax(npy(m(torch.from_numpy(x).to(DEV))), g["y"]) < 2e-2
+    for k in [k[2:] for k in g.files if k.startswith("g.")]:
+        assert cosine(npy(P[k].grad), g["g." + k]) > 0.995, k
+    assert cosine(npy(P["experts.2.fc1.weight"].grad)[:64], g["rows64_experts_2_fc1_weight"]) > 0.995
+
+
+def test_mosa_projector_true_width():
+    rng = np.random.RandomState(4)
+    x = rng.standard_normal((2, 101, 1280)).astype(np.float32)               # odd length: T1 = 51, T2 = 26
+    dy = rng.standard_normal((2, 26, 1024)).astype(np.float32)
+    m = _mosa_case(1280, 1024, x, dy)
+    assert m.get_output_length(500) == 125 and m.get_output_length(101) == 26
+
+
 # ============================================================================ greedy generation (section 8(f) rank 1)
 def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12):
     """Greedy parity that is robust to bf16 near-ties: feed the HIP path's OWN tokens to the fp32 oracle and require

@@ -35,6 +35,59 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------- ReLU (MOSA router)
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ a, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a[i] = (h[i] & 0x8000) ? (bf16_t)0 : h[i];
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ da, const bf16_t* __restrict__ h,
+                                                       bf16_t* __restrict__ dh, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dh[i] = (bf2f(h[i]) > 0.f) ? da[i] : (bf16_t)0;
+}
+
+// ---------------------------------------------------------------------------- dense mixture (MOSA): softmax gate + weighted sum
+// rw = softmax(logits) over E <= 16 experts; out[m,:] = sum_e rw[m,e] * o[e][m,:]        (tiny_audio/projectors.py:158-166)
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ o,
+                                                      float* __restrict__ rw, float* __restrict__ out, int M, int D, int E) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float p[16], mx = -INFINITY, sum = 0.f;
+  for (int e = 0; e < E; ++e) { p[e] = logits[(long)row * E + e]; mx = fmaxf(mx, p[e]); }
+  for (int e = 0; e < E; ++e) { p[e] = __expf(p[e] - mx); sum += p[e]; }
+  for (int e = 0; e < E; ++e) p[e] /= sum;
+  if (lane < E) rw[(long)row * E + lane] = p[lane];
+  for (int c = lane; c < D / 4; c += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = 0; e < E; ++e) {
+      const float4 v = ((const float4*)(o + ((long)e * M + row) * D))[c];
+      acc.x += p[e] * v.x; acc.y += p[e] * v.y; acc.z += p[e] * v.z; acc.w += p[e] * v.w;
+    }
+    ((float4*)(out + (long)row * D))[c] = acc;
+  }
+}
+// do[e][m,:] = dout[m,:] * rw[m,e] (bf16, feeds the expert GEMMs); drw[e] = <dout[m,:], o[e][m,:]>;
+// dlogits = rw * (drw - sum_e drw rw)   (softmax backward)
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ o,
+                                                      const float* __restrict__ rw, bf16_t* __restrict__ dob,
+                                                      float* __restrict__ dlogits, int M, int D, int E) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float p[16], dr[16];
+  for (int e = 0; e < E; ++e) { p[e] = rw[(long)row * E + e]; dr[e] = 0.f; }
+  for (int c = lane; c < D / 4; c += 64) {
+    const float4 g = ((const float4*)(dout + (long)row * D))[c];
+    for (int e = 0; e < E; ++e) {
+      const float4 v = ((const float4*)(o + ((long)e * M + row) * D))[c];
+      dr[e] += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+      uint2 q; q.x = pack2bf(g.x * p[e], g.y * p[e]); q.y = pack2bf(g.z * p[e], g.w * p[e]);
+      ((uint2*)(dob + ((long)e * M + row) * D))[c] = q;
+    }
+  }
+  float dot = 0.f;
+  for (int e = 0; e < E; ++e) { dr[e] = wave_sum(dr[e]); dot += dr[e] * p[e]; }
+  if (lane < E) dlogits[(long)row * E + lane] = p[lane] * (dr[lane] - dot);
+}
+
 // ---------------------------------------------------------------------------- column sums (bias gradients)
 // out[c] += sum_r x[r, c]; grid (ceil(C/256), row chunks); out must be zeroed
 template <typename T>
@@ -334,5 +387,30 @@ extern "C" int ta_attn_small_bwd(const void* dO, const void* Q, const void* K, c
   if (hd % 8 || heads * Lq * Lk > ATT_MAX_S) return TA_ERR_ARG;
   TA_LAUNCH(attn_small_bwd_kernel, dim3(EB), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)Q, (const bf16_t*)K,
             (const bf16_t*)V, P, keep, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, heads, hd, Lq, Lk, scale);
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
+extern "C" int ta_relu_fwd(const void* h, void* a, long n, hipStream_t st) {
+  if (n <= 0) return TA_OK;
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  TA_LAUNCH(relu_fwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)a, n);
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
+extern "C" int ta_relu_bwd(const void* da, const void* h, void* dh, long n, hipStream_t st) {
+  if (n <= 0) return TA_OK;
+  int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+  TA_LAUNCH(relu_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)da, (const bf16_t*)h, (bf16_t*)dh, n);
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
+extern "C" int ta_mix_fwd(const float* logits, const float* o, float* rw, float* out, int M, int D, int E, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if (E > 16 || E <= 0 || D % 4) return TA_ERR_ARG;
+  TA_LAUNCH(mix_fwd_kernel, dim3(ta_cdiv(M, 4)), dim3(256), 0, st, logits, o, rw, out, M, D, E);
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
+extern "C" int ta_mix_bwd(const float* dout, const float* o, const float* rw, void* do_bf16, float* dlogits, int M, int D, int E,
+                          hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if (E > 16 || E <= 0 || D % 4) return TA_ERR_ARG;
+  TA_LAUNCH(mix_bwd_kernel, dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dout, o, rw, (bf16_t*)do_bf16, dlogits, M, D, E);
   TA_CHECK_LAUNCH(); return TA_OK;
 }

@@ -172,9 +172,11 @@ def cast_bf16(x):
     return y
 
 
-def transpose_to_bf16(x, ld_out=None, in_map=None):
-    """x [R, C] (f32 or bf16) -> bf16 [C, ld_out] (zero padded columns)."""
-    R, Cc = x.shape
+def transpose_to_bf16(x, ld_out=None, in_map=None, rows=None, cols=None):
+    """x [R, C] (f32 or bf16) -> bf16 [C, ld_out] (zero padded columns).  With ``in_map`` = (ld_in, batch_stride,
+    rows_per_batch) the logical [rows, cols] matrix is an affine view of ``x`` (e.g. the im2col view of a padded
+    time-major buffer: overlapping rows)."""
+    R, Cc = (rows, cols) if rows is not None else x.shape
     ld_out = ld_out or R
     ld_in, in_bs, in_rpb = in_map or (Cc, 0, 0)
     out = torch.empty((Cc, ld_out), device=x.device, dtype=BF16)
@@ -289,3 +291,37 @@ def attn_small_bwd(dO, Q, K, V, P, EB, heads, Lq, Lk, scale, keep=None):
     check(lib().ta_attn_small_bwd(ptr(dO), ptr(Q), ptr(K), ptr(V), ptr(P), ptr(keep), scale, ptr(dQ), ptr(dK), ptr(dV), EB,
                                   heads, H // heads, Lq, Lk, stream()), "ta_attn_small_bwd")
     return dQ, dK, dV
+
+
+def relu_fwd(h):
+    _req(h, BF16)
+    a = torch.empty_like(h)
+    check(lib().ta_relu_fwd(ptr(h), ptr(a), h.numel(), stream()), "ta_relu_fwd")
+    return a
+
+
+def relu_bwd(da, h):
+    _req(da, BF16); _req(h, BF16)
+    dh = torch.empty_like(h)
+    check(lib().ta_relu_bwd(ptr(da), ptr(h), ptr(dh), h.numel(), stream()), "ta_relu_bwd")
+    return dh
+
+
+def mix_fwd(logits, o):
+    """logits f32 [M, E], o f32 [E, M, D] -> (rw [M, E], out [M, D])"""
+    _req(logits, F32); _req(o, F32)
+    E, M, D = o.shape
+    rw = torch.empty((M, E), device=o.device, dtype=F32)
+    out = torch.empty((M, D), device=o.device, dtype=F32)
+    check(lib().ta_mix_fwd(ptr(logits), ptr(o), ptr(rw), ptr(out), M, D, E, stream()), "ta_mix_fwd")
+    return rw, out
+
+
+def mix_bwd(dout, o, rw):
+    """-> (do bf16 [E, M, D], dlogits f32 [M, E])"""
+    _req(dout, F32)
+    E, M, D = o.shape
+    dob = torch.empty((E, M, D), device=o.device, dtype=BF16)
+    dlg = torch.empty((M, E), device=o.device, dtype=F32)
+    check(lib().ta_mix_bwd(ptr(dout), ptr(o), ptr(rw), ptr(dob), ptr(dlg), M, D, E, stream()), "ta_mix_bwd")
+    return dob, dlg

@@ -260,5 +260,6 @@ class MoEAudioProjector(nn.Module):
 
 
 from .qformer_projector import QFormerAudioProjector  # noqa: E402
+from .mosa_projector import MOSAProjector  # noqa: E402
 
-PROJECTOR_CLASSES = {"mlp": MLPAudioProjector, "moe": MoEAudioProjector, "qformer": QFormerAudioProjector}
+PROJECTOR_CLASSES = {"mlp": MLPAudioProjector, "mosa": MOSAProjector, "moe": MoEAudioProjector, "qformer": QFormerAudioProjector}
