@@ -42,9 +42,11 @@ if only in ("all", "gemm"):
     variants = sys.argv[sys.argv.index("--variants") + 1].split(",") if "--variants" in sys.argv else [""]
     for name, M, N, K, obf, act, hasres in shapes:
       for var in variants:
+        os.environ["TA355_GROUP_M"] = var.split("g")[1] if "g" in var else ""
+        var = var.split("g")[0]
         os.environ["TA355_GEMM_VARIANT"] = var.split("w")[0]
         os.environ["TA355_EPI_WIDE"] = "0" if var.endswith("w0") else "1"
-        name_v = name + (":v" + var if var else "")
+        name_v = name + (":v" + var if var else "") + (":g" + os.environ["TA355_GROUP_M"] if os.environ["TA355_GROUP_M"] else "")
         A = (torch.randn(M, K, device=DEV) * 1.0).to(BF16)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(BF16)
         out = torch.empty(M, N, device=DEV, dtype=BF16 if obf else F32)

@@ -286,23 +286,58 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     RC(ta_i_lora_skinny_nt(x, in, g.a, xa, M, st));
     return ta_gemm_set_k_extension(xa, g.b, 64, 64);
   };
+  if (lora) {
+    // bf16 images of every layer's adapters (kept in the tape / the caller's image buffer for backward and decoding).
+    // The masters of consecutive layers are usually one tensor [L, ...] and the images are carved with a constant
+    // per-layer stride: then each of the 8 image kinds is ONE launch over all layers instead of one per layer.
+    const int NB = 1 << 30, bq = d.nq * d.hd, bk = bq + d.nkv * d.hd, NL = w->n_layers;
+    auto imgs_of = [&](int l) {
+      LmLayerTape q = store[(alias || ext) ? 0 : l];
+      if (ext) { q.i_qkv = ext[l].g[0]; q.i_o = ext[l].g[1]; q.i_gu = ext[l].g[2]; q.i_d = ext[l].g[3]; }
+      return q;
+    };
+    const LmLayerTape q0 = imgs_of(0), q1 = imgs_of(NL > 1 ? 1 : 0);
+    const ta_lm_layer &L0 = w->layers[0], &L1 = w->layers[NL > 1 ? 1 : 0];
+    bool strided = NL > 1 && (ext || !alias);
+    const long is_ = strided ? (long)(q1.i_qkv.a - q0.i_qkv.a) : 0;        // image stride (bf16 elements), same for every kind
+    struct Kind { const float* m0; const float* m1; bf16_t* o0; bf16_t* o1; bf16_t* t0; bf16_t* t1; };
+    const Kind kinds[8] = {{L0.la_qkv, L1.la_qkv, q0.i_qkv.a, q1.i_qkv.a, q0.i_qkv.at, q1.i_qkv.at}, {L0.lb_qkv, L1.lb_qkv, q0.i_qkv.b, q1.i_qkv.b, q0.i_qkv.bt, q1.i_qkv.bt},
+                           {L0.la_o, L1.la_o, q0.i_o.a, q1.i_o.a, q0.i_o.at, q1.i_o.at}, {L0.lb_o, L1.lb_o, q0.i_o.b, q1.i_o.b, q0.i_o.bt, q1.i_o.bt},
+                           {L0.la_gu, L1.la_gu, q0.i_gu.a, q1.i_gu.a, q0.i_gu.at, q1.i_gu.at}, {L0.lb_gu, L1.lb_gu, q0.i_gu.b, q1.i_gu.b, q0.i_gu.bt, q1.i_gu.bt},
+                           {L0.la_d, L1.la_d, q0.i_d.a, q1.i_d.a, q0.i_d.at, q1.i_d.at}, {L0.lb_d, L1.lb_d, q0.i_d.b, q1.i_d.b, q0.i_d.bt, q1.i_d.bt}};
+    long ms[8];
+    for (int k = 0; k < 8 && strided; ++k) {
+      ms[k] = (long)(kinds[k].m1 - kinds[k].m0);
+      if ((long)(kinds[k].o1 - kinds[k].o0) != is_ || (long)(kinds[k].t1 - kinds[k].t0) != is_) strided = false;
+    }
+    for (int l = 2; l < NL && strided; ++l) {
+      const ta_lm_layer& Ll = w->layers[l];
+      const LmLayerTape ql = imgs_of(l);
+      const float* mm[8] = {Ll.la_qkv, Ll.lb_qkv, Ll.la_o, Ll.lb_o, Ll.la_gu, Ll.lb_gu, Ll.la_d, Ll.lb_d};
+      const bf16_t* oo[8] = {ql.i_qkv.a, ql.i_qkv.b, ql.i_o.a, ql.i_o.b, ql.i_gu.a, ql.i_gu.b, ql.i_d.a, ql.i_d.b};
+      for (int k = 0; k < 8; ++k)
+        if (mm[k] != kinds[k].m0 + l * ms[k] || oo[k] != kinds[k].o0 + l * is_) strided = false;
+    }
+    const int reps = strided ? 1 : NL, per = strided ? NL : 1;
+    for (int l = 0; l < reps; ++l) {
+      const ta_lm_layer& Ll = w->layers[l];
+      const LmLayerTape ql = imgs_of(l);
+      RC(ta_i_lora_pack_a(Ll.la_qkv, w->lora_scale, ql.i_qkv.a, ql.i_qkv.at, 3 * r, d.D, per, strided ? ms[0] : 0, is_, st));
+      RC(ta_i_lora_pack_b(Ll.lb_qkv, ql.i_qkv.b, ql.i_qkv.bt, d.NQKV, r, bq, bk, per, strided ? ms[1] : 0, is_, st));
+      RC(ta_i_lora_pack_a(Ll.la_o, w->lora_scale, ql.i_o.a, ql.i_o.at, r, bq, per, strided ? ms[2] : 0, is_, st));
+      RC(ta_i_lora_pack_b(Ll.lb_o, ql.i_o.b, ql.i_o.bt, d.D, r, NB, NB, per, strided ? ms[3] : 0, is_, st));
+      RC(ta_i_lora_pack_a(Ll.la_gu, w->lora_scale, ql.i_gu.a, ql.i_gu.at, 2 * r, d.D, per, strided ? ms[4] : 0, is_, st));
+      RC(ta_i_lora_pack_b(Ll.lb_gu, ql.i_gu.b, ql.i_gu.bt, 2 * d.F, r, d.F, NB, per, strided ? ms[5] : 0, is_, st));
+      RC(ta_i_lora_pack_a(Ll.la_d, w->lora_scale, ql.i_d.a, ql.i_d.at, r, d.F, per, strided ? ms[6] : 0, is_, st));
+      RC(ta_i_lora_pack_b(Ll.lb_d, ql.i_d.b, ql.i_d.bt, d.D, r, NB, NB, per, strided ? ms[7] : 0, is_, st));
+    }
+  }
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_lm_layer& Lw = w->layers[l];
     LmLayerTape p = store[alias ? 0 : l];
     if (ext) { p.i_qkv = ext[l].g[0]; p.i_o = ext[l].g[1]; p.i_gu = ext[l].g[2]; p.i_d = ext[l].g[3]; }
     float* x_next = (l + 1 < w->n_layers) ? store[alias ? 0 : l + 1].x_in : x_final;
     bf16_t* xn = lora ? p.xn_s : s.xn;
-    if (lora) {   // bf16 images of this layer's adapters (kept in the tape for backward)
-      const int NB = 1 << 30, bq = d.nq * d.hd, bk = bq + d.nkv * d.hd;
-      RC(ta_i_lora_pack_a(Lw.la_qkv, w->lora_scale, p.i_qkv.a, p.i_qkv.at, 3 * r, d.D, st));
-      RC(ta_i_lora_pack_b(Lw.lb_qkv, p.i_qkv.b, p.i_qkv.bt, d.NQKV, r, bq, bk, st));
-      RC(ta_i_lora_pack_a(Lw.la_o, w->lora_scale, p.i_o.a, p.i_o.at, r, bq, st));
-      RC(ta_i_lora_pack_b(Lw.lb_o, p.i_o.b, p.i_o.bt, d.D, r, NB, NB, st));
-      RC(ta_i_lora_pack_a(Lw.la_gu, w->lora_scale, p.i_gu.a, p.i_gu.at, 2 * r, d.D, st));
-      RC(ta_i_lora_pack_b(Lw.lb_gu, p.i_gu.b, p.i_gu.bt, 2 * d.F, r, d.F, NB, st));
-      RC(ta_i_lora_pack_a(Lw.la_d, w->lora_scale, p.i_d.a, p.i_d.at, r, d.F, st));
-      RC(ta_i_lora_pack_b(Lw.lb_d, p.i_d.b, p.i_d.bt, d.D, r, NB, NB, st));
-    }
     RC(ta_rmsnorm_fwd(p.x_in, Lw.ln_in_w, xn, nullptr, p.r_in, M, d.D, w->eps, 0, st));
     if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
     RC(gemm(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));

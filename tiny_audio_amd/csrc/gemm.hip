@@ -38,6 +38,7 @@ struct GemmArgs {
   // K extension (LoRA): after the K columns of A / W the contraction continues over K2 more columns taken from
   // A2 [M, K2] (row stride lda2) and W2 [N, K2]:  C = A W^T + A2 W2^T  in one accumulator pass
   const bf16_t* A2; const bf16_t* W2; int K2; long lda2;
+  int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
 };
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int tiles = p.tiles_m * p.tiles_n;
   const int z = bid / tiles;
   int t = bid - z * tiles;
-  const int GROUP_M = 8;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 8;
   const int width = GROUP_M * p.tiles_n;
   const int group = t / width;
   const int first_m = group * GROUP_M;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int tiles = p.tiles_m * p.tiles_n;
   const int z = bid / tiles;
   int t = bid - z * tiles;
-  const int GROUP_M = 4;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
   const int width = GROUP_M * p.tiles_n;
   const int group = t / width;
   const int first_m = group * GROUP_M;
@@ -485,6 +486,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   {
+    const char* gm = getenv("TA355_GROUP_M");             // experiments: tile-order group height
+    a.group_m = gm && *gm ? atoi(gm) : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD
     const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
     a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
   }

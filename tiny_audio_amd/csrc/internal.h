@@ -7,8 +7,11 @@
 struct LoraImg { bf16_t *a, *at, *b, *bt; };
 struct ta_i_lora_layer_imgs { LoraImg g[4]; };   // qkv, o, gate|up, down
 
-int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, hipStream_t st);
-int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, hipStream_t st);
+// `layers` images in one launch when masters / images of consecutive layers are a constant stride apart (else layers = 1)
+int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, int layers, long in_ls, long out_ls,
+                     hipStream_t st);
+int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, int layers, long in_ls, long out_ls,
+                     hipStream_t st);
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
                         int r, int b0, int b1, hipStream_t st);
 int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T

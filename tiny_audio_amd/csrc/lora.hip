@@ -12,8 +12,10 @@
 // lb_g [N_g, r] (member B's stacked on rows).  The 64-wide bf16 images are rebuilt from them every forward.
 
 // A master fp32 [R, in] -> s*A image bf16 [64, in] (rows >= R zero) and its transpose [in, 64]
+// blockIdx.y = layer: the masters and the images of consecutive layers are `in_ls` floats / `out_ls` bf16 apart
 __global__ __launch_bounds__(256) void lora_pack_a_kernel(const float* __restrict__ in, float scale, bf16_t* __restrict__ out,
-                                                          bf16_t* __restrict__ outT, int R, int Cn) {
+                                                          bf16_t* __restrict__ outT, int R, int Cn, long in_ls, long out_ls) {
+  in += blockIdx.y * in_ls; out += blockIdx.y * out_ls; outT += blockIdx.y * out_ls;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)64 * Cn) return;
   const int j = (int)(idx / Cn), c = (int)(idx % Cn);
@@ -23,7 +25,9 @@ __global__ __launch_bounds__(256) void lora_pack_a_kernel(const float* __restric
 }
 // B master fp32 [N, r] -> Bext image bf16 [N, 64] (row n of member j owns columns [j*r, (j+1)*r)) and transpose [64, N]
 __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
-                                                          bf16_t* __restrict__ outT, int N, int r, int b0, int b1) {
+                                                          bf16_t* __restrict__ outT, int N, int r, int b0, int b1, long in_ls,
+                                                          long out_ls) {
+  in += blockIdx.y * in_ls; out += blockIdx.y * out_ls; outT += blockIdx.y * out_ls;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)N * 64) return;
   const int n = (int)(idx >> 6), j = (int)(idx & 63);
@@ -189,13 +193,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
   }
 }
 
-int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, hipStream_t st) {
-  TA_LAUNCH(lora_pack_a_kernel, dim3(ta_cdiv(64 * Cn, 256)), dim3(256), 0, st, in, scale, (bf16_t*)out, (bf16_t*)outT, R, Cn);
+int ta_i_lora_pack_a(const float* in, float scale, void* out, void* outT, int R, int Cn, int layers, long in_ls, long out_ls,
+                     hipStream_t st) {
+  TA_LAUNCH(lora_pack_a_kernel, dim3(ta_cdiv(64 * Cn, 256), layers), dim3(256), 0, st, in, scale, (bf16_t*)out, (bf16_t*)outT, R, Cn,
+            in_ls, out_ls);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
-int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, hipStream_t st) {
-  TA_LAUNCH(lora_pack_b_kernel, dim3(ta_cdiv(N * 64, 256)), dim3(256), 0, st, in, (bf16_t*)out, (bf16_t*)outT, N, r, b0, b1);
+int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b0, int b1, int layers, long in_ls, long out_ls,
+                     hipStream_t st) {
+  TA_LAUNCH(lora_pack_b_kernel, dim3(ta_cdiv(N * 64, 256), layers), dim3(256), 0, st, in, (bf16_t*)out, (bf16_t*)outT, N, r, b0, b1,
+            in_ls, out_ls);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
