@@ -391,6 +391,14 @@ def gen_text_post():
     out = {"truncate": [[c, _truncate_repetitions(c)] for c, _ in old["truncate"]],
            "truncate_min2": [[c, _truncate_repetitions(c, 2)] for c, _ in old["truncate_min2"]],
            "think": [[c, _THINK_TAG_RE.sub("", c).strip()] for c, _ in old["think"]]}
+    # label normaliser of the training collator (scripts/train.py:62-97).  scripts/train.py cannot be imported here (hydra /
+    # trl are not installed), so exactly its regex definitions and _normalize_label are executed from the source text.
+    import re as _re
+    src = open("/root/reference/scripts/train.py").read()
+    a, b = src.index("_CORPUS_MARKER_RE = re.compile("), src.index("class DatasetLoader")
+    ns = {"re": _re}
+    exec(src[a:b], ns)
+    out["normalize_label"] = [[c, ns["_normalize_label"](c)] for c, _ in old.get("normalize_label", [])]
     json.dump(out, open(os.path.join(HERE, "text_post.json"), "w"), ensure_ascii=False, indent=0)
     print("wrote text_post.json")
 

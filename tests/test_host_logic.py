@@ -206,3 +206,99 @@ def test_word_error_rate_known_answers():
     assert wer("Hello, World", "hello world", normalize=lambda s: s.lower().replace(",", "")) == 0.0
     with pytest.raises(ValueError):
         wer(["a"], ["a", "b"])
+
+
+# ----------------------------------------------------------------------------- collator (8(f) rank 2)
+class _StubChatTokenizer:
+    """Whitespace tokenizer with a ChatML-shaped template: <|im_start|>role\n content <|im_end|>\n per message."""
+    pad_token_id, eos_token_id = 0, 2
+
+    def __init__(self):
+        self.vocab = {"<pad>": 0, "<|im_start|>": 1, "<|im_end|>": 2, "<audio>": 3, "\n": 4}
+
+    def _id(self, w):
+        return self.vocab.setdefault(w, len(self.vocab))
+
+    def convert_tokens_to_ids(self, t):
+        return self.vocab.get(t)
+
+    def _words(self, text):
+        return [w for w in text.replace("<audio>", " <audio> ").split() if w]
+
+    def apply_chat_template(self, messages, tokenize=True, add_generation_prompt=False, **_):
+        ids = []
+        for m in messages:
+            ids += [1, self._id(m["role"]), 4] + [self._id(w) for w in self._words(m["content"])] + [2, 4]
+        if add_generation_prompt:
+            ids += [1, self._id("assistant"), 4]
+        return ids
+
+    def decode(self, ids, skip_special_tokens=True):
+        inv = {v: k for k, v in self.vocab.items()}
+        return " ".join(inv[i] for i in ids if not (skip_special_tokens and i in (0, 1, 2, 4)))
+
+
+def test_label_normaliser_matches_reference_outputs():
+    import json, os
+    from tiny_audio_amd.collator import normalize_label
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "text_post.json")))
+    assert len(g["normalize_label"]) >= 20
+    for src, want in g["normalize_label"]:
+        assert normalize_label(src) == want, src
+
+
+def test_collator_contract(dry_lib_for_features):
+    """What the reference's tests/test_data_collator.py pins: assistant text + <|im_end|> unmasked, system / user prompt and
+    every <audio> placeholder masked, one placeholder per projector output frame, row filters, batch keys."""
+    from tiny_audio_amd.collator import DataCollator, MultiTaskDataCollator
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.projectors import MLPAudioProjector
+    tok, fe = _StubChatTokenizer(), dry_lib_for_features
+    proj = MLPAudioProjector(ASRConfig())
+    col = DataCollator(tok, fe, 16000, system_prompt="You are a helpful assistant.", projector=proj)
+    rng = np.random.RandomState(0)
+    mk = lambda text, sec: {"audio": {"array": (0.1 * rng.standard_normal(int(sec * 16000))).astype(np.float32), "sampling_rate": 16000}, "text": text}
+    batch = col([mk("Hello World this is a TEST <comma>", 1.0), mk("second clip", 2.0)])
+    assert set(batch) == {"input_ids", "attention_mask", "labels", "input_features", "audio_attention_mask", "audio_token_counts"}
+    assert batch["audio_token_counts"].tolist() == [12, 25]                       # 100 / 200 mel frames -> 50 / 100 -> 12 / 25
+    ids, lab, att = batch["input_ids"], batch["labels"], batch["attention_mask"]
+    for i, n_audio in enumerate([12, 25]):
+        row, lr = ids[i].tolist(), lab[i].tolist()
+        assert row.count(3) == n_audio and all(lr[j] == -100 for j, t in enumerate(row) if t == 3)       # <audio> masked
+        unmasked = [t for t, l in zip(row, lr) if l != -100]
+        assert unmasked[-2:] == [2, 4] or unmasked[-1] == 2 or 2 in unmasked      # the stop token is learned
+        text = tok.decode(unmasked)
+        assert text == ("hello world this is a test" if i == 0 else "second clip")
+        assert all(l == -100 for l, a in zip(lr, att[i].tolist()) if a == 0)      # padding masked
+        prompt_part = tok.decode([t for t, l in zip(row, lr) if l == -100 and t != 0])
+        assert "helpful" in prompt_part and "Transcribe" in prompt_part and "hello" not in prompt_part
+    assert att[0].tolist()[0] == 0 and att[1].tolist()[0] == 1                    # left padding of the shorter row
+    # row filters (scripts/train.py:274-311)
+    bad = [mk("<noise>", 1.0), mk("", 1.0), mk("too long", 30.5), {"audio": {"array": np.array([np.nan, 0.1], np.float32)}, "text": "nan"},
+           {"audio": {"array": np.zeros(0, np.float32)}, "text": "empty"}]
+    kept = col(bad + [mk("fine", 30.0)])
+    assert kept["input_ids"].shape[0] == 1
+    with pytest.raises(ValueError, match="No valid audio"):
+        col([mk("<unk>", 1.0)])
+    mt = MultiTaskDataCollator(tok, fe, 16000, projector=proj)
+    b2 = mt([dict(mk("ignored", 1.0), task="sift", sift_response="A man speaks calmly")])
+    un = tok.decode([t for t, l in zip(b2["input_ids"][0].tolist(), b2["labels"][0].tolist()) if l != -100])
+    assert un == "A man speaks calmly" and "Describe" in tok.decode(b2["input_ids"][0].tolist())
+
+
+class _StubFeatureExtractor:
+    """Stands in for the device log-mel (numerics are covered by the -m gpu tests): shapes + the frame mask contract
+    (one frame per 160 samples, TF:models/whisper/feature_extraction_whisper.py:330-339)."""
+
+    def __call__(self, arrays, sampling_rate=16000, padding="longest", return_attention_mask=True, return_tensors="pt"):
+        lens = [len(a) for a in arrays]
+        T = max(lens) // 160
+        mask = torch.zeros((len(arrays), T), dtype=torch.int32)
+        for i, n in enumerate(lens):
+            mask[i, : n // 160] = 1
+        return {"input_features": torch.zeros((len(arrays), 128, T)), "attention_mask": mask}
+
+
+@pytest.fixture()
+def dry_lib_for_features():
+    return _StubFeatureExtractor()
