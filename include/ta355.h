@@ -253,6 +253,10 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
 /* K extension (LoRA): arms the NEXT ta_gemm_bf16_nt* call of this host thread to compute
  * C = epilogue(A W^T + A2 W2^T) with A2 [M, K2] (row stride lda2) and W2 [N, K2], K2 % 64 == 0, in one pass. */
 int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2);
+/* SwiGLU backward fused into the epilogue of the NEXT ta_gemm_bf16_nt* call on this thread (one-shot): that GEMM's bf16
+ * result is d(act) [M, N = F] (dX of Qwen3MLP.down_proj, TF:models/qwen3/modeling_qwen3.py:70-83); it is not stored --
+ * d(gate|up) [M, 2F] is written to dgu from gate|up gu [M, 2F] instead (plain row map, no bias / act / residual). */
+int ta_gemm_set_swiglu_bwd(const void* gu_bf16, void* dgu_bf16);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */

@@ -468,3 +468,21 @@ def test_relu_and_mix():
     ref.backward(dout)
     dob, dlg = ops.mix_bwd(dout, o, rw)
     assert relerr(dob, ot.grad) < 1e-2 and relerr(dlg, lt.grad) < 1e-4
+
+
+@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
+    """dX GEMM of down_proj with the SwiGLU backward in its epilogue == GEMM followed by ta_swiglu_bwd."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    M, F, K = 700, 768, 256
+    dx, W = rnd(M, K, seed=1, dtype=BF16), rnd(F, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    gu = rnd(M, 2 * F, seed=3, dtype=BF16)
+    dgu = torch.zeros(M, 2 * F, device=DEV, dtype=BF16)
+    ops.gemm_nt(dx, W, out_dtype=BF16, swiglu_bwd=(gu, dgu))
+    dact = dx.float() @ W.float().T
+    g, u = gu[:, :F].float(), gu[:, F:].float()
+    sg = torch.sigmoid(g)
+    ref = torch.cat([dact * u * sg * (1 + g * (1 - sg)), dact * g * sg], 1)
+    assert relerr(dgu, ref) < 1.5e-2
+    assert relerr(ops.gemm_nt(dx, W, out_dtype=F32), dact) < 2e-3             # one-shot

@@ -1,6 +1,7 @@
 // ta355 composite ops: the layer loops of the hot path, orchestrated on the host side of the C ABI so a
 // binding makes one call per reference nn.Module boundary (see include/ta355.h).  Pure kernel launches on
 // the caller's stream: no allocation, no synchronisation, graph-capturable.
+#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 #include "../../include/ta355.h"
@@ -493,8 +494,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     const LmLayerTape& p = store[l];
     // ---- MLP: x2 = x1 + down(silu(gate) * up)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
+    // Measured (same box, 3 runs each): fusing the SwiGLU backward into this GEMM's epilogue makes the step 0.4 ms SLOWER
+    // (54.8 vs 54.3 ms) -- at one workgroup per CU nothing overlaps an epilogue, so bytes moved there (gate|up read,
+    // d(gate|up) written in 32-B pieces) cost more than the separate streaming kernel at 6 TB/s.  Off unless asked for.
+    static const bool fuse_swiglu = [] { const char* e = getenv("TA355_FUSE_SWIGLU_BWD"); return e && *e == '1'; }();
+    if (fuse_swiglu) RC(ta_gemm_set_swiglu_bwd(p.gu, s.dgu));
     RC(gemm(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, st));
-    RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
+    if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
     RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, 0, st));
     RC(ta_rmsnorm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt, s.dxb, nullptr, M, d.D, 0, st));

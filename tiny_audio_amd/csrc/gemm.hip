@@ -38,6 +38,9 @@ struct GemmArgs {
   // K extension (LoRA): after the K columns of A / W the contraction continues over K2 more columns taken from
   // A2 [M, K2] (row stride lda2) and W2 [N, K2]:  C = A W^T + A2 W2^T  in one accumulator pass
   const bf16_t* A2; const bf16_t* W2; int K2; long lda2;
+  // fused SwiGLU backward (LM): the GEMM result is d(act) [M, N = F]; instead of storing it, the epilogue reads gate|up
+  // from sw_gu [M, 2F] and writes d(gate|up) to sw_dgu [M, 2F]  (plain row map only)
+  const bf16_t* sw_gu; bf16_t* sw_dgu;
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
 };
@@ -87,7 +90,25 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
     }
-    if (OUT_BF16) {
+    if (OUT_BF16 && p.sw_gu) {                                  // block-uniform
+      if (in) {
+        const long go = roff * 2 + n;                            // row m of [M, 2F]: roff = m * F
+        const uint2 gv = *(const uint2*)(p.sw_gu + go), uv = *(const uint2*)(p.sw_gu + go + p.N);
+        const float gt[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
+        const float up[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
+        float dg[4], du[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float sg = 1.f / (1.f + __expf(-gt[q]));
+          dg[q] = v[q] * up[q] * (sg * (1.f + gt[q] * (1.f - sg)));
+          du[q] = v[q] * gt[q] * sg;
+        }
+        uint2 w; w.x = pack2bf(dg[0], dg[1]); w.y = pack2bf(dg[2], dg[3]);
+        *(uint2*)(p.sw_dgu + go) = w;
+        w.x = pack2bf(du[0], du[1]); w.y = pack2bf(du[2], du[3]);
+        *(uint2*)(p.sw_dgu + go + p.N) = w;
+      }
+    } else if (OUT_BF16) {
       o[j].x = pack2bf(v[0], v[1]);
       o[j].y = pack2bf(v[2], v[3]);
       if (in && (!wide || (j == NT - 1 && (NT & 1)))) *(uint2*)(Cb + (roff + n) * 2) = o[j];
@@ -95,7 +116,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
-  if (OUT_BF16 && wide) {
+  if (OUT_BF16 && wide && !p.sw_gu) {
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
@@ -541,6 +562,14 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
                             splits, splitk_ws, nullptr, nullptr, nullptr, st);
 }
 
+static thread_local const void* g_sw_gu = nullptr;
+static thread_local void* g_sw_dgu = nullptr;
+// Arms the NEXT ta_gemm_bf16_nt* call on this thread: its bf16 result d(act) [M, F] is not stored; d(gate|up) [M, 2F] is
+// written instead from gate|up [M, 2F] (SwiGLU backward fused into the down-projection's dX GEMM epilogue).
+extern "C" int ta_gemm_set_swiglu_bwd(const void* gu, void* dgu) {
+  g_sw_gu = gu; g_sw_dgu = dgu;
+  return TA_OK;
+}
 static thread_local const void* g_ext_A2 = nullptr;
 static thread_local const void* g_ext_W2 = nullptr;
 static thread_local int g_ext_K2 = 0;
@@ -559,6 +588,8 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
                                   const float* bias, const float* residual,
                                   int act, int out_bf16, int splits, float* splitk_ws,
                                   const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
+  const void* sw_gu = g_sw_gu; void* sw_dgu = g_sw_dgu;
+  g_sw_gu = nullptr; g_sw_dgu = nullptr;                                // one-shot, like the K extension
   const void *xA2 = g_ext_A2, *xW2 = g_ext_W2;
   const int xK2 = g_ext_K2;
   g_ext_A2 = nullptr; g_ext_W2 = nullptr; g_ext_K2 = 0;          // one-shot: consumed by this call whatever its outcome
@@ -575,6 +606,8 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
   if (seg && a_rpb <= 0) a.a_rpb = 0x7fffffff;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = g_ext_lda2;
+  a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
+  if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;
   if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
   a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
   a.splits = splits > 1 ? splits : 1;

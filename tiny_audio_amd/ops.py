@@ -34,10 +34,12 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None):
+            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile)."""
     _req(A, BF16); _req(W, BF16)
+    if swiglu_bwd is not None:          # (gu [M, 2F], dgu [M, 2F]): the result d(act) is consumed in the epilogue
+        check(lib().ta_gemm_set_swiglu_bwd(ptr(swiglu_bwd[0]), ptr(swiglu_bwd[1])), "ta_gemm_set_swiglu_bwd")
     if k_ext is not None:
         A2, W2 = k_ext
         _req(A2, BF16); _req(W2, BF16)
