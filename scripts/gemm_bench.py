@@ -65,7 +65,8 @@ if only in ("all", "attn"):
         K_ = torch.randn(B, Hkv, L, hd, device=DEV).to(BF16)
         Lp = ops.pad64(L)
         VT = torch.zeros(B, Hkv, hd, Lp, device=DEV, dtype=BF16); VT[..., :L] = torch.randn(B, Hkv, hd, L, device=DEV).to(BF16)
-        t = timeit(lambda: ops.attention_fwd(Q, K_, VT, L, causal, hd ** -0.5, None, want_lse=causal))
+        sc = float(os.environ.get('ATTN_SCALE', hd ** -0.5))
+        t = timeit(lambda: ops.attention_fwd(Q, K_, VT, L, causal, sc, None, want_lse=causal))
         fl = 4.0 * B * Hq * L * L * hd * (0.5 if causal else 1.0)
         res[name] = round(fl / t / 1e12, 1)
         print(f"{name:12s} {t * 1e6:8.1f} us  {res[name]:7.1f} TF/s", flush=True)

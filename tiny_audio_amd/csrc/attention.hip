@@ -17,6 +17,7 @@
 //   "row tiles"  [64 rows][HD]   XOR-swizzled 16-B chunks -> conflict-free ds_read_b128 fragments
 //   "col tiles"  [HD rows][64]   8-B granules XOR-swizzled by the row -> conflict-free ds_read_b64 halves
 //                (first version padded rows to 144 B: SQ_LDS_BANK_CONFLICT showed 30 % conflict cycles)
+#include <cstdlib>
 #include "common.h"
 
 #define KV_TILE 64
@@ -285,6 +286,181 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// ============================================================================ forward, short sequences (LM, L <= 192)
+// One workgroup = one (clip, kv head): ALL keys / values of the sequence are staged once (3 K row tiles + 3 V^T column
+// tiles, 102 KB of LDS) and shared by every query of the GQA group -- 2 q heads x 192 queries = 12 waves x 2 sub-tiles
+// of 16 rows.  After the single staging barrier each wave walks its causal key range alone: no barriers, no
+// re-staging, and B * Hkv = 256 workgroups are one round of the 256 CUs.  (The tiled kernel above spent its time in
+// 1536 small workgroups that each re-staged K / V for 64 queries: 42 us per layer for 4.8 GFLOP.)
+template <int HD, int MAXT, int QSUB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ VT, bf16_t* __restrict__ O,
+                                                           float* __restrict__ LSE, const int* __restrict__ kmask,
+                                                           int B, int Hq, int Hkv, int L, int Lp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ND = HD / 16, VBYTES = (HD + 16) * CT_STRIDE, NT_ = NW * 64;
+  char* Ks = smem;                                   // MAXT row tiles
+  char* Vs = smem + MAXT * RowTile<HD>::BYTES;       // MAXT column tiles, each with its ones-row block
+  int* Ms = (int*)(Vs + MAXT * VBYTES);              // key mask, MAXT * 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
+  // query chunks of 16 * QSUB rows: chunk c belongs to q head c / cph; a wave takes chunk `wave` and then its mirror
+  // image (nchunk - 1 - wave), which pairs a short causal key range with a long one
+  const int grp = Hq / Hkv, cph = (L + 16 * QSUB - 1) / (16 * QSUB), nchunk = grp * cph;
+  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
+  const bf16_t* Vb = VT + ((long)(b * Hkv + hk) * HD) * Lp;
+  const float sl2 = scale * LOG2E;
+  const int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  // ---- stage everything once.  All global loads are issued before the first LDS store (MAXT * 1024 16-B chunks of K
+  // and of V^T = 4 + 4 per thread): a load -> store loop per tile serialises 12 round trips to memory (measured: the
+  // kernel took 38 us that way, no faster than the tiled one).
+  constexpr int PER = (MAXT * 64 * (HD / 8) + NT_ - 1) / NT_;
+  uint4 kreg[PER], vreg[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+    if (t < ntiles) {
+      const int r = w / (HD / 8), c = w % (HD / 8);
+      int gr = t * KV_TILE + r; if (gr > L - 1) gr = L - 1;
+      kreg[i] = *(const uint4*)(Kb + (long)gr * HD + c * 8);
+      const int vr = w >> 3, vc = w & 7;
+      vreg[i] = *(const uint4*)(Vb + (long)vr * Lp + t * KV_TILE + vc * 8);
+    }
+  }
+  for (int i = tid; i < ntiles * 16 * (CT_STRIDE / 4); i += NT_) {
+    const int t = i / (16 * (CT_STRIDE / 4)), w = i % (16 * (CT_STRIDE / 4)), r = w / (CT_STRIDE / 4);
+    ((uint32_t*)(Vs + t * VBYTES + HD * CT_STRIDE))[w] = r == 0 ? 0x3f803f80u : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+    if (t < ntiles) {
+      const int r = w / (HD / 8), c = w % (HD / 8);
+      *(uint4*)(Ks + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c)) = kreg[i];
+      const int vr = w >> 3, vc = w & 7;
+      const uint4 x = vreg[i];
+      const uint4 y = (vr & 1) ? make_uint4(x.z, x.w, x.x, x.y) : x;
+      *(uint4*)(Vs + t * VBYTES + vr * CT_STRIDE + ((vc ^ ((vr & 15) >> 1)) << 4)) = y;
+    }
+  }
+  for (int i = tid; i < ntiles * 64; i += NT_) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+  const int chunk = pass == 0 ? wave : nchunk - 1 - wave;
+  if (chunk >= nchunk || (pass == 1 && chunk < NW)) continue;          // wave-uniform
+  const int h = hk * grp + chunk / cph;
+  const int q0 = (chunk % cph) * 16 * QSUB;
+  const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
+  bf16x8 qf[QSUB][HD / 32];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) {
+    int qr = q0 + sub * 16 + l15; if (qr > L - 1) qr = L - 1;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf[sub][ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+  }
+  f32x4 o[QSUB][ND + 1];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub)
+#pragma unroll
+    for (int i = 0; i <= ND; ++i) o[sub][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[QSUB];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) m_run[sub] = NEG_BIG;
+  const int my_tiles = min(ntiles, (q0 + 16 * QSUB - 1) / KV_TILE + 1);      // causal: keys beyond the wave's last query never count
+  for (int t = 0; t < my_tiles; ++t) {
+    const int key0 = t * KV_TILE;
+    const char* Kt = Ks + t * RowTile<HD>::BYTES;
+    const char* Vt = Vs + t * VBYTES;
+    f32x4 s[QSUB][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int sub = 0; sub < QSUB; ++sub) s[sub][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Kt + RowTile<HD>::off(kt * 16 + l15, ks * 4 + g));
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          s[sub][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[sub][ks], s[sub][kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);             // keep the K fragments of one key block live at a time (VGPR budget)
+    }
+#pragma unroll
+    for (int sub = 0; sub < QSUB; ++sub) {
+      const int qrow = q0 + sub * 16 + l15;
+      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (key0 + KV_TILE - 1 <= q0 + sub * 16);
+      if (!full) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const int4 mk = *(const int4*)(Ms + key0 + kt * 16 + g * 4);
+          const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kt * 16 + g * 4 + r;
+            const bool v = (key <= qrow) & (mkv[r] != 0);
+            s[sub][kt][r] = v ? s[sub][kt][r] : -INFINITY;
+          }
+        }
+      }
+      float mloc = max3(s[sub][0][0], s[sub][0][1], s[sub][0][2]);
+      mloc = max3(mloc, s[sub][0][3], s[sub][1][0]);
+      mloc = max3(mloc, s[sub][1][1], s[sub][1][2]);
+      mloc = max3(mloc, s[sub][1][3], s[sub][2][0]);
+      mloc = max3(mloc, s[sub][2][1], s[sub][2][2]);
+      mloc = max3(mloc, s[sub][2][3], s[sub][3][0]);
+      mloc = max3(mloc, s[sub][3][1], s[sub][3][2]);
+      mloc = fmaxf(mloc, s[sub][3][3]);
+      const float m_new = fmaxf(m_run[sub], group_max(mloc));
+      if (__any(m_new != m_run[sub])) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[sub] - m_new) * sl2);
+#pragma unroll
+        for (int i = 0; i <= ND; ++i) { o[sub][i][0] *= alpha; o[sub][i][1] *= alpha; o[sub][i][2] *= alpha; o[sub][i][3] *= alpha; }
+        m_run[sub] = m_new;
+      }
+      const float mb = m_new * sl2;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[sub][kt][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sl2, -mb));
+    }
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 pb[QSUB];
+#pragma unroll
+      for (int sub = 0; sub < QSUB; ++sub) pb[sub] = pack_p(s[sub][2 * kp], s[sub][2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt <= ND; ++dt) {
+        const bf16x8 va = read_colfrag(Vt, dt * 16 + l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          o[sub][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[sub], o[sub][dt], 0, 0, 0);
+        if (dt & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) {
+    const int qrow = q0 + sub * 16 + l15;
+    const float l_run = __shfl(o[sub][ND][0], l15, 64);
+    if (qrow < L) {
+      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      bf16_t* orow = O + ((long)b * L + qrow) * ((long)Hq * HD) + (long)h * HD;
+      // adjacent 16-column blocks are exchanged between lane rows (v_permlane16_swap) so that a lane stores 8
+      // consecutive columns: 64 contiguous bytes per row per store instead of 32 (see gemm.hip epilogue_strip)
+#pragma unroll
+      for (int dt = 0; dt < ND; dt += 2) {
+        const uint32_t x0 = pack2bf(o[sub][dt][0] * inv, o[sub][dt][1] * inv), x1 = pack2bf(o[sub][dt][2] * inv, o[sub][dt][3] * inv);
+        const uint32_t y0 = pack2bf(o[sub][dt + 1][0] * inv, o[sub][dt + 1][1] * inv), y1 = pack2bf(o[sub][dt + 1][2] * inv, o[sub][dt + 1][3] * inv);
+        const auto a = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        *(uint4*)(orow + 16 * (dt + (g & 1)) + 8 * (g >> 1)) = make_uint4(a[0], c[0], a[1], c[1]);
+      }
+      if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
+    }
+  }
+  }   // pass
+}
+
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
 template <int HD, bool CAUSAL>
@@ -507,6 +683,21 @@ extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, vo
                                 hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
+  // LM with a short prompt: the whole sequence of a (clip, kv head) lives in LDS, one workgroup serves the GQA group
+  {
+    const int grp = Hq / Hkv;
+    static const bool gqa_off = [] { const char* e = getenv("TA355_ATTN_GQA"); return e && *e == '0'; }();
+    if (!gqa_off && head_dim == 128 && causal && L <= 192 && grp * ((L + 31) / 32) <= 12) {
+      constexpr int MAXT = 3, QS = 2, NW = 6;          // 6 waves x 2 passes x 32 queries = 384 query rows per workgroup
+      const size_t lds = MAXT * (RowTile<128>::BYTES + (128 + 16) * CT_STRIDE) + MAXT * 64 * 4;
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_gqa_kernel<128, MAXT, QS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+      TA_LAUNCH((attn_fwd_gqa_kernel<128, MAXT, QS, NW>), dim3(B * Hkv), dim3(NW * 64), lds, st, (const bf16_t*)Q, (const bf16_t*)K,
+                (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, Lp, scale);
+      TA_CHECK_LAUNCH();
+      return TA_OK;
+    }
+  }
   // encoder (hd 64, S = 500, non-causal): 128 query rows per workgroup; LM (hd 128, short causal L): 64
   const int qsub = (head_dim == 64) ? 2 : 1;
   dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64 * qsub), B * Hkv)), blk(256);
