@@ -51,11 +51,12 @@ def rotate_half(x):
 
 
 def apply_rope(x, cos, sin):
-    """x [B, heads, S, hd]; cos/sin [S, rot]; first ``rot`` dims rotated
-    (modeling_glmasr.py:153-168: partial rotary; Qwen3 uses rot == hd)."""
+    """x [B, heads, S, hd]; cos/sin [S, rot] (or [B, S, rot] for per-clip position ids); first ``rot`` dims
+    rotated (modeling_glmasr.py:153-168: partial rotary; Qwen3 uses rot == hd)."""
     rot = cos.shape[-1]
     xr, xp = x[..., :rot], x[..., rot:]
-    xr = xr * cos[None, None] + rotate_half(xr) * sin[None, None]
+    c, s_ = (cos[None, None], sin[None, None]) if cos.ndim == 2 else (cos[:, None], sin[:, None])
+    xr = xr * c + rotate_half(xr) * s_
     return np.concatenate([xr, xp], axis=-1).astype(x.dtype)
 
 

@@ -125,8 +125,10 @@ def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, gr
     dk = dkr.reshape(B, hkv, g, L, hd).sum(2)
     dv = dvr.reshape(B, hkv, g, L, hd).sum(2)
     # rope backward: y = x*cos + rot(x)*sin  =>  dx = dy*cos - rot(dy*sin)
+    cb, sb = (cos[None, None], sin[None, None]) if cos.ndim == 2 else (cos[:, None], sin[:, None])   # per-clip position ids
+
     def rope_bwd(dy):
-        return dy * cos[None, None] - rotate_half(dy * sin[None, None])
+        return dy * cb - rotate_half(dy * sb)
     dqn = rope_bwd(dq).transpose(0, 2, 1, 3)
     dkn = rope_bwd(dk).transpose(0, 2, 1, 3)
     dq0 = rms_bwd_dx(dqn, c["q0"], c["rq"], w[p + "self_attn.q_norm.weight"]).reshape(B, L, hq * hd)

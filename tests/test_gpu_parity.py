@@ -232,6 +232,38 @@ def test_lm_text_only_and_dx_vs_oracle():
     assert relmax(got_dx[valid], ref_dx[valid]) < 5e-2
 
 
+def test_lm_long_sequence_and_single_clip_vs_oracle():
+    """Edge shapes: L = 260 (> 192: the tiled attention kernels instead of the whole-sequence one; 5 key tiles, ragged
+    last tile) with left AND right padding in one batch, and B = 1 with L = 33 (single partial tile)."""
+    wL = OW.init_lm(TRUE_LM, 1)
+    lm = Qwen3MI355X(LMConfig(TRUE_LM), DEV).load_state_dict_hf(wL)
+    rng = np.random.RandomState(12)
+    for B, L in ((2, 260), (1, 33)):
+        ids = rng.randint(0, 4900, (B, L)).astype(np.int64)
+        att = np.ones((B, L), np.int64)
+        lab = np.full((B, L), -100, np.int64)
+        if B == 2:
+            att[0, 230:] = 0; att[1, :17] = 0                        # right-padded clip 0, left-padded clip 1
+            lab[0, 150:230] = ids[0, 150:230]; lab[1, 200:260] = ids[1, 200:260]
+        else:
+            lab[0, 20:33] = ids[0, 20:33]
+        pos = np.clip(np.cumsum(att, -1) - 1, 0, None).astype(np.int32)
+        rows, tg, n = ops.label_rows(torch.from_numpy(lab).to(DEV))
+        n = int(n.item())
+        loss, nll, logits, ctx = lm.forward_loss(torch.from_numpy(ids).to(DEV), None, None, torch.from_numpy(att).to(DEV).int(),
+                                                 rows, tg, n, 1.0 / n, want_logits=True, pos=torch.from_numpy(pos).to(DEV))
+        x0 = wL["model.embed_tokens.weight"][ids]
+        ref_logits, cache = OQ.lm_forward(x0, att, wL, TRUE_LM, position_ids=None if B == 1 else pos)
+        ref_loss, dlogits, n_ref = OQ.causal_lm_loss(ref_logits, lab)
+        assert n == n_ref and abs(float(loss) - float(ref_loss)) < 5e-3 * float(ref_loss)
+        valid = att.astype(bool)
+        got = npy(logits).reshape(B, L, -1)[:, :, :TRUE_LM["vocab"]]
+        assert logits_close(got[valid], ref_logits[valid])
+        _, d_emb, _ = lm.backward_from_ctx(ctx, 1, want_d_embeds=True)
+        ref_dx = OQ.lm_backward_dx(dlogits, wL, TRUE_LM, cache)
+        assert cosine(npy(d_emb).reshape(B, L, -1)[valid], ref_dx[valid]) > 0.999
+
+
 # ============================================================================ LoRA stage 2 (row a11, BASELINE configs[4])
 def _lora_case(cfg, wL, lo, x_ids, att, lab):
     """HIP LM with adapters vs oracle: loss, logits, d(inputs_embeds), every adapter gradient."""
