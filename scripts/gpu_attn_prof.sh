@@ -1,9 +1,14 @@
 #!/bin/bash
-# kernel-time A/B of the LM attention forward variants under rocprofv3 (GPU durations, not host launch rate)
+# kernel-time A/B of attention variants under rocprofv3 (GPU durations, not host launch rate): VAR=ENVNAME VALS="a b"
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+VAR=${VAR:-TA355_ATTN_GQA}; VALS=${VALS:-"1 0"}
 cd /tmp && export TMPDIR=/tmp
-for f in 1 0; do
-  TA355_ATTN_GQA=$f timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_attn$f -o a -- python $REPO/scripts/gemm_bench.py --only attn --reps 30 > /dev/null 2>&1
-  echo "gqa=$f"; grep -E "attn_fwd" $REPO/gpurun_out/prof_attn$f/a_kernel_stats.csv | cut -d, -f1-4 | cut -c1-60,200-400 | sed 's/"//g' | awk -F, '{print $1, $(NF-2), $(NF-1), $NF}' | cut -c1-160
-  rm -f $REPO/gpurun_out/prof_attn$f/a_kernel_trace.csv
+for f in $VALS; do
+  env $VAR=$f timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_attn_$f -o a -- python $REPO/scripts/gemm_bench.py --only attn --reps 30 > /dev/null 2>&1
+  python - <<PY
+import csv
+for r in csv.DictReader(open("$REPO/gpurun_out/prof_attn_$f/a_kernel_stats.csv")):
+    if "attn_fwd" in r["Name"]: print("$VAR=$f", r["Name"][:44], r["Calls"], round(float(r["AverageNs"])/1e3,1), "us")
+PY
+  rm -rf $REPO/gpurun_out/prof_attn_$f
 done
