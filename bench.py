@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
     ap.add_argument("--projector", choices=["mlp", "moe", "qformer", "mosa"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
+    ap.add_argument("--proj-hidden", type=int, default=1024, help="MLP projector hidden width (2048 = the 'embedded' recipe)")
     ap.add_argument("--lora", action="store_true",
                     help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +80,7 @@ def main():
     from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
     from oracle import weights as OW
 
-    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=1024, audio_token_dropout=a.dropout,
+    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
                     use_lora=a.lora, freeze_projector=a.lora)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
@@ -162,17 +163,17 @@ def main():
                         "hbm_kernels": hbm_kernel_rates(B, L, cfg, fe, wav, lens)}
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora:
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024:
         cpu = cpu_baseline(model, cfg, L)
 
     if rank == 0:
-        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full")
+        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden)
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
                "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
-                                       else "configs[1]: MLP projector (H=D=1024)" if a.projector == "mlp" else
+                                       else ("configs[1]: MLP projector (H=%d, D=1024)" % a.proj_hidden) if a.projector == "mlp" else
                                        "QFormer projector (2 layers, 16 heads, windows of 15 -> 3 queries, 102 audio tokens)" if a.projector == "qformer" else
                                        "MOSA projector (2 stride-2 convs, 4 dense experts of width 4096)" if a.projector == "mosa" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
