@@ -257,6 +257,10 @@ int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2);
  * result is d(act) [M, N = F] (dX of Qwen3MLP.down_proj, TF:models/qwen3/modeling_qwen3.py:70-83); it is not stored --
  * d(gate|up) [M, 2F] is written to dgu from gate|up gu [M, 2F] instead (plain row map, no bias / act / residual). */
 int ta_gemm_set_swiglu_bwd(const void* gu_bf16, void* dgu_bf16);
+/* The NEXT ta_gemm_bf16_nt* call on this thread (one-shot) adds a bf16 residual with the row map of C (it may alias C);
+ * that call's `residual` must be NULL.  GlmAsrEncoderLayer residual adds in the model dtype
+ * (TF:models/glmasr/modeling_glmasr.py:249-270 on a bf16 model). */
+int ta_gemm_set_residual_bf16(const void* residual_bf16);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */
@@ -265,6 +269,8 @@ int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launche
 
 int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
                      const float* rowscale, int M, int H, float eps, hipStream_t st);
+int ta_layernorm_bf16(const void* x_bf16, const float* w, const float* b, void* y_bf16, float* y_f32, const float* rowscale,
+                      int M, int H, float eps, hipStream_t st);            /* same, the row is read as bf16 */
 int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, float* y_f32, float* rstd, int M, int H,
                    float eps, int act_gelu, hipStream_t st);
 int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd, const float* w, const float* dres,

@@ -486,3 +486,32 @@ def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     ref = torch.cat([dact * u * sg * (1 + g * (1 - sg)), dact * g * sg], 1)
     assert relerr(dgu, ref) < 1.5e-2
     assert relerr(ops.gemm_nt(dx, W, out_dtype=F32), dact) < 2e-3             # one-shot
+
+
+@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+def test_gemm_bf16_residual_in_place(variant, monkeypatch):
+    """x += A W^T + b with a bf16 residual stream aliased to the output (the encoder's residual GEMMs)."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    M, N, K = 900, 1280, 256
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    bias, xr = rnd(N, seed=3), rnd(M, N, seed=4, dtype=BF16)
+    ref = A.float() @ W.float().T + bias + xr.float()
+    x = xr.clone()
+    ops.gemm_nt(A, W, bias=bias, out=x, residual_bf16=x)
+    assert relerr(x, ref) < 1.5e-2
+    out = ops.gemm_nt(A, W, bias=bias, out_dtype=F32, residual_bf16=xr)         # f32 output, bf16 residual, not aliased
+    assert relerr(out, ref) < 2e-3
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32), A.float() @ W.float().T) < 2e-3     # one-shot
+
+
+def test_layernorm_bf16_input():
+    M, H = 517, 1280
+    x = rnd(M, H, seed=1, scale=2.0, dtype=BF16)
+    w, b = 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    keep = (torch.rand(M, generator=torch.Generator().manual_seed(4)) < 0.8).float().to(DEV)
+    ref = torch.nn.functional.layer_norm(x.float(), (H,), w, b, 1e-5)
+    yb, yf = ops.layernorm(x, w, b, out_f32=True)
+    assert relerr(yf, ref) < 1e-5 and relerr(yb, ref) < 1e-2
+    yb2, _ = ops.layernorm(x, w, b, rowscale=keep)
+    assert relerr(yb2, ref * keep[:, None]) < 1e-2

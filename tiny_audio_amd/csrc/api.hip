@@ -24,7 +24,7 @@ EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
   EncWs e;
   e.x0 = c.take<bf16_t>((size_t)B * (T + 2) * w->n_mels);
   e.x1 = c.take<bf16_t>((size_t)B * (T + 2) * H);
-  e.xr = c.take<float>((size_t)M * H);
+  e.xr = (float*)c.take<float>((size_t)M * H);      // residual stream (bf16 by default: the fp32 size is reserved)
   e.xn = c.take<bf16_t>((size_t)M * H);
   e.qkv = c.take<bf16_t>((size_t)M * 3 * H);
   e.q = c.take<bf16_t>((size_t)M * H);
@@ -56,21 +56,34 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   RC(ta_zero_pad_rows(e.x1, B, T, H, st));
   RC(ta_gemm_bf16_nt(e.x0, w->conv1_w, e.x1, B * T, H, 3 * NM, NM, T, (long)(T + 2) * NM, H, T, (long)(T + 2) * H, H,
                      w->conv1_b, nullptr, 1, 1, 1, nullptr, st));
+  // Residual stream: bf16, the dtype the reference's encoder runs in (model_dtype bfloat16: every residual add and
+  // LayerNorm input is bf16 there).  It halves the bytes of the two residual GEMM epilogues and of the LayerNorm reads
+  // per layer -- HBM time that nothing overlaps.  TA355_ENC_RES_F32=1 keeps an fp32 stream instead.
+  static const bool res_f32 = [] { const char* v = getenv("TA355_ENC_RES_F32"); return v && *v == '1'; }();
+  const int rb = res_f32 ? 0 : 1;
+  auto ln = [&](const float* gw, const float* gb, void* yb, float* yf, const float* rowscale) -> int {
+    return rb ? ta_layernorm_bf16(e.xr, gw, gb, yb, yf, rowscale, M, H, w->ln_eps, st)
+              : ta_layernorm_f32(e.xr, gw, gb, yb, yf, rowscale, M, H, w->ln_eps, st);
+  };
+  auto res_gemm = [&](const void* A, const void* Wm, int K, const float* bias) -> int {      // xr += A Wm^T + bias
+    if (rb) { RC(ta_gemm_set_residual_bf16(e.xr)); return gemm(A, Wm, e.xr, M, H, K, bias, nullptr, 0, 1, st); }
+    return gemm(A, Wm, e.xr, M, H, K, bias, e.xr, 0, 0, st);
+  };
   RC(ta_gemm_bf16_nt(e.x1, w->conv2_w, e.xr, M, H, 3 * H, 2L * H, S, (long)(T + 2) * H, H, 0, 0, 0, w->conv2_b, nullptr,
-                     1, 0, 1, nullptr, st));
+                     1, rb, 1, nullptr, st));
   const float scale = 0.125f;   // head_dim ** -0.5, head_dim = 64
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_enc_layer& L = w->layers[l];
-    RC(ta_layernorm_f32(e.xr, L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr, M, H, w->ln_eps, st));
+    RC(ln(L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr));
     RC(gemm(e.xn, L.wqkv, e.qkv, M, 3 * H, H, L.bqkv, nullptr, 0, 1, st));
     RC(ta_enc_qkv_post(e.qkv, w->rope_cos, w->rope_sin, e.q, e.k, e.vt, B, nh, S, Sp, st));
     RC(ta_attention_fwd(e.q, e.k, e.vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, st));
-    RC(gemm(e.ao, L.wo, e.xr, M, H, H, L.bo, e.xr, 0, 0, st));
-    RC(ta_layernorm_f32(e.xr, L.ln2_w, L.ln2_b, e.xn, nullptr, nullptr, M, H, w->ln_eps, st));
+    RC(res_gemm(e.ao, L.wo, H, L.bo));
+    RC(ln(L.ln2_w, L.ln2_b, e.xn, nullptr, nullptr));
     RC(gemm(e.xn, L.w1, e.hf, M, F, H, L.b1, nullptr, 1, 1, st));
-    RC(gemm(e.hf, L.w2, e.xr, M, H, F, L.b2, e.xr, 0, 0, st));
+    RC(res_gemm(e.hf, L.w2, F, L.b2));
   }
-  RC(ta_layernorm_f32(e.xr, w->norm_w, w->norm_b, out_bf16, out_f32, frame_keep, M, H, w->ln_eps, st));
+  RC(ln(w->norm_w, w->norm_b, out_bf16, out_f32, frame_keep));
   return TA_OK;
 }
 

@@ -41,6 +41,7 @@ struct GemmArgs {
   // fused SwiGLU backward (LM): the GEMM result is d(act) [M, N = F]; instead of storing it, the epilogue reads gate|up
   // from sw_gu [M, 2F] and writes d(gate|up) to sw_dgu [M, 2F]  (plain row map only)
   const bf16_t* sw_gu; bf16_t* sw_dgu;
+  int res_bf16;        // the residual is bf16 (same row map as C), not f32
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
 };
@@ -86,8 +87,14 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
       }
       if (HAS_RES) {
-        const float4 r = *(const float4*)(p.res + roff + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        if (p.res_bf16) {
+          const uint2 r = *(const uint2*)((const bf16_t*)p.res + roff + n);
+          v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+          v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+        } else {
+          const float4 r = *(const float4*)(p.res + roff + n);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
       }
     }
     if (OUT_BF16 && p.sw_gu) {                                  // block-uniform
@@ -562,6 +569,13 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
                             splits, splitk_ws, nullptr, nullptr, nullptr, st);
 }
 
+static thread_local const void* g_res_bf16 = nullptr;
+// Arms the NEXT ta_gemm_bf16_nt* call on this thread with a bf16 residual (same row map as C; may alias C): the
+// encoder's residual stream in the reference's own dtype.  That call's `residual` argument must be NULL.
+extern "C" int ta_gemm_set_residual_bf16(const void* residual_bf16) {
+  g_res_bf16 = residual_bf16;
+  return TA_OK;
+}
 static thread_local const void* g_sw_gu = nullptr;
 static thread_local void* g_sw_dgu = nullptr;
 // Arms the NEXT ta_gemm_bf16_nt* call on this thread: its bf16 result d(act) [M, F] is not stored; d(gate|up) [M, 2F] is
@@ -588,6 +602,9 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
                                   const float* bias, const float* residual,
                                   int act, int out_bf16, int splits, float* splitk_ws,
                                   const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
+  const void* resb = g_res_bf16;
+  g_res_bf16 = nullptr;
+  if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
   const void* sw_gu = g_sw_gu; void* sw_dgu = g_sw_dgu;
   g_sw_gu = nullptr; g_sw_dgu = nullptr;                                // one-shot, like the K extension
   const void *xA2 = g_ext_A2, *xW2 = g_ext_W2;
@@ -607,6 +624,8 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = g_ext_lda2;
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
+  a.res_bf16 = resb != nullptr;
+  if (resb && splits > 1) return TA_ERR_ARG;
   if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;
   if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
   a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);

@@ -10,7 +10,8 @@
 #define MAXV_LIMIT 20   // float4 per lane -> rows up to 64*4*20 = 5120 columns
 // MAXV (float4 per lane held in registers) is a template parameter: 4 (H<=1024), 8 (<=2048), 20 (<=5120)
 
-template <int MAXV, bool OUT_BF16, bool OUT_F32>
+// IN_BF16: the row is read as bf16 (the encoder's bf16 residual stream, as the reference's bf16 model keeps it)
+template <int MAXV, bool OUT_BF16, bool OUT_F32, bool IN_BF16 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, bf16_t* __restrict__ yb,
                                                         float* __restrict__ yf, const float* __restrict__ rowscale,
@@ -20,12 +21,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int nv = H >> 2;
   const float4* xr = (const float4*)(x + (long)row * H);
+  const uint2* xb = (const uint2*)((const bf16_t*)x + (long)row * H);
   float4 v[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
-    if (c < nv) { v[i] = xr[c]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    if (c < nv) {
+      if (IN_BF16) {
+        const uint2 u = xb[c];
+        v[i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+      } else {
+        v[i] = xr[c];
+      }
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
   }
   const float mean = wave_sum(s) / (float)H;
   float q = 0.f;
@@ -174,6 +184,24 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     else if ((H) <= 2048) { CALL(8); }    \
     else { CALL(20); }                    \
   } while (0)
+
+extern "C" int ta_layernorm_bf16(const void* x_bf16, const float* w, const float* b, void* y_bf16, float* y_f32,
+                                 const float* rowscale, int M, int H, float eps, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT || (!y_bf16 && !y_f32)) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(M, 4)), blk(256);
+  const float* x = (const float*)x_bf16;
+#define LNB_CALL(V)                                                                                              \
+  if (y_bf16 && y_f32)                                                                                           \
+    TA_LAUNCH((layernorm_kernel<V, true, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
+  else if (y_bf16)                                                                                               \
+    TA_LAUNCH((layernorm_kernel<V, true, false, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps); \
+  else                                                                                                           \
+    TA_LAUNCH((layernorm_kernel<V, false, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);
+  DISPATCH_MAXV(H, LNB_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
 
 extern "C" int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
                                 const float* rowscale, int M, int H, float eps, hipStream_t st) {

@@ -34,10 +34,13 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None):
+            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile)."""
     _req(A, BF16); _req(W, BF16)
+    if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
+        _req(residual_bf16, BF16)
+        check(lib().ta_gemm_set_residual_bf16(ptr(residual_bf16)), "ta_gemm_set_residual_bf16")
     if swiglu_bwd is not None:          # (gu [M, 2F], dgu [M, 2F]): the result d(act) is consumed in the epilogue
         check(lib().ta_gemm_set_swiglu_bwd(ptr(swiglu_bwd[0]), ptr(swiglu_bwd[1])), "ta_gemm_set_swiglu_bwd")
     if k_ext is not None:
@@ -61,6 +64,13 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
 
 
 def layernorm(x, w, b, eps=1e-5, rowscale=None, out_bf16=True, out_f32=False):
+    if x.dtype == BF16:
+        M, H = x.shape
+        yb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
+        yf = torch.empty((M, H), device=x.device, dtype=F32) if out_f32 else None
+        check(lib().ta_layernorm_bf16(ptr(x), ptr(w), ptr(b), ptr(yb), ptr(yf), ptr(rowscale), M, H, eps, stream()),
+              "ta_layernorm_bf16")
+        return yb, yf
     _req(x, F32)
     M, H = x.shape
     yb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
