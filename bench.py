@@ -211,10 +211,10 @@ def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
 
     Me, H = B * 500, cfg.audio_config.hidden_size
     Ml, D, F = B * L, cfg.text_config.hidden_size, cfg.text_config.intermediate_size
-    xe = torch.randn(Me, H, device=dev); we, be = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    xe = torch.randn(Me, H, device=dev).to(torch.bfloat16); we, be = torch.ones(H, device=dev), torch.zeros(H, device=dev)
     xl = torch.randn(Ml, D, device=dev); wl = torch.ones(D, device=dev)
     gu = torch.randn(Ml, 2 * F, device=dev).to(torch.bfloat16)
-    out = {"layernorm_kernel (encoder, f32 in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 6),
+    out = {"layernorm_kernel (encoder, bf16 residual stream in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 4),
            "rmsnorm_fwd_kernel (LM, f32 in -> bf16 out)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 6),
            "swiglu_fwd_kernel (LM, bf16 gate|up -> bf16)": rate(lambda: ops.swiglu_fwd(gu, F), Ml * F * 6),
            "logmel (f32 wav -> f32 [128, 1000]; exact-f32 DFT, VALU-bound)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000), reps=5)}
