@@ -515,3 +515,17 @@ def test_layernorm_bf16_input():
     assert relerr(yf, ref) < 1e-5 and relerr(yb, ref) < 1e-2
     yb2, _ = ops.layernorm(x, w, b, rowscale=keep)
     assert relerr(yb2, ref * keep[:, None]) < 1e-2
+
+
+def test_rmsnorm_bf16_stream():
+    """RMSNorm forward / backward with the input stream in bf16 == the f32 kernels on the same (bf16-rounded) values."""
+    M, H = 333, 1024
+    xb = rnd(M, H, seed=1, scale=1.5, dtype=BF16)
+    w = 1 + 0.1 * rnd(H, seed=2)
+    yb0, yf0, r0 = ops.rmsnorm_fwd(xb.float(), w, out_f32=True)
+    yb1, yf1, r1 = ops.rmsnorm_fwd(xb, w, out_f32=True)
+    assert torch.equal(yf0, yf1) and torch.equal(r0, r1) and torch.equal(yb0, yb1)
+    dy, dres = rnd(M, H, seed=3), rnd(M, H, seed=4)
+    dx0, dxb0, _ = ops.rmsnorm_bwd(dy, xb.float(), r0, w, dres=dres)
+    dx1, dxb1, _ = ops.rmsnorm_bwd(dy, xb, r1, w, dres=dres)
+    assert torch.equal(dx0, dx1) and torch.equal(dxb0, dxb1)

@@ -176,6 +176,13 @@ extern "C" int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x,
 
 // ============================================================================ Qwen3 LM
 namespace {
+// Residual stream of the LM (x_in / x1 of every layer, kept in the tape): bf16, the dtype the reference's LM runs in
+// (model_dtype bfloat16).  Halves the bytes of the o / down GEMM epilogues, of the RMSNorm reads (forward and
+// backward) and of the tape.  TA355_LM_RES_F32=1 keeps fp32 instead.  The gradient stream d(x) stays fp32.
+inline bool lm_res_bf16() {
+  static const bool v = [] { const char* e = getenv("TA355_LM_RES_F32"); return !(e && *e == '1'); }();
+  return v;
+}
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
@@ -352,7 +359,15 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     if (ext) { p.i_qkv = ext[l].g[0]; p.i_o = ext[l].g[1]; p.i_gu = ext[l].g[2]; p.i_d = ext[l].g[3]; }
     float* x_next = (l + 1 < w->n_layers) ? store[alias ? 0 : l + 1].x_in : x_final;
     bf16_t* xn = lora ? p.xn_s : s.xn;
-    RC(ta_rmsnorm_fwd(p.x_in, Lw.ln_in_w, xn, nullptr, p.r_in, M, d.D, w->eps, 0, st));
+    const bool rb = lm_res_bf16();
+    auto norm = [&](const float* x, const float* gw, bf16_t* y, float* r) -> int {
+      return rb ? ta_rmsnorm_fwd_bf16(x, gw, y, nullptr, r, M, d.D, w->eps, st) : ta_rmsnorm_fwd(x, gw, y, nullptr, r, M, d.D, w->eps, 0, st);
+    };
+    auto res_gemm = [&](const void* A, const void* Wm, float* out, int K, const float* res) -> int {   // out = res + A Wm^T
+      if (rb) { RC(ta_gemm_set_residual_bf16(res)); return gemm(A, Wm, out, M, d.D, K, nullptr, nullptr, 0, 1, st); }
+      return gemm(A, Wm, out, M, d.D, K, nullptr, res, 0, 0, st);
+    };
+    RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
     if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
     RC(gemm(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
@@ -365,15 +380,15 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     }
     RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
-    RC(gemm(p.ao, Lw.wo, p.x1, M, d.D, d.nq * d.hd, nullptr, p.x_in, 0, 0, st));
+    RC(res_gemm(p.ao, Lw.wo, p.x1, d.nq * d.hd, p.x_in));
     bf16_t* xn2 = lora ? p.xn2_s : s.xn;
     bf16_t* act = lora ? p.act_s : s.act;
-    RC(ta_rmsnorm_fwd(p.x1, Lw.ln_post_w, xn2, nullptr, p.r_post, M, d.D, w->eps, 0, st));
+    RC(norm(p.x1, Lw.ln_post_w, xn2, p.r_post));
     if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu));
     RC(gemm(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, st));
     RC(ta_swiglu_fwd(p.gu, act, M, d.F, st));
     if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d));
-    RC(gemm(act, Lw.wd, x_next, M, d.D, d.F, nullptr, p.x1, 0, 0, st));
+    RC(res_gemm(act, Lw.wd, x_next, d.F, p.x1));
   }
   return TA_OK;
 }
@@ -394,9 +409,11 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
   if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
   float* x = store[0].x_in;
   // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
-  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
+  if (lm_res_bf16()) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, x, M, d.D, w->vocab, st));
+  else RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
   RC(lm_layers_forward(w, d, B, L, kmask, pos, store, false, t.x_final, s, nullptr, nullptr, nullptr, 0, st));
-  RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
+  if (lm_res_bf16()) RC(ta_rmsnorm_fwd_bf16(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, st));
+  else RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
   if (logits_out)   // the reference's outputs.logits (bf16 under autocast), all positions
     RC(gemm(t.hn, w->embed_bf16, logits_out, M, w->vocab_pad, d.D, nullptr, nullptr, 0, 1, st));
   if (n_lab > 0) {
@@ -445,10 +462,12 @@ extern "C" int ta_lm_prefill(const ta_lm_weights* w, const long* ids, const int*
   if ((long)p.bytes > ws_bytes) return TA_ERR_ARG;
   ta_i_lora_layer_imgs imgs[MAX_LM_LAYERS];
   if (w->lora_rank > 0) lora_imgs_carve(w, lora_img, imgs);
-  RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, p.layer[0].x_in, nullptr, M, d.D, w->vocab, st));
+  if (lm_res_bf16()) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, p.layer[0].x_in, M, d.D, w->vocab, st));
+  else RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, p.layer[0].x_in, nullptr, M, d.D, w->vocab, st));
   RC(lm_layers_forward(w, d, B, L, kmask, pos, p.layer, true, p.t.x_final, p.s, w->lora_rank > 0 ? imgs : nullptr,
                        (bf16_t*)kcache, (bf16_t*)vcache, Lmax, st));
-  RC(ta_rmsnorm_fwd(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, 0, st));
+  if (lm_res_bf16()) RC(ta_rmsnorm_fwd_bf16(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, st));
+  else RC(ta_rmsnorm_fwd(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, 0, st));
   RC(ta_gather_rows_bf16(p.t.hn, last_rows, p.s.hl, B, d.D, st));
   RC(gemm(p.s.hl, w->embed_bf16, logits, B, w->vocab_pad, d.D, nullptr, nullptr, 0, 0, st));
   return TA_OK;
@@ -501,7 +520,11 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
   float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
   float* dx_alt = s.dxb32;
-  RC(ta_rmsnorm_bwd(s.dhn, t.x_final, t.r_f, w->norm_w, nullptr, dx, s.dxb, nullptr, M, d.D, 0, st));
+  auto norm_bwd = [&](const float* dy, const float* x, const float* r, const float* gw, const float* dres, float* dxf) -> int {
+    return lm_res_bf16() ? ta_rmsnorm_bwd_bf16(dy, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
+                         : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
+  };
+  RC(norm_bwd(s.dhn, t.x_final, t.r_f, w->norm_w, nullptr, dx));
   for (int l = w->n_layers - 1; l >= 0; --l) {
     const ta_lm_layer& Lw = w->layers[l];
     const LmLayerTape& p = store[l];
@@ -516,7 +539,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
     RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, 0, st));
-    RC(ta_rmsnorm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt, s.dxb, nullptr, M, d.D, 0, st));
+    RC(norm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
     RC(gemm(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, st));
@@ -527,7 +550,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
                           d.nq, d.nkv, L, st));
     if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
     RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, 0, st));
-    RC(ta_rmsnorm_bwd(s.dxn, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, s.dxb, nullptr, M, d.D, 0, st));
+    RC(norm_bwd(s.dxn, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx));
   }
   if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return TA_ERR_LAUNCH;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const long* __restri
   const float4* src = s >= 0 ? (const float4*)(audio + (long)s * D) : (const float4*)(emb + id * D);
   for (int c = lane; c < D / 4; c += 64) {
     const float4 v = (s == -2) ? make_float4(0.f, 0.f, 0.f, 0.f) : src[c];
-    ((float4*)(x0 + (long)row * D))[c] = v;
+    if (x0) ((float4*)(x0 + (long)row * D))[c] = v;
     if (x0b) { uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w); ((uint2*)(x0b + (long)row * D))[c] = o; }
   }
 }

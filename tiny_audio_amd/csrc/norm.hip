@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // y = w * (x * rstd)   [ACT==1: y = gelu(y)];  x f32 [M,H]
-template <int MAXV, int ACT>
+template <int MAXV, int ACT, bool IN_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           bf16_t* __restrict__ yb, float* __restrict__ yf,
                                                           float* __restrict__ rstd_out, int M, int H, float eps) {
@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
-    if (c < nv) { v[i] = xr[c]; q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w; }
+    if (c < nv) {
+      if (IN_BF16) { const uint2 u = ((const uint2*)((const bf16_t*)x + (long)row * H))[c]; v[i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))); }
+      else v[i] = xr[c];
+      q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
   if (rstd_out && lane == 0) rstd_out[row] = rstd;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 //   dn = dy * act'(n)           (ACT==1, n = w*x*rstd recomputed)
 //   dx = rstd * (dn*w - xh * mean(dn*w*xh)),  xh = x*rstd        (+ dres if given)
 //   dw += sum_rows dn * xh      (if dw != null; LDS partials + one atomicAdd per column per block)
-template <int MAXV, int ACT>
+template <int MAXV, int ACT, bool X_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ rstd_in,
                                                           const float* __restrict__ w, const float* dres,
@@ -135,7 +139,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-          const float4 xv = xr[c], dv = dr[c], ww = ((const float4*)w)[c];
+          float4 xv;
+          if (X_BF16) { const uint2 u = ((const uint2*)((const bf16_t*)x + (long)row * H))[c]; xv = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))); }
+          else xv = xr[c];
+          const float4 dv = dr[c], ww = ((const float4*)w)[c];
           xh[i] = make_float4(xv.x * r, xv.y * r, xv.z * r, xv.w * r);
           float4 d = dv;
           if (ACT == 1) {
@@ -231,6 +238,30 @@ extern "C" int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, floa
   else                                                                                                             \
     TA_LAUNCH((rmsnorm_fwd_kernel<V, 0>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
   DISPATCH_MAXV(H, RF_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// x read as bf16 (the LM's residual stream in the reference's model dtype)
+extern "C" int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_bf16, float* y_f32, float* rstd, int M, int H,
+                                   float eps, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(M, 4)), blk(256);
+  const float* x = (const float*)x_bf16;
+#define RFB_CALL(V) TA_LAUNCH((rmsnorm_fwd_kernel<V, 0, true>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
+  DISPATCH_MAXV(H, RFB_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+extern "C" int ta_rmsnorm_bwd_bf16(const float* dy, const void* x_bf16, const float* rstd, const float* w, const float* dres,
+                                   float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  const float* x = (const float*)x_bf16;
+#define RBB_CALL(V) TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dy, x, rstd, w, dres, dx_f32, \
+                              (bf16_t*)dx_bf16, (float*)nullptr, M, H);
+  DISPATCH_MAXV(H, RBB_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

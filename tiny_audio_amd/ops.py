@@ -81,21 +81,31 @@ def layernorm(x, w, b, eps=1e-5, rowscale=None, out_bf16=True, out_f32=False):
 
 
 def rmsnorm_fwd(x, w, eps=1e-6, act_gelu=False, out_bf16=True, out_f32=False):
-    _req(x, F32)
     M, H = x.shape
     yb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
     yf = torch.empty((M, H), device=x.device, dtype=F32) if out_f32 else None
     r = torch.empty(M, device=x.device, dtype=F32)
+    if x.dtype == BF16:                  # residual stream kept in the model dtype
+        assert not act_gelu
+        check(lib().ta_rmsnorm_fwd_bf16(ptr(x), ptr(w), ptr(yb), ptr(yf), ptr(r), M, H, eps, stream()), "ta_rmsnorm_fwd_bf16")
+        return yb, yf, r
+    _req(x, F32)
     check(lib().ta_rmsnorm_fwd(ptr(x), ptr(w), ptr(yb), ptr(yf), ptr(r), M, H, eps, int(act_gelu), stream()),
           "ta_rmsnorm_fwd")
     return yb, yf, r
 
 
 def rmsnorm_bwd(dy, x, rstd, w, dres=None, act_gelu=False, want_dw=False, out_bf16=True):
-    _req(dy, F32); _req(x, F32)
+    _req(dy, F32)
     M, H = x.shape
     dx = torch.empty((M, H), device=x.device, dtype=F32)
     dxb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
+    if x.dtype == BF16:
+        assert not act_gelu and not want_dw
+        check(lib().ta_rmsnorm_bwd_bf16(ptr(dy), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), M, H, stream()),
+              "ta_rmsnorm_bwd_bf16")
+        return dx, dxb, None
+    _req(x, F32)
     dw = torch.zeros(H, device=x.device, dtype=F32) if want_dw else None
     check(lib().ta_rmsnorm_bwd(ptr(dy), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), M, H,
                                int(act_gelu), stream()), "ta_rmsnorm_bwd")
