@@ -278,8 +278,8 @@ int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd, const flo
 /* the same with x read as bf16 (frozen weights: no dw, no GELU): the LM's residual stream in the model dtype */
 int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_bf16, float* y_f32, float* rstd, int M, int H, float eps,
                         hipStream_t st);
-int ta_rmsnorm_bwd_bf16(const float* dy, const void* x_bf16, const float* rstd, const float* w, const float* dres,
-                        float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
+int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
+                        const float* dres, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
 
 int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
                      int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, hipStream_t st);

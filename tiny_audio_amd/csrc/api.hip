@@ -520,11 +520,14 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
   float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
   float* dx_alt = s.dxb32;
-  auto norm_bwd = [&](const float* dy, const float* x, const float* r, const float* gw, const float* dres, float* dxf) -> int {
-    return lm_res_bf16() ? ta_rmsnorm_bwd_bf16(dy, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
+  // dyb: the incoming gradient is bf16 (the two dX GEMMs that feed an RMSNorm backward write bf16 in that mode: it is
+  // read exactly once, so fp32 there only doubles epilogue and read bytes; the accumulating d(x) stream stays fp32)
+  const int gb = lm_res_bf16() ? 1 : 0;
+  auto norm_bwd = [&](const float* dy, int dyb, const float* x, const float* r, const float* gw, const float* dres, float* dxf) -> int {
+    return lm_res_bf16() ? ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
                          : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
   };
-  RC(norm_bwd(s.dhn, t.x_final, t.r_f, w->norm_w, nullptr, dx));
+  RC(norm_bwd(s.dhn, 0, t.x_final, t.r_f, w->norm_w, nullptr, dx));
   for (int l = w->n_layers - 1; l >= 0; --l) {
     const ta_lm_layer& Lw = w->layers[l];
     const LmLayerTape& p = store[l];
@@ -538,8 +541,8 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     RC(gemm(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, st));
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
-    RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, 0, st));
-    RC(norm_bwd(s.dxn, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
+    RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, st));
+    RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
     RC(gemm(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, st));
@@ -549,8 +552,8 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv, B,
                           d.nq, d.nkv, L, st));
     if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
-    RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, 0, st));
-    RC(norm_bwd(s.dxn, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx));
+    RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, st));
+    RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx));
   }
   if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return TA_ERR_LAUNCH;

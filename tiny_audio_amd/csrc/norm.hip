@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 //   dn = dy * act'(n)           (ACT==1, n = w*x*rstd recomputed)
 //   dx = rstd * (dn*w - xh * mean(dn*w*xh)),  xh = x*rstd        (+ dres if given)
 //   dw += sum_rows dn * xh      (if dw != null; LDS partials + one atomicAdd per column per block)
-template <int MAXV, int ACT, bool X_BF16 = false>
+template <int MAXV, int ACT, bool X_BF16 = false, bool DY_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ rstd_in,
                                                           const float* __restrict__ w, const float* dres,
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
           float4 xv;
           if (X_BF16) { const uint2 u = ((const uint2*)((const bf16_t*)x + (long)row * H))[c]; xv = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))); }
           else xv = xr[c];
-          const float4 dv = dr[c], ww = ((const float4*)w)[c];
+          float4 dv;
+          if (DY_BF16) { const uint2 u = ((const uint2*)((const bf16_t*)dy + (long)row * H))[c]; dv = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16))); }
+          else dv = dr[c];
+          const float4 ww = ((const float4*)w)[c];
           xh[i] = make_float4(xv.x * r, xv.y * r, xv.z * r, xv.w * r);
           float4 d = dv;
           if (ACT == 1) {
@@ -254,13 +257,17 @@ extern "C" int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_b
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
-extern "C" int ta_rmsnorm_bwd_bf16(const float* dy, const void* x_bf16, const float* rstd, const float* w, const float* dres,
-                                   float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st) {
+extern "C" int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
+                                   const float* dres, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st) {
   if (M <= 0) return TA_OK;
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
   const float* x = (const float*)x_bf16;
-#define RBB_CALL(V) TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dy, x, rstd, w, dres, dx_f32, \
-                              (bf16_t*)dx_bf16, (float*)nullptr, M, H);
+  const float* dyf = (const float*)dy;
+#define RBB_CALL(V)                                                                                                        \
+  if (dy_is_bf16) TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, \
+                            dx_f32, (bf16_t*)dx_bf16, (float*)nullptr, M, H);                                              \
+  else TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, false>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, dx_f32,  \
+                 (bf16_t*)dx_bf16, (float*)nullptr, M, H);
   DISPATCH_MAXV(H, RBB_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;

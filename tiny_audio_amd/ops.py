@@ -96,13 +96,14 @@ def rmsnorm_fwd(x, w, eps=1e-6, act_gelu=False, out_bf16=True, out_f32=False):
 
 
 def rmsnorm_bwd(dy, x, rstd, w, dres=None, act_gelu=False, want_dw=False, out_bf16=True):
-    _req(dy, F32)
+    if x.dtype != BF16:
+        _req(dy, F32)
     M, H = x.shape
     dx = torch.empty((M, H), device=x.device, dtype=F32)
     dxb = torch.empty((M, H), device=x.device, dtype=BF16) if out_bf16 else None
     if x.dtype == BF16:
         assert not act_gelu and not want_dw
-        check(lib().ta_rmsnorm_bwd_bf16(ptr(dy), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), M, H, stream()),
+        check(lib().ta_rmsnorm_bwd_bf16(ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), M, H, stream()),
               "ta_rmsnorm_bwd_bf16")
         return dx, dxb, None
     _req(x, F32)
