@@ -250,17 +250,25 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
                        long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
                        int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
                        const int* krange, hipStream_t st);
-/* K extension (LoRA): arms the NEXT ta_gemm_bf16_nt* call of this host thread to compute
- * C = epilogue(A W^T + A2 W2^T) with A2 [M, K2] (row stride lda2) and W2 [N, K2], K2 % 64 == 0, in one pass. */
-int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2);
-/* SwiGLU backward fused into the epilogue of the NEXT ta_gemm_bf16_nt* call on this thread (one-shot): that GEMM's bf16
- * result is d(act) [M, N = F] (dX of Qwen3MLP.down_proj, TF:models/qwen3/modeling_qwen3.py:70-83); it is not stored --
- * d(gate|up) [M, 2F] is written to dgu from gate|up gu [M, 2F] instead (plain row map, no bias / act / residual). */
-int ta_gemm_set_swiglu_bwd(const void* gu_bf16, void* dgu_bf16);
-/* The NEXT ta_gemm_bf16_nt* call on this thread (one-shot) adds a bf16 residual with the row map of C (it may alias C);
- * that call's `residual` must be NULL.  GlmAsrEncoderLayer residual adds in the model dtype
- * (TF:models/glmasr/modeling_glmasr.py:249-270 on a bf16 model). */
-int ta_gemm_set_residual_bf16(const void* residual_bf16);
+/* Optional extras of one GEMM call (all pointers NULL = plain GEMM).  Passed by value semantics: read during the call,
+ * no state is kept (the composites run on any host thread / stream concurrently).
+ *   a2/w2/k2/lda2   K extension (LoRA): C = epilogue(A W^T + A2 W2^T), A2 [M, k2] (row stride lda2), W2 [N, k2],
+ *                   k2 % 64 == 0, in the same accumulator pass (no split-K, no krange)
+ *   residual_bf16   bf16 residual with C's row map (may alias C); the call's f32 `residual` must then be NULL.  The
+ *                   frozen models' residual adds in the model dtype (TF:models/glmasr/modeling_glmasr.py:249-270,
+ *                   TF:models/qwen3/modeling_qwen3.py:283-324 on bf16 models)
+ *   swiglu_gu/dgu   SwiGLU backward in the epilogue: the bf16 result d(act) [M, N = F] (dX of Qwen3MLP.down_proj) is
+ *                   not stored; d(gate|up) [M, 2F] is written to swiglu_dgu from gate|up swiglu_gu [M, 2F]
+ *                   (plain row map, no bias / act / residual) */
+typedef struct {
+  const void* a2; const void* w2; int k2; long lda2;
+  const void* residual_bf16;
+  const void* swiglu_gu; void* swiglu_dgu;
+} ta_gemm_opts;
+int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
+                        long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
+                        int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
+                        const int* krange, const ta_gemm_opts* opts, hipStream_t st);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */

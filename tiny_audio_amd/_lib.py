@@ -61,6 +61,11 @@ class LmLayer(C.Structure):
                                           "la_qkv", "lb_qkv", "la_o", "lb_o", "la_gu", "lb_gu", "la_d", "lb_d")]
 
 
+class GemmOpts(C.Structure):
+    _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
+                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p)]
+
+
 class LmLoraGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dla_qkv", "dlb_qkv", "dla_o", "dlb_o", "dla_gu", "dlb_gu", "dla_d", "dlb_d")]
 

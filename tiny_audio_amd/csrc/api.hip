@@ -66,7 +66,7 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
               : ta_layernorm_f32(e.xr, gw, gb, yb, yf, rowscale, M, H, w->ln_eps, st);
   };
   auto res_gemm = [&](const void* A, const void* Wm, int K, const float* bias) -> int {      // xr += A Wm^T + bias
-    if (rb) { RC(ta_gemm_set_residual_bf16(e.xr)); return gemm(A, Wm, e.xr, M, H, K, bias, nullptr, 0, 1, st); }
+    if (rb) { ta_gemm_opts o = opts_none(); o.residual_bf16 = e.xr; return gemm_opt(A, Wm, e.xr, M, H, K, bias, nullptr, 0, 1, o, st); }
     return gemm(A, Wm, e.xr, M, H, K, bias, e.xr, 0, 0, st);
   };
   RC(ta_gemm_bf16_nt(e.x1, w->conv2_w, e.xr, M, H, 3 * H, 2L * H, S, (long)(T + 2) * H, H, 0, 0, 0, w->conv2_b, nullptr,
@@ -303,10 +303,13 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
   const int r = w->lora_rank;
   if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
   // y = x W^T + xa Bext^T with xa = x (s Acat)^T: one skinny GEMM for xa, then the frozen GEMM runs one extra K-tile
+  ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen GEMM (consumed and cleared by it)
   auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa) -> int {
     RC(ta_i_lora_skinny_nt(x, in, g.a, xa, M, st));
-    return ta_gemm_set_k_extension(xa, g.b, 64, 64);
+    kx = opts_kext(xa, g.b);
+    return TA_OK;
   };
+  auto take_ext = [&]() { const ta_gemm_opts o = kx; kx = opts_none(); return o; };
   if (lora) {
     // bf16 images of every layer's adapters (kept in the tape / the caller's image buffer for backward and decoding).
     // The masters of consecutive layers are usually one tensor [L, ...] and the images are carved with a constant
@@ -364,12 +367,13 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
       return rb ? ta_rmsnorm_fwd_bf16(x, gw, y, nullptr, r, M, d.D, w->eps, st) : ta_rmsnorm_fwd(x, gw, y, nullptr, r, M, d.D, w->eps, 0, st);
     };
     auto res_gemm = [&](const void* A, const void* Wm, float* out, int K, const float* res) -> int {   // out = res + A Wm^T
-      if (rb) { RC(ta_gemm_set_residual_bf16(res)); return gemm(A, Wm, out, M, d.D, K, nullptr, nullptr, 0, 1, st); }
-      return gemm(A, Wm, out, M, d.D, K, nullptr, res, 0, 0, st);
+      ta_gemm_opts o = take_ext();
+      if (rb) { o.residual_bf16 = res; return gemm_opt(A, Wm, out, M, d.D, K, nullptr, nullptr, 0, 1, o, st); }
+      return gemm_opt(A, Wm, out, M, d.D, K, nullptr, res, 0, 0, o, st);
     };
     RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
     if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
-    RC(gemm(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, st));
+    RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
                           p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
     if (kcache) {   // greedy decoding: keys / values of the prompt go to the cache [layer, B, Hkv, Lmax, hd]
@@ -385,7 +389,7 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     bf16_t* act = lora ? p.act_s : s.act;
     RC(norm(p.x1, Lw.ln_post_w, xn2, p.r_post));
     if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu));
-    RC(gemm(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, st));
+    RC(gemm_opt(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_swiglu_fwd(p.gu, act, M, d.F, st));
     if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d));
     RC(res_gemm(act, Lw.wd, x_next, d.F, p.x1));
@@ -505,13 +509,16 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   //   dyB = dy Bext            (rank space, [M, 64])       dBext = dy^T xa   (block-masked)
   //   dx  = dy W + dyB (sAcat) (K extension of the dX GEMM) dAcat = s (dyB)^T x
   // `arm` only prepares the K extension; the caller then issues the frozen dX GEMM.
+  ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen dX GEMM
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1) -> int {
     RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, st));
     RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
     RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
-    return ta_gemm_set_k_extension(s.dyB, g.at, 64, 64);
+    kx = opts_kext(s.dyB, g.at);
+    return TA_OK;
   };
+  auto take_ext = [&]() { const ta_gemm_opts o = kx; kx = opts_none(); return o; };
   // d hidden (labelled rows) = dlogits x E   (split-K over the vocabulary), scattered back to all positions
   const int sp = pick_splits(n_lab, d.D, w->vocab_pad);
   RC(ta_gemm_bf16_nt(t.dlogits, w->embed_t_bf16, s.dhl, n_lab, d.D, w->vocab_pad, w->vocab_pad, 0, 0, d.D, 0, 0, 0, nullptr,
@@ -537,22 +544,25 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     // (54.8 vs 54.3 ms) -- at one workgroup per CU nothing overlaps an epilogue, so bytes moved there (gate|up read,
     // d(gate|up) written in 32-B pieces) cost more than the separate streaming kernel at 6 TB/s.  Off unless asked for.
     static const bool fuse_swiglu = [] { const char* e = getenv("TA355_FUSE_SWIGLU_BWD"); return e && *e == '1'; }();
-    if (fuse_swiglu) RC(ta_gemm_set_swiglu_bwd(p.gu, s.dgu));
-    RC(gemm(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, st));
+    {
+      ta_gemm_opts o = take_ext();
+      if (fuse_swiglu) { o.swiglu_gu = p.gu; o.swiglu_dgu = s.dgu; }
+      RC(gemm_opt(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, o, st));
+    }
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
-    RC(gemm(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, st));
+    RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
     RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
-    RC(gemm(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, st));
+    RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
                         B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv, B,
                           d.nq, d.nkv, L, st));
     if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
-    RC(gemm(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, st));
+    RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));
     RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx));
   }
   if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)

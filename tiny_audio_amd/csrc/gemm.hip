@@ -19,6 +19,7 @@
 //   * the projector's frame stacking [B,S,E] -> [B,S/k,k*E] incl. tail truncation
 //     (tiny_audio/projectors.py:79-87).
 #include "common.h"
+#include "../../include/ta355.h"
 
 struct GemmArgs {
   const bf16_t* A;
@@ -565,51 +566,33 @@ extern "C" int ta_gemm_bf16_nt(const void* A, const void* W, void* C, int M, int
                                long ldc, int c_rpb, long c_bs, long c_off,
                                const float* bias, const float* residual,
                                int act, int out_bf16, int splits, float* splitk_ws, hipStream_t st) {
-  return ta_gemm_bf16_nt_ex(A, W, C, M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, bias, residual, act, out_bf16,
-                            splits, splitk_ws, nullptr, nullptr, nullptr, st);
+  return ta_gemm_bf16_nt_opt(A, W, C, M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, bias, residual, act, out_bf16,
+                             splits, splitk_ws, nullptr, nullptr, nullptr, nullptr, st);
 }
-
-static thread_local const void* g_res_bf16 = nullptr;
-// Arms the NEXT ta_gemm_bf16_nt* call on this thread with a bf16 residual (same row map as C; may alias C): the
-// encoder's residual stream in the reference's own dtype.  That call's `residual` argument must be NULL.
-extern "C" int ta_gemm_set_residual_bf16(const void* residual_bf16) {
-  g_res_bf16 = residual_bf16;
-  return TA_OK;
-}
-static thread_local const void* g_sw_gu = nullptr;
-static thread_local void* g_sw_dgu = nullptr;
-// Arms the NEXT ta_gemm_bf16_nt* call on this thread: its bf16 result d(act) [M, F] is not stored; d(gate|up) [M, 2F] is
-// written instead from gate|up [M, 2F] (SwiGLU backward fused into the down-projection's dX GEMM epilogue).
-extern "C" int ta_gemm_set_swiglu_bwd(const void* gu, void* dgu) {
-  g_sw_gu = gu; g_sw_dgu = dgu;
-  return TA_OK;
-}
-static thread_local const void* g_ext_A2 = nullptr;
-static thread_local const void* g_ext_W2 = nullptr;
-static thread_local int g_ext_K2 = 0;
-static thread_local long g_ext_lda2 = 0;
-// C = epilogue(A W^T + A2 W2^T): the K extension is armed for the NEXT ta_gemm_bf16_nt* call on this thread.
-extern "C" int ta_gemm_set_k_extension(const void* A2, const void* W2, int K2, long lda2) {
-  if (A2 && (K2 <= 0 || K2 % BK || lda2 % 8)) return TA_ERR_ARG;
-  g_ext_A2 = A2; g_ext_W2 = W2; g_ext_K2 = K2; g_ext_lda2 = lda2;
-  return TA_OK;
+extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
+                                  long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual,
+                                  int act, int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
+                                  const int* krange, hipStream_t st) {
+  return ta_gemm_bf16_nt_opt(A, W, C, M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, bias, residual, act, out_bf16,
+                             splits, splitk_ws, a_idx, seg, krange, nullptr, st);
 }
 
 // M is the UPPER BOUND on rows when `seg` is given (grid sizing); the kernel reads the actual base/count on device.
-extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int K,
-                                  long lda, int a_rpb, long a_bs,
-                                  long ldc, int c_rpb, long c_bs, long c_off,
-                                  const float* bias, const float* residual,
-                                  int act, int out_bf16, int splits, float* splitk_ws,
-                                  const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
-  const void* resb = g_res_bf16;
-  g_res_bf16 = nullptr;
+extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K,
+                                   long lda, int a_rpb, long a_bs,
+                                   long ldc, int c_rpb, long c_bs, long c_off,
+                                   const float* bias, const float* residual,
+                                   int act, int out_bf16, int splits, float* splitk_ws,
+                                   const int* a_idx, const int* seg, const int* krange, const ta_gemm_opts* opts,
+                                   hipStream_t st) {
+  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+  const ta_gemm_opts& o = opts ? *opts : none;
+  const void* resb = o.residual_bf16;
   if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
-  const void* sw_gu = g_sw_gu; void* sw_dgu = g_sw_dgu;
-  g_sw_gu = nullptr; g_sw_dgu = nullptr;                                // one-shot, like the K extension
-  const void *xA2 = g_ext_A2, *xW2 = g_ext_W2;
-  const int xK2 = g_ext_K2;
-  g_ext_A2 = nullptr; g_ext_W2 = nullptr; g_ext_K2 = 0;          // one-shot: consumed by this call whatever its outcome
+  const void* sw_gu = o.swiglu_gu; void* sw_dgu = o.swiglu_dgu;
+  const void *xA2 = o.a2, *xW2 = o.w2;
+  const int xK2 = o.a2 ? o.k2 : 0;
+  if (o.a2 && (o.k2 <= 0 || o.k2 % BK || o.lda2 % 8 || !o.w2)) return TA_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return TA_OK;
   if ((a_idx || seg || krange) && splits > 1) return TA_ERR_ARG;
   if ((K % BK) != 0 || (N % 4) != 0 || (lda % 8) != 0 || (a_bs % 8) != 0 || (ldc % 4) != 0 ||
@@ -622,7 +605,7 @@ extern "C" int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, 
   a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : (seg ? 0x7fffffff : M); a.c_bs = c_bs; a.c_off = c_off;
   if (seg && a_rpb <= 0) a.a_rpb = 0x7fffffff;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
-  a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = g_ext_lda2;
+  a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = o.lda2;
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
   a.res_bf16 = resb != nullptr;
   if (resb && splits > 1) return TA_ERR_ARG;

@@ -322,8 +322,7 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
       a2 = s.xa; w2 = g->b;
     }
     if (small) return linear_small_m(x, (const bf16_t*)Wm, y, B, N, K, res, out_bf16, a2, w2, st);
-    if (g) RC(ta_gemm_set_k_extension(a2, w2, 64, 64));
-    return gemm(x, Wm, y, B, N, K, nullptr, res, 0, out_bf16 ? 1 : 0, st);
+    return gemm_opt(x, Wm, y, B, N, K, nullptr, res, 0, out_bf16 ? 1 : 0, g ? opts_kext(a2, w2) : opts_none(), st);
   };
   RC(ta_embed_scatter(ids, nullptr, w->embed_f32, nullptr, s.x, nullptr, B, D, w->vocab, st));
   for (int l = 0; l < w->n_layers; ++l) {

@@ -38,15 +38,19 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile)."""
     _req(A, BF16); _req(W, BF16)
-    if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
-        _req(residual_bf16, BF16)
-        check(lib().ta_gemm_set_residual_bf16(ptr(residual_bf16)), "ta_gemm_set_residual_bf16")
-    if swiglu_bwd is not None:          # (gu [M, 2F], dgu [M, 2F]): the result d(act) is consumed in the epilogue
-        check(lib().ta_gemm_set_swiglu_bwd(ptr(swiglu_bwd[0]), ptr(swiglu_bwd[1])), "ta_gemm_set_swiglu_bwd")
-    if k_ext is not None:
-        A2, W2 = k_ext
-        _req(A2, BF16); _req(W2, BF16)
-        check(lib().ta_gemm_set_k_extension(ptr(A2), ptr(W2), W2.shape[1], A2.shape[1]), "ta_gemm_set_k_extension")
+    opts = None
+    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None:
+        from ._lib import GemmOpts
+        opts = GemmOpts()
+        if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
+            _req(residual_bf16, BF16)
+            opts.residual_bf16 = ptr(residual_bf16)
+        if swiglu_bwd is not None:          # (gu [M, 2F], dgu [M, 2F]): the result d(act) is consumed in the epilogue
+            opts.swiglu_gu, opts.swiglu_dgu = ptr(swiglu_bwd[0]), ptr(swiglu_bwd[1])
+        if k_ext is not None:
+            A2, W2 = k_ext
+            _req(A2, BF16); _req(W2, BF16)
+            opts.a2, opts.w2, opts.k2, opts.lda2 = ptr(A2), ptr(W2), W2.shape[1], A2.shape[1]
     N = N or W.shape[0]
     K = K or W.shape[1]
     M = M or A.numel() // K
@@ -57,9 +61,10 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
     ws = None
     if splits > 1:
         ws = torch.empty(lib().ta_gemm_splitk_ws_bytes(M, N, splits) // 4, device=A.device, dtype=F32)
-    check(lib().ta_gemm_bf16_nt(ptr(A), ptr(W), ptr(out), M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off,
-                                ptr(bias), ptr(residual), act, 1 if out.dtype == BF16 else 0, splits, ptr(ws),
-                                stream()), "ta_gemm_bf16_nt")
+    import ctypes as _C
+    check(lib().ta_gemm_bf16_nt_opt(ptr(A), ptr(W), ptr(out), M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off,
+                                    ptr(bias), ptr(residual), act, 1 if out.dtype == BF16 else 0, splits, ptr(ws),
+                                    None, None, None, None if opts is None else _C.addressof(opts), stream()), "ta_gemm_bf16_nt_opt")
     return out
 
 
