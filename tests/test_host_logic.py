@@ -302,3 +302,25 @@ class _StubFeatureExtractor:
 @pytest.fixture()
 def dry_lib_for_features():
     return _StubFeatureExtractor()
+
+
+def test_split_parameter_groups():
+    """scripts/train.py:384-437: language_model.* parameters take decoder_learning_rate / decoder_weight_decay, the rest the
+    base LR / projector_weight_decay; norm scales and biases never decay."""
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.projector = torch.nn.Linear(4, 4)
+            self.projector.norm = torch.nn.LayerNorm(4)
+            self.language_model = torch.nn.Module()
+            self.language_model.lora_la_qkv = torch.nn.Parameter(torch.zeros(2, 8, 4))
+    tr = ASRTrainer(M(), TrainingArguments(learning_rate=1e-3, weight_decay=0.1), decoder_learning_rate=1e-4,
+                    decoder_weight_decay=0.01, projector_weight_decay=0.05)
+    hp = {n: tr.group_hparams(n, d) for n, d in zip(tr.flat.names, tr.flat.decay)}
+    assert hp["projector.weight"] == (1e-3, 0.05) and hp["projector.bias"] == (1e-3, 0.0)
+    assert hp["projector.norm.weight"] == (1e-3, 0.0)
+    assert hp["language_model.lora_la_qkv"] == (1e-4, 0.01)
+    tr2 = ASRTrainer(M(), TrainingArguments(learning_rate=1e-3, weight_decay=0.1))
+    assert tr2.group_hparams("language_model.lora_la_qkv", True) == (1e-3, 0.1) and tr2.group_hparams("projector.weight", True) == (1e-3, 0.1)

@@ -112,8 +112,15 @@ def allreduce_flat(flat: torch.Tensor, group=None) -> torch.Tensor:
 
 
 class ASRTrainer:
-    def __init__(self, model, args: Optional[TrainingArguments] = None, group=None):
+    def __init__(self, model, args: Optional[TrainingArguments] = None, group=None, decoder_learning_rate: Optional[float] = None,
+                 decoder_weight_decay: Optional[float] = None, projector_weight_decay: Optional[float] = None):
+        """``decoder_*`` / ``projector_weight_decay``: the split parameter groups of scripts/train.py:384-437 -- parameters
+        under ``language_model.`` (the LoRA adapters in stage 2) take the decoder LR / weight decay, everything else the
+        base LR and the projector weight decay; each falls back to ``args.learning_rate`` / ``args.weight_decay``; norm
+        scales and biases never decay.  The schedule multiplies both LRs alike (one LambdaLR over all groups)."""
         self.model, self.args, self.group = model, args or TrainingArguments(), group
+        self.decoder_learning_rate, self.decoder_weight_decay = decoder_learning_rate, decoder_weight_decay
+        self.projector_weight_decay = projector_weight_decay
         self.flat = FlatTrainable(list(model.named_parameters()))
         self.sqnorm = torch.zeros(1, device=self.flat.flat_p.device, dtype=torch.float32)
         self.global_step = 0
@@ -144,14 +151,26 @@ class ASRTrainer:
         a, f = self.args, self.flat
         allreduce_flat(f.flat_g, self.group)                      # grads, token count and loss sum in one collective
         self.global_step += 1
-        lr = a.learning_rate * lr_multiplier(self.global_step - 1, a)
         self.sqnorm.zero_()
         ops.grad_sqnorm(f.grads, self.sqnorm)
-        for o, s, dec in zip(f.offsets, f.sizes, f.decay):
-            ops.adamw_step(f.flat_p[o:o + s], f.flat_g[o:o + s], f.flat_m[o:o + s], f.flat_v[o:o + s], lr,
-                           a.adam_beta1, a.adam_beta2, a.adam_epsilon, a.weight_decay if dec else 0.0, self.global_step,
+        mult = lr_multiplier(self.global_step - 1, a)
+        for name, o, s, dec in zip(f.names, f.offsets, f.sizes, f.decay):
+            lr_p, wd_p = self.group_hparams(name, dec)
+            ops.adamw_step(f.flat_p[o:o + s], f.flat_g[o:o + s], f.flat_m[o:o + s], f.flat_v[o:o + s], lr_p * mult,
+                           a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd_p, self.global_step,
                            sqnorm=self.sqnorm, max_norm=a.max_grad_norm, grad_scale=1.0, denom=f.count_slot)
         self._invalidate()
+
+    def group_hparams(self, name: str, decays: bool):
+        """(base lr, weight decay) of one parameter: scripts/train.py:406-432."""
+        a = self.args
+        if name.startswith("language_model."):
+            lr = self.decoder_learning_rate if self.decoder_learning_rate is not None else a.learning_rate
+            wd = self.decoder_weight_decay if self.decoder_weight_decay is not None else a.weight_decay
+        else:
+            lr = a.learning_rate
+            wd = self.projector_weight_decay if self.projector_weight_decay is not None else a.weight_decay
+        return lr, (wd if decays else 0.0)
 
     def last_loss(self) -> float:
         """Global mean loss of the last optimizer step (one host sync; for logging)."""
