@@ -222,6 +222,44 @@ def test_generate_plumbing(dry):
         m.generate(input_features=torch.zeros(2, 128, 100), audio_attention_mask=torch.ones(2, 100, dtype=torch.int64))
     with pytest.raises(NotImplementedError):
         m.generate(**kw, do_sample=True)
+    # streaming (asr_modeling.py:648-760): one clip, one token per step, same launches as generate
+    one = dict(input_ids=ids[:1], input_features=torch.zeros(1, 128, 100), audio_attention_mask=torch.ones(1, 100, dtype=torch.int64))
+    dry.calls.clear()
+    toks = list(m.generate_streaming(**one, return_token_ids=True, max_new_tokens=5, eos_token_id=[]))
+    assert toks == [990] * 5 and dry.calls.count("ta_lm_decode_step") == 4
+    assert list(m.generate_streaming(**one, return_token_ids=True, max_new_tokens=5)) == [990]      # pad is an eos id
+    with pytest.raises(ValueError, match="one clip at a time"):
+        next(m.generate_streaming(input_ids=ids, input_features=torch.zeros(2, 128, 100),
+                                  audio_attention_mask=torch.ones(2, 100, dtype=torch.int64), return_token_ids=True))
+    with pytest.raises(ValueError, match="needs a tokenizer"):
+        next(m.generate_streaming(**one))
+
+
+def test_streaming_text_release():
+    """The text side of generate_streaming: word-boundary release (as transformers' TextStreamer), special tokens
+    skipped, <think> spans dropped (tiny_audio/asr_modeling.py:737-757)."""
+    from tiny_audio_amd.asr_modeling import _TextPieces, _ThinkGate
+
+    class Tok:
+        vocab = {1: "hel", 2: "lo", 3: " wor", 4: "ld", 5: " ", 6: "<think>", 7: "secret", 8: "</think>", 9: "\n", 10: "\u4f60",
+                 11: "<eos>"}
+
+        def decode(self, ids, skip_special_tokens=True):
+            return "".join(self.vocab[i] for i in ids if not (skip_special_tokens and i == 11))
+
+    def run(ids):
+        p, g, out = _TextPieces(Tok()), _ThinkGate(), []
+        for i in ids:
+            out += list(g.feed(p.push(i)))
+        out += list(g.feed(p.flush()))
+        tail = g.flush()
+        return [o for o in out + ([tail] if tail else []) if o]
+
+    assert run([1, 2, 3, 4, 11]) == ["hello ", "world"]             # released up to the last space, rest on flush
+    assert run([1, 2, 9, 3, 4]) == ["hello\n", " ", "world"]        # a finished line is released whole
+    assert run([10, 10]) == ["\u4f60", "\u4f60"]                    # CJK characters at once
+    assert "".join(run([1, 5, 6, 7, 5, 8, 3, 4, 5])) == "hel  world "
+    assert "secret" not in "".join(run([6, 7, 5, 7, 5]))             # unterminated think block: nothing leaks
 
 
 def test_checkpoint_interchange(dry, tmp_path):

@@ -573,6 +573,11 @@ def test_generate_true_width_ragged_prompts_and_cache_consistency():
     ids_l[0, :4] = [9, 10, 11, 12]
     both = m.generate(input_ids=torch.from_numpy(ids_l), attention_mask=torch.from_numpy(att_l), **kw, max_new_tokens=6).cpu().numpy()
     assert (both[1] == solo[0]).mean() >= 5 / 6            # identical up to one bf16 near-tie
+    # (iv) streaming (asr_modeling.py:648-760): the same kernels, one sync per token -> the very same tokens
+    streamed = list(m.generate_streaming(input_ids=torch.from_numpy(ids[1:2]), input_features=kw["input_features"][1:2],
+                                         audio_attention_mask=kw["audio_attention_mask"][1:2], max_new_tokens=6,
+                                         return_token_ids=True))
+    assert streamed == solo[0].tolist()[:len(streamed)] and len(streamed) >= min(solo.shape[1], 6)
 
 
 # ============================================================================ size-independent properties at full shapes

@@ -10,7 +10,7 @@ There is no CPU path: without libta355.so / a GPU every entry point raises.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Iterator, Optional
 
 import torch
 import torch.nn as nn
@@ -29,6 +29,66 @@ class CausalLMOutput:
 
     def __getitem__(self, k):
         return getattr(self, k)
+
+
+def _is_cjk(ch: str) -> bool:
+    """CJK ideograph blocks (a streamer releases such characters one by one: they carry no spaces)."""
+    cp = ord(ch)
+    return any(lo <= cp <= hi for lo, hi in ((0x4E00, 0x9FFF), (0x3400, 0x4DBF), (0x20000, 0x2A6DF), (0x2A700, 0x2B73F),
+                                             (0x2B740, 0x2B81F), (0x2B820, 0x2CEAF), (0xF900, 0xFAFF), (0x2F800, 0x2FA1F)))
+
+
+class _TextPieces:
+    """Incremental detokeniser with the release rule of transformers' TextStreamer (generation/streamers.py
+    ``put``/``end``): decode the tokens of the current line, release a finished line whole, a trailing CJK character at
+    once, otherwise everything up to the last space; ``flush`` releases the rest."""
+
+    def __init__(self, tokenizer):
+        self.tok, self.ids, self.shown = tokenizer, [], 0
+
+    def push(self, token_id: int) -> str:
+        self.ids.append(int(token_id))
+        text = self.tok.decode(self.ids, skip_special_tokens=True)
+        if text.endswith("\n"):
+            out, self.ids, self.shown = text[self.shown:], [], 0
+        elif text and _is_cjk(text[-1]):
+            out, self.shown = text[self.shown:], len(text)
+        else:
+            cut = text.rfind(" ") + 1
+            out = text[self.shown:cut] if cut > self.shown else ""
+            self.shown = max(self.shown, cut)
+        return out
+
+    def flush(self) -> str:
+        out = self.tok.decode(self.ids, skip_special_tokens=True)[self.shown:] if self.ids else ""
+        self.ids, self.shown = [], 0
+        return out
+
+
+class _ThinkGate:
+    """Drops ``<think>...</think>`` spans from a stream of text pieces (tiny_audio/asr_modeling.py:737-757)."""
+
+    def __init__(self):
+        self.buf, self.inside = "", False
+
+    def feed(self, text: str):
+        self.buf += text
+        while "<think>" in self.buf:
+            self.inside = True
+            before, self.buf = self.buf.split("<think>", 1)
+            if before:
+                yield before
+        while self.inside and "</think>" in self.buf:
+            self.inside = False
+            self.buf = self.buf.split("</think>", 1)[1]
+        if not self.inside and self.buf:
+            out, self.buf = self.buf, ""
+            yield out
+
+    def flush(self) -> str:
+        out = "" if self.inside else self.buf
+        self.buf = ""
+        return out
 
 
 def _gather_audio_embeds(audio_embeds: torch.Tensor, token_counts: torch.Tensor) -> torch.Tensor:
@@ -200,19 +260,14 @@ class ASRModel(nn.Module):
         lens = self._compute_encoder_output_lengths(audio_attention_mask)
         return int(self.projector.get_output_length(int(lens.max().item())))
 
-    @torch.no_grad()
-    def generate(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
-                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
-                 system_prompt: Optional[str] = None, **generate_kwargs) -> torch.Tensor:
-        """Transcription token ids [B, n_new] (prompt stripped), as ASRModel.generate of the reference
-        (tiny_audio/asr_modeling.py:562-646): audio -> encoder -> projector -> <audio> rows of the prompt embeddings ->
-        greedy search on the LM.  Only the reference's own generation config is built (greedy: num_beams 1,
-        do_sample False, repetition_penalty 1.0, no_repeat_ngram_size 0, min_new_tokens 0; asr_config.py:103-111)."""
+    def _prepare_generation(self, input_ids, input_features, audio_attention_mask, attention_mask, system_prompt, kw):
+        """Everything ``generate`` and ``generate_streaming`` share (tiny_audio/asr_modeling.py:580-640, :669-716):
+        generation settings, audio -> encoder -> projector, the chat prompt with one <audio> placeholder per projected
+        frame, and the placeholder -> audio-row index.  -> kwargs of ``Qwen3MI355X.greedy_decode_iter``."""
         if input_features is None:
             raise ValueError("input_features required for generation")
         if audio_attention_mask is None:
             raise ValueError("audio_attention_mask required for generation")
-        kw = dict(generate_kwargs)
         max_new = int(self._generation_setting("max_new_tokens", 128, kw))
         if (int(self._generation_setting("num_beams", 1, kw)) != 1 or bool(self._generation_setting("do_sample", False, kw))
                 or float(self._generation_setting("repetition_penalty", 1.0, kw)) != 1.0
@@ -225,37 +280,95 @@ class ASRModel(nn.Module):
         eos_ids = [int(e) for e in (eos_ids if isinstance(eos_ids, (list, tuple)) else [eos_ids]) if e is not None]
         pad_id = int(kw.pop("pad_token_id", self.config.pad_token_id))
         dev = self.device_
+        feats = input_features.to(dev)
+        B = feats.shape[0]
+        amask = audio_attention_mask.to(dev)
+        enc_len = self._compute_encoder_output_lengths(amask)
+        counts = self.projector.get_output_length(enc_len).to(device=dev, dtype=torch.int64).contiguous()
+        y = self._encode_audio(feats)                                                   # [B, N, D]
+        N = y.shape[1]
+        if input_ids is None:
+            if self.tokenizer is None:
+                raise ValueError("input_ids required: no tokenizer is attached to build the chat prompt")
+            n_audio = self._get_num_audio_tokens(amask)
+            messages = []
+            sp = system_prompt or self.system_prompt
+            if sp:
+                messages.append({"role": "system", "content": sp})
+            content = "<audio>" * n_audio + (" " + self.TRANSCRIBE_PROMPT if self.TRANSCRIBE_PROMPT else "")
+            messages.append({"role": "user", "content": content})
+            chat = self.tokenizer.apply_chat_template(messages, tokenize=True, add_generation_prompt=True,
+                                                      return_tensors="pt", enable_thinking=False)
+            input_ids = chat.input_ids if hasattr(chat, "input_ids") else chat
+            if input_ids.dim() == 1:
+                input_ids = input_ids.unsqueeze(0)
+            if input_ids.shape[0] == 1 and B > 1:
+                input_ids = input_ids.expand(B, -1)
+            attention_mask = torch.ones_like(input_ids)
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
+        return dict(input_ids=ids, src_row=src_row, audio=y.reshape(B * N, -1), attention_mask=attention_mask,
+                    max_new_tokens=max_new, eos_ids=eos_ids, pad_id=pad_id)
+
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
+                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                 system_prompt: Optional[str] = None, **generate_kwargs) -> torch.Tensor:
+        """Transcription token ids [B, n_new] (prompt stripped), as ASRModel.generate of the reference
+        (tiny_audio/asr_modeling.py:562-646): audio -> encoder -> projector -> <audio> rows of the prompt embeddings ->
+        greedy search on the LM.  Only the reference's own generation config is built (greedy: num_beams 1,
+        do_sample False, repetition_penalty 1.0, no_repeat_ngram_size 0, min_new_tokens 0; asr_config.py:103-111)."""
         was_training = self.training
         self.eval()
         try:
-            feats = input_features.to(dev)
-            B = feats.shape[0]
-            amask = audio_attention_mask.to(dev)
-            enc_len = self._compute_encoder_output_lengths(amask)
-            counts = self.projector.get_output_length(enc_len).to(device=dev, dtype=torch.int64).contiguous()
-            y = self._encode_audio(feats)                                                   # [B, N, D]
-            N = y.shape[1]
-            if input_ids is None:
-                if self.tokenizer is None:
-                    raise ValueError("input_ids required: no tokenizer is attached to build the chat prompt")
-                n_audio = self._get_num_audio_tokens(amask)
-                messages = []
-                sp = system_prompt or self.system_prompt
-                if sp:
-                    messages.append({"role": "system", "content": sp})
-                content = "<audio>" * n_audio + (" " + self.TRANSCRIBE_PROMPT if self.TRANSCRIBE_PROMPT else "")
-                messages.append({"role": "user", "content": content})
-                chat = self.tokenizer.apply_chat_template(messages, tokenize=True, add_generation_prompt=True,
-                                                          return_tensors="pt", enable_thinking=False)
-                input_ids = chat.input_ids if hasattr(chat, "input_ids") else chat
-                if input_ids.dim() == 1:
-                    input_ids = input_ids.unsqueeze(0)
-                if input_ids.shape[0] == 1 and B > 1:
-                    input_ids = input_ids.expand(B, -1)
-                attention_mask = torch.ones_like(input_ids)
-            ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
-            src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
-            return self.language_model.greedy_decode(ids, src_row, y.reshape(B * N, -1), attention_mask, max_new, eos_ids,
-                                                     pad_id)
+            args = self._prepare_generation(input_ids, input_features, audio_attention_mask, attention_mask, system_prompt,
+                                            dict(generate_kwargs))
+            return self.language_model.greedy_decode(**args)
+        finally:
+            self.train(was_training)
+
+    def generate_streaming(self, input_features: torch.Tensor, audio_attention_mask: torch.Tensor,
+                           system_prompt: Optional[str] = None, input_ids: Optional[torch.Tensor] = None,
+                           return_token_ids: bool = False, **generate_kwargs) -> Iterator:
+        """Partial transcript text, piece by piece, while the clip is still being decoded (ASRModel.generate_streaming,
+        tiny_audio/asr_modeling.py:648-760).  The reference runs ``language_model.generate`` on a thread feeding a
+        ``TextIteratorStreamer``; here the decode loop itself is a generator (one device sync per token), so no thread
+        is needed.  Text is released at word boundaries the way that streamer does (complete lines at once, otherwise
+        up to the last space; CJK characters immediately), special tokens are skipped and ``<think>...</think>`` spans
+        are dropped (:737-757).  One clip at a time, like the reference's streamer.
+
+        ``return_token_ids=True`` yields the raw int token id of every step instead (no tokenizer needed)."""
+        if input_features.shape[0] != 1:
+            raise ValueError("generate_streaming handles one clip at a time (TextIteratorStreamer: batch size 1 only)")
+        if not return_token_ids and self.tokenizer is None:
+            raise ValueError("generate_streaming needs a tokenizer to produce text (or return_token_ids=True)")
+        was_training = self.training
+        self.eval()
+        try:
+            with torch.no_grad():
+                args = self._prepare_generation(input_ids, input_features, audio_attention_mask, None, system_prompt,
+                                                dict(generate_kwargs))
+            eos = set(args["eos_ids"])
+            pieces = _TextPieces(self.tokenizer) if not return_token_ids else None
+            gate = _ThinkGate()
+            for col in self.language_model.greedy_decode_iter(per_token=True, **args):
+                if col.dim() != 1:                       # the closing full [B, n_new] tensor
+                    break
+                tok = int(col[0])
+                if return_token_ids:
+                    yield tok
+                    if tok in eos:
+                        break
+                    continue
+                for out in gate.feed(pieces.push(tok)):
+                    yield out
+                if tok in eos:
+                    break
+            if pieces is not None:
+                for out in gate.feed(pieces.flush()):
+                    yield out
+                tail = gate.flush()
+                if tail:
+                    yield tail
         finally:
             self.train(was_training)

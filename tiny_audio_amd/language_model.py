@@ -302,11 +302,25 @@ class Qwen3MI355X(torch.nn.Module):
     @torch.no_grad()
     def greedy_decode(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
                       sync_every=8, use_graph=True):
+        """-> int64 [B, n_new]; see ``greedy_decode_iter`` (this drains it, polling the device every ``sync_every``
+        steps only)."""
+        out = None
+        for out in self.greedy_decode_iter(input_ids, src_row, audio, attention_mask, max_new_tokens, eos_ids, pad_id,
+                                           sync_every, use_graph, per_token=False):
+            pass
+        return out
+
+    def greedy_decode_iter(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
+                           sync_every=8, use_graph=True, per_token=True):
         """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
         config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
         emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
         padded with ``pad_id``).  All per-step state lives on the device; the host only polls the number of
-        unfinished clips every ``sync_every`` steps."""
+        unfinished clips every ``sync_every`` steps.
+
+        A generator: with ``per_token`` it yields the int64 [B] host tensor of every step's tokens as soon as that step
+        has run (one device sync per token: the streaming mode of tiny_audio/asr_modeling.py:648-760) and stops when
+        every clip is finished; the last item yielded is always the full [B, n_new] device tensor."""
         if self._w is None:
             raise _lib.Ta355Error("LM weights not loaded")
         L_ = _lib.lib()
@@ -314,7 +328,8 @@ class Qwen3MI355X(torch.nn.Module):
         B, L = input_ids.shape
         max_new = int(max_new_tokens)
         if max_new <= 0:
-            return torch.empty((B, 0), dtype=torch.int64, device=dev)
+            yield torch.empty((B, 0), dtype=torch.int64, device=dev)
+            return
         Lmax = L + max_new
         if Lmax > c.max_position_embeddings:
             raise ValueError(f"prompt ({L}) + max_new_tokens ({max_new}) exceeds max_position_embeddings")
@@ -370,8 +385,10 @@ class Qwen3MI355X(torch.nn.Module):
         graph = None
         want_graph = (use_graph and dev.type == "cuda" and not _lib.DRY_RUN and max_new > 3
                       and os.environ.get("TA355_DECODE_GRAPH", "1") != "0")
+        if per_token:
+            yield out_seq[:, 0].cpu()
         for t in range(1, max_new):
-            if t % sync_every == 0 and int(alive.item()) == 0:
+            if (per_token or t % sync_every == 0) and int(alive.item()) == 0:
                 break
             if graph is not None:
                 graph.replay()
@@ -383,6 +400,8 @@ class Qwen3MI355X(torch.nn.Module):
                 graph.replay()                      # capture records, it does not run
             else:
                 step()
+            if per_token:
+                yield out_seq[:, t].cpu()
         seq = out_seq.cpu()
         # HF stops right after the step in which the last clip finished: trim the surplus (all-pad) columns
         n_new = max_new
@@ -390,7 +409,7 @@ class Qwen3MI355X(torch.nn.Module):
             is_eos = torch.isin(seq, torch.tensor(list(eos_ids), dtype=i64))
             first = torch.where(is_eos.any(-1), is_eos.to(torch.int8).argmax(-1) + 1, torch.full((B,), max_new + 1))
             n_new = min(max_new, int(first.max()))
-        return out_seq[:, :n_new]
+        yield out_seq[:, :n_new]
 
 
 class FrozenLMLoss(torch.autograd.Function):
