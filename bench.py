@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--projector", choices=["mlp", "moe", "qformer", "mosa"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
     ap.add_argument("--proj-hidden", type=int, default=1024, help="MLP projector hidden width (2048 = the 'embedded' recipe)")
+    ap.add_argument("--lm", choices=["0.6b", "1.7b"], default="0.6b",
+                    help="frozen LM shape: Qwen3-0.6B (north_star) or Qwen3-1.7B (hidden 2048, ffn 6144: transcription.yaml:14-16)")
     ap.add_argument("--lora", action="store_true",
                     help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -49,15 +51,15 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024):
+def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=3072):
     """BASELINE.md section 3 (2*MAC, dense).  lm_head is counted at the positions actually computed."""
     conv = 0.983 + 4.915
     enc = 32 * (2 * 500 * 4 * 1280 ** 2 + 4 * 500 ** 2 * 1280 + 4 * 500 * 1280 * 5120) / 1e9
     proj_f = 2 * 125 * (5120 * H + H * D) / 1e9
     proj_b = 2 * 125 * (2 * 5120 * H + 2 * H * D) / 1e9 - 2 * 125 * 5120 * H / 1e9        # dW1, dW2, dA1 (no dX)
-    lm_body = 28 * (2 * L * (1024 * 2048 + 2 * 1024 * 1024 + 2048 * 1024 + 3 * 1024 * 3072) + 2 * L * L * 2048) / 1e9
+    lm_body = 28 * (2 * L * (D * 2048 + 2 * D * 1024 + 2048 * D + 3 * D * F) + 2 * L * L * 2048) / 1e9   # 16 q / 8 kv heads x 128
     head_rows = (L if full_logits else 0) + n_label
-    head = 2 * head_rows * 1024 * V / 1e9 + 2 * n_label * 1024 * V / 1e9                  # fwd (+ labelled dH backward)
+    head = 2 * head_rows * D * V / 1e9 + 2 * n_label * D * V / 1e9                        # fwd (+ labelled dH backward)
     return conv + enc + proj_f + proj_b + 2 * lm_body + head
 
 
@@ -80,7 +82,8 @@ def main():
     from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
     from oracle import weights as OW
 
-    cfg = ASRConfig(projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
+    text = dict(hidden_size=2048, intermediate_size=6144) if a.lm == "1.7b" else None
+    cfg = ASRConfig(text_config=text, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
                     use_lora=a.lora, freeze_projector=a.lora)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
@@ -163,22 +166,23 @@ def main():
                         "hbm_kernels": hbm_kernel_rates(B, L, cfg, fe, wav, lens)}
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024:
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024 and a.lm == "0.6b":
         cpu = cpu_baseline(model, cfg, L)
 
     if rank == 0:
-        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden)
+        D_, F_ = cfg.text_config.hidden_size, cfg.text_config.intermediate_size
+        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden, D=D_, F=F_)
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
                "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
-                                       else ("configs[1]: MLP projector (H=%d, D=1024)" % a.proj_hidden) if a.projector == "mlp" else
+                                       else ("configs[1]: MLP projector (H=%d, D=%d)" % (a.proj_hidden, D_)) if a.projector == "mlp" else
                                        "QFormer projector (2 layers, 16 heads, windows of 15 -> 3 queries, 102 audio tokens)" if a.projector == "qformer" else
                                        "MOSA projector (2 stride-2 convs, 4 dense experts of width 4096)" if a.projector == "mosa" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
-                                      " bf16, GLM-ASR-Nano encoder 32L + Qwen3-0.6B 28L, "
-                                      "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % L,
+                                      " bf16, GLM-ASR-Nano encoder 32L + Qwen3-%s 28L, "
+                                      "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % (a.lm.upper(), L),
                           "clips_per_gpu": B, "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
                           "logits": a.logits, "audio_token_dropout": a.dropout,
                           "algorithmic_gflop_per_clip": round(gf, 1),

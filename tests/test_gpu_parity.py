@@ -181,9 +181,15 @@ def _true_batch(B=2, T=200):
     return dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
 
 
-def test_full_model_true_width_vs_oracle():
+LM_17B = OW.lm_config(vocab=5003, layers=2, hidden=2048, ffn=6144)     # Qwen3-1.7B widths (transcription.yaml:14-16)
+
+
+@pytest.mark.parametrize("lm_cfg", [TRUE_LM, LM_17B], ids=["qwen3-0.6b", "qwen3-1.7b"])
+def test_full_model_true_width_vs_oracle(lm_cfg):
+    TRUE_LM = lm_cfg
+    D = lm_cfg["hidden"]
     wE, wL = OW.init_encoder(TRUE_ENC, 0), OW.init_lm(TRUE_LM, 1)
-    wP = OW.init_mlp_projector(1280, 1024, 1024)
+    wP = OW.init_mlp_projector(1280, D, 1024)
     m = build_model(TRUE_ENC, TRUE_LM, 1024, wE, wL, wP, audio_token_id=AID)
     b = _true_batch()
     m.train()
