@@ -51,6 +51,14 @@ typedef struct {
   const float* b1;
   const void* w2;     /* bf16 [H, F] */
   const float* b2;
+  /* Optional derived images for the fused q|k|v path (all three NULL = the ta_enc_qkv_post path):
+   *   wqk_il  bf16 [2H, H]: the q | k rows of wqkv with every head's rows reordered for ta_gemm_opts.rope_tab
+   *           (row 2i = head dim i, row 2i+1 = head dim i+16 for i < 16, rows 32..63 unchanged); bqk_il [2H] likewise.
+   *   bo_fold [H] = bo + Wo b_v: softmax rows sum to 1, so attention(V + 1 b_v^T) = attention(V) + b_v^T and the v_proj
+   *           bias moves into the o_proj bias; V^T is then produced directly by the GEMM  V^T = Wv xn^T. */
+  const void* wqk_il;
+  const float* bqk_il;
+  const float* bo_fold;
 } ta_enc_layer;
 
 typedef struct {
@@ -63,6 +71,7 @@ typedef struct {
   const float *norm_w, *norm_b;
   const float *rope_cos, *rope_sin; /* [max_pos, 16] (partial rotary: 32 of 64 dims) */
   const ta_enc_layer* layers;       /* host array [n_layers] */
+  const float* rope_il;             /* [max_pos, 16, 2] (cos, sin) interleaved, or NULL (see ta_enc_layer.wqk_il) */
 } ta_encoder_weights;
 
 long ta_encoder_workspace_bytes(const ta_encoder_weights* w, int B, int T);
@@ -259,11 +268,18 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
  *                   TF:models/qwen3/modeling_qwen3.py:283-324 on bf16 models)
  *   swiglu_gu/dgu   SwiGLU backward in the epilogue: the bf16 result d(act) [M, N = F] (dX of Qwen3MLP.down_proj) is
  *                   not stored; d(gate|up) [M, 2F] is written to swiglu_dgu from gate|up swiglu_gu [M, 2F]
- *                   (plain row map, no bias / act / residual) */
+ *                   (plain row map, no bias / act / residual)
+ *   rope_tab/rows   act == 2: GLM-ASR partial rotary embedding (TF:models/glmasr/modeling_glmasr.py:153-168) applied to the
+ *                   bf16 result after the bias.  Heads are 64 columns (N % 64 == 0); W's rows must be ordered so that the
+ *                   first 32 columns of each head hold the 16 rotation pairs interleaved -- column 2i = head dim i,
+ *                   column 2i+1 = head dim i+16 -- and columns 32..63 = head dims 32..63 (q and k permuted alike leave
+ *                   q.k unchanged).  rope_tab f32 [rope_rows][16][2] = (cos, sin) of pair i at position p; row m of the
+ *                   GEMM is position m % rope_rows. */
 typedef struct {
   const void* a2; const void* w2; int k2; long lda2;
   const void* residual_bf16;
   const void* swiglu_gu; void* swiglu_dgu;
+  const float* rope_tab; int rope_rows;
 } ta_gemm_opts;
 int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
                         long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
@@ -291,6 +307,17 @@ int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, cons
 
 int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
                      int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, hipStream_t st);
+/* The same over caller-described operand layouts (element strides; NULL = the head-major defaults above):
+ *   Q(b,h,row,d)  = Q  + b*q_bs + h*q_hs + row*q_rs + d        K likewise with k_*
+ *   VT(b,h,d,col) = VT + b*v_bs + h*v_hs + d*v_rs + col
+ * so the encoder reads q | k straight from the token-major GEMM output [B*L, 2*H*64] and V^T from the [H*64, B*L]
+ * result of V^T = Wv xn^T (v_bs = L, v_rs = B*L: key columns beyond L belong to the next clip -- they are masked,
+ * but must be readable and finite: keep 64 elements of slack behind the image).  Column offsets that are not
+ * multiples of 8 elements are read with narrower loads. */
+typedef struct { long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs; } ta_attn_layout;
+int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
+                        int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, const ta_attn_layout* lay,
+                        hipStream_t st);
 int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V, const void* dO,
                      long dO_stride, const void* dOT, const float* LSE, const float* Delta, const int* kmask,
                      void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal,

@@ -529,3 +529,52 @@ def test_rmsnorm_bf16_stream():
     dx0, dxb0, _ = ops.rmsnorm_bwd(dy, xb.float(), r0, w, dres=dres)
     dx1, dxb1, _ = ops.rmsnorm_bwd(dy, xb, r1, w, dres=dres)
     assert relerr(dx1, dx0) < 1e-6 and relerr(dxb1, dxb0) < 1e-2          # (FMA contraction may differ between the two instantiations)
+
+
+# ----------------------------------------------------------------------------- fused encoder q|k|v path
+def il_perm():
+    """column p of a head <- head dim (the interleaved rotary layout of ta_gemm_opts.rope_tab)."""
+    p = torch.arange(64)
+    return torch.where(p < 32, (p >> 1) + 16 * (p & 1), p)
+
+
+@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+def test_gemm_rope_epilogue(variant, monkeypatch):
+    """act = 2: q|k = rope(A W^T + b) with W's rows in the interleaved pair order == HF rotate-half rope on the plain
+    projection, column-permuted (TF:models/glmasr/modeling_glmasr.py:153-168)."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    B, S, nh, K = 3, 100, 5, 256
+    M, N = B * S, 2 * nh * 64
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    bias = 0.1 * rnd(N, seed=3)
+    cos, sin = rope_tables(128, 32, 10000.0)                                  # [128, 16]
+    tab = torch.stack([cos, sin], -1).contiguous()
+    rows = (torch.arange(2 * nh)[:, None] * 64 + il_perm()[None, :]).reshape(-1).to(DEV)
+    out = ops.gemm_nt(A, W[rows].contiguous(), bias=bias[rows].contiguous(), act=2, rope=(tab, S))
+    y = (A.float() @ W.float().T + bias).reshape(B, S, 2 * nh, 64)
+    c = torch.cat([cos[:S], cos[:S]], -1)[None, :, None]; s = torch.cat([sin[:S], sin[:S]], -1)[None, :, None]
+    ref = torch.cat([y[..., :32] * c + rot_half(y[..., :32]) * s, y[..., 32:]], -1)
+    ref = ref[..., il_perm().to(DEV)].reshape(M, N)
+    assert relerr(out, ref) < 8e-3
+    assert relerr(ops.gemm_nt(A, W, out_dtype=F32), A.float() @ W.float().T) < 2e-3       # next call: plain again
+
+
+@pytest.mark.parametrize("S", [104, 100, 99])        # V^T clip offsets 16-B, 8-B and 2-B aligned
+def test_attention_fwd_strided_layout(S):
+    """ta_attention_fwd_ex over the encoder's fused layout (token-major q|k, V^T as [H*64, B*S]) == the head-major call."""
+    B, nh, hd = 3, 5, 64
+    M, H = B * S, nh * hd
+    qk = rnd(M, 2 * H, seed=1).to(BF16)
+    v = rnd(M, H, seed=2).to(BF16)
+    vt = torch.zeros(H * M + 64, device=DEV, dtype=BF16)
+    vt[:H * M] = v.T.contiguous().reshape(-1)
+    lay = (S * 2 * H, 64, 2 * H, S * 2 * H, 64, 2 * H, S, 64 * M, M)
+    O = ops.attention_fwd_strided(qk, qk[:, H:], vt, B, nh, nh, S, hd, False, 0.125, lay)
+    q = qk[:, :H].reshape(B, S, nh, hd).transpose(1, 2).contiguous()
+    k = qk[:, H:].reshape(B, S, nh, hd).transpose(1, 2).contiguous()
+    vh = v.reshape(B, S, nh, hd).transpose(1, 2).contiguous()
+    ref, _ = ops.attention_fwd(q, k, to_T(vh, ops.pad64(S)), S, False, 0.125, None, want_lse=False)
+    assert relerr(O, ref) < 1e-6, relerr(O, ref)
+    ref32, _ = ref_attention(q.float(), k.float(), vh.float(), False, 0.125, None)
+    assert relerr(O, ref32.transpose(1, 2).reshape(M, H)) < 2e-2

@@ -138,18 +138,27 @@ TRUE_LM = OW.lm_config(vocab=5003, layers=2)        # true widths; small odd voc
 AID, PAD, EOS = 5002, 4990, 4991
 
 
-def test_encoder_true_width_vs_oracle():
+@pytest.mark.parametrize("B,T", [(2, 301), (2, 207), (8, 77)], ids=["S151-unfused", "S104-fused", "S39-fused-unaligned"])
+def test_encoder_true_width_vs_oracle(B, T, monkeypatch):
+    """(2, 301): M = 302 is not a multiple of 8 -> the qkv_post path; the other two run the fused q|k|v path (rope in the
+    GEMM epilogue, V^T from a GEMM, strided attention), with 16-B-aligned and element-aligned clip offsets in V^T."""
     w = OW.init_encoder(TRUE_ENC, 0)
     enc = GlmAsrEncoderMI355X(EncoderConfig(TRUE_ENC), DEV).load_state_dict_hf(w)
-    x = (0.6 * np.random.RandomState(3).standard_normal((2, 128, 301))).astype(np.float32)   # odd T, S = 151
+    x = (0.6 * np.random.RandomState(3).standard_normal((B, 128, T))).astype(np.float32)
+    S = (T - 1) // 2 + 1
     ref = OE.encoder_forward(x, w, TRUE_ENC)
     out = enc(torch.from_numpy(x), return_f32=True).last_hidden_state
-    assert out.shape == (2, 151, 1280)
+    assert out.shape == (B, S, 1280)
     assert relmax(npy(out), ref) < 2e-2 and cosine(npy(out), ref) > 0.9995
-    keep = (np.random.RandomState(4).rand(2, 151) < 0.8).astype(np.float32)
-    out = enc(torch.from_numpy(x), frame_keep=torch.from_numpy(keep).reshape(-1), return_f32=True).last_hidden_state
-    assert relmax(npy(out), ref * keep[:, :, None]) < 2e-2
-    assert float(npy(out)[keep == 0].__abs__().max()) == 0.0          # dropped frames are exactly zero, no rescale
+    keep = (np.random.RandomState(4).rand(B, S) < 0.8).astype(np.float32)
+    outk = enc(torch.from_numpy(x), frame_keep=torch.from_numpy(keep).reshape(-1), return_f32=True).last_hidden_state
+    assert relmax(npy(outk), ref * keep[:, :, None]) < 2e-2
+    assert float(npy(outk)[keep == 0].__abs__().max()) == 0.0          # dropped frames are exactly zero, no rescale
+    if (B * S) % 8 == 0:                                               # both paths compute the same function
+        monkeypatch.setenv("TA355_ENC_QKV_FUSED", "0")
+        out0 = enc(torch.from_numpy(x), return_f32=True).last_hidden_state
+        assert relmax(npy(out0), ref) < 2e-2 and relmax(npy(out), npy(out0)) < 1.5e-2
+        assert not np.array_equal(npy(out), npy(out0))                 # ... through different kernels
 
 
 @pytest.mark.parametrize("hidden", [1024, 2048])

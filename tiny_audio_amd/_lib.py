@@ -31,7 +31,7 @@ class Ta355Error(RuntimeError):
 # ----------------------------------------------------------------------------- structs (must mirror ta355.h)
 class EncLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo",
-                                          "w1", "b1", "w2", "b2")]
+                                          "w1", "b1", "w2", "b2", "wqk_il", "bqk_il", "bo_fold")]
 
 
 class EncoderWeights(C.Structure):
@@ -39,7 +39,7 @@ class EncoderWeights(C.Structure):
                 ("n_mels", C.c_int), ("max_pos", C.c_int), ("ln_eps", C.c_float),
                 ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(EncLayer))]
+                ("layers", C.POINTER(EncLayer)), ("rope_il", C.c_void_p)]
 
 
 class MlpWeights(C.Structure):
@@ -63,7 +63,11 @@ class LmLayer(C.Structure):
 
 class GemmOpts(C.Structure):
     _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
-                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p)]
+                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int)]
+
+
+class AttnLayout(C.Structure):
+    _fields_ = [(n, C.c_long) for n in ("q_bs", "q_hs", "q_rs", "k_bs", "k_hs", "k_rs", "v_bs", "v_hs", "v_rs")]
 
 
 class LmLoraGrads(C.Structure):

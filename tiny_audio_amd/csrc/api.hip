@@ -26,7 +26,7 @@ EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
   e.x1 = c.take<bf16_t>((size_t)B * (T + 2) * H);
   e.xr = (float*)c.take<float>((size_t)M * H);      // residual stream (bf16 by default: the fp32 size is reserved)
   e.xn = c.take<bf16_t>((size_t)M * H);
-  e.qkv = c.take<bf16_t>((size_t)M * 3 * H);
+  e.qkv = c.take<bf16_t>((size_t)M * 3 * H + 128);  // fused path: q|k [M, 2H] then V^T [H, M] + the slack its last tile reads
   e.q = c.take<bf16_t>((size_t)M * H);
   e.k = c.take<bf16_t>((size_t)M * H);
   e.vt = c.take<bf16_t>((size_t)B * H * Sp);
@@ -72,13 +72,29 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   RC(ta_gemm_bf16_nt(e.x1, w->conv2_w, e.xr, M, H, 3 * H, 2L * H, S, (long)(T + 2) * H, H, 0, 0, 0, w->conv2_b, nullptr,
                      1, rb, 1, nullptr, st));
   const float scale = 0.125f;   // head_dim ** -0.5, head_dim = 64
+  // Fused q|k|v path (no qkv_post pass: 246 MB of HBM traffic per layer at B = 32): needs the derived weight images and
+  // M % 8 == 0 (the V^T GEMM has N = ldc = M).  TA355_ENC_QKV_FUSED=0 keeps the three-kernel path.
+  const char* fz = getenv("TA355_ENC_QKV_FUSED");             // read per call: the tests compare both paths
+  const bool fused = !(fz && *fz == '0') && w->rope_il && (M % 8) == 0;
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_enc_layer& L = w->layers[l];
     RC(ln(L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr));
-    RC(gemm(e.xn, L.wqkv, e.qkv, M, 3 * H, H, L.bqkv, nullptr, 0, 1, st));
-    RC(ta_enc_qkv_post(e.qkv, w->rope_cos, w->rope_sin, e.q, e.k, e.vt, B, nh, S, Sp, st));
-    RC(ta_attention_fwd(e.q, e.k, e.vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, st));
-    RC(res_gemm(e.ao, L.wo, H, L.bo));
+    if (fused && L.wqk_il && L.bqk_il && L.bo_fold) {
+      // q|k = rope(xn Wqk^T + b) straight from the GEMM epilogue (token-major [M, 2H], heads' rotary pairs interleaved),
+      // V^T [H, M] = Wv xn^T as a second GEMM (its bias lives in bo_fold); attention reads both in place.
+      ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S;
+      RC(gemm_opt(e.xn, L.wqk_il, e.qkv, M, 2 * H, H, L.bqk_il, nullptr, 2, 1, o, st));
+      bf16_t* vt = e.qkv + (size_t)M * 2 * H;
+      RC(gemm((const bf16_t*)L.wqkv + (size_t)2 * H * H, e.xn, vt, H, M, H, nullptr, nullptr, 0, 1, st));
+      const ta_attn_layout lay = {(long)S * 2 * H, 64, 2L * H, (long)S * 2 * H, 64, 2L * H, S, 64L * M, M};
+      RC(ta_attention_fwd_ex(e.qkv, e.qkv + H, vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, &lay, st));
+      RC(res_gemm(e.ao, L.wo, H, L.bo_fold));
+    } else {
+      RC(gemm(e.xn, L.wqkv, e.qkv, M, 3 * H, H, L.bqkv, nullptr, 0, 1, st));
+      RC(ta_enc_qkv_post(e.qkv, w->rope_cos, w->rope_sin, e.q, e.k, e.vt, B, nh, S, Sp, st));
+      RC(ta_attention_fwd(e.q, e.k, e.vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, st));
+      RC(res_gemm(e.ao, L.wo, H, L.bo));
+    }
     RC(ln(L.ln2_w, L.ln2_b, e.xn, nullptr, nullptr));
     RC(gemm(e.xn, L.w1, e.hf, M, F, H, L.b1, nullptr, 1, 1, st));
     RC(res_gemm(e.hf, L.w2, F, L.b2));

@@ -19,6 +19,7 @@
 //                (first version padded rows to 144 B: SQ_LDS_BANK_CONFLICT showed 30 % conflict cycles)
 #include <cstdlib>
 #include "common.h"
+#include "../../include/ta355.h"
 
 #define KV_TILE 64
 #define CT_STRIDE 128          // bytes, [d][64 keys] tiles; 8-byte granule index XOR (row & 15)
@@ -63,12 +64,24 @@ template <int HD>
 struct ColStage {   // HD rows x 64 bf16 (128 B per row) from a [.., HD, Lp] image
   static constexpr int N = HD / 32;
   uint4 v[N];
-  __device__ __forceinline__ void load(const bf16_t* base, int Lp, int col0, int tid) {
+  // al: 0 = every chunk 16-B aligned, 1 = 8-B aligned (e.g. clip offsets b * 500 columns), 2 = element aligned
+  __device__ __forceinline__ void load(const bf16_t* base, long Lp, int col0, int tid, int al = 0) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int ch = tid + i * 256;
       const int r = ch >> 3, c = ch & 7;
-      v[i] = *(const uint4*)(base + (long)r * Lp + col0 + c * 8);
+      const bf16_t* src = base + (long)r * Lp + col0 + c * 8;
+      if (al == 0) {
+        v[i] = *(const uint4*)src;
+      } else if (al == 1) {
+        const uint2 a = *(const uint2*)src, b = *(const uint2*)(src + 4);
+        v[i] = make_uint4(a.x, a.y, b.x, b.y);
+      } else {
+        uint32_t u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = (uint32_t)src[2 * k] | ((uint32_t)src[2 * k + 1] << 16);
+        v[i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
     }
   }
   __device__ __forceinline__ void store(char* lds, int tid) const {
@@ -137,7 +150,8 @@ template <int HD, bool CAUSAL, int QSUB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ VT, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE, const int* __restrict__ kmask,
-                                                       int B, int Hq, int Hkv, int L, int Lp, float scale) {
+                                                       int B, int Hq, int Hkv, int L, int Lp, float scale,
+                                                       const ta_attn_layout lay, const int valign) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ND = HD / 16;                        // O^T row blocks; block ND is the row-sum block
   char* Ks = smem;
@@ -151,9 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int b = group / Hkv, hk = group % Hkv;
   const int h = hk * grp + member / nq, qt = member % nq;
   const int q0 = qt * QROWS + wave * 16 * QSUB;         // first query row of this wave
-  const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
-  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
-  const bf16_t* Vb = VT + ((long)(b * Hkv + hk) * HD) * Lp;
+  const bf16_t* Qb = Q + b * lay.q_bs + h * lay.q_hs;
+  const bf16_t* Kb = K + b * lay.k_bs + hk * lay.k_hs;
+  const bf16_t* Vb = VT + b * lay.v_bs + hk * lay.v_hs;
   const float sl2 = scale * LOG2E;
 
   // rows HD .. HD+15 of the V^T image: [1 1 1 ...] then zeros (written once, never restaged)
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   for (int sub = 0; sub < QSUB; ++sub) {
     int qr = q0 + sub * 16 + l15; if (qr > L - 1) qr = L - 1;
 #pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) qf[sub][ks] = *(const bf16x8*)(Qb + (long)qr * HD + ks * 32 + g * 8);
+    for (int ks = 0; ks < HD / 32; ++ks) qf[sub][ks] = *(const bf16x8*)(Qb + (long)qr * lay.q_rs + ks * 32 + g * 8);
   }
   f32x4 o[QSUB][ND + 1];
 #pragma unroll
@@ -181,8 +195,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   if (CAUSAL) { const int lim = (qt * QROWS + QROWS - 1) / KV_TILE + 1; if (lim < ntiles) ntiles = lim; }
 
   RowStage<HD> ks_reg; ColStage<HD> vs_reg; int mk_reg = 1;
-  ks_reg.load(Kb, HD, 0, L, tid);
-  vs_reg.load(Vb, Lp, 0, tid);
+  ks_reg.load(Kb, lay.k_rs, 0, L, tid);
+  vs_reg.load(Vb, lay.v_rs, 0, tid, valign);
   if (kmask && tid < 64) mk_reg = (tid < L) ? kmask[(long)b * L + tid] : 0;
 
   for (int t = 0; t < ntiles; ++t) {
@@ -192,8 +206,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     if (tid < 64) Ms[tid] = mk_reg;
     __syncthreads();
     if (t + 1 < ntiles) {
-      ks_reg.load(Kb, HD, key0 + KV_TILE, L, tid);
-      vs_reg.load(Vb, Lp, key0 + KV_TILE, tid);
+      ks_reg.load(Kb, lay.k_rs, key0 + KV_TILE, L, tid);
+      vs_reg.load(Vb, lay.v_rs, key0 + KV_TILE, tid, valign);
       if (kmask && tid < 64) { const int kk = key0 + KV_TILE + tid; mk_reg = (kk < L) ? kmask[(long)b * L + kk] : 0; }
     }
     // ---- S^T = K Q^T for both query sub-tiles
@@ -681,10 +695,16 @@ template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + (HD + 16
 extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask,
                                 int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
                                 hipStream_t st) {
+  return ta_attention_fwd_ex(Q, K, VT, O, LSE, kmask, B, Hq, Hkv, L, Lp, head_dim, causal, scale, nullptr, st);
+}
+
+extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask,
+                                   int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                                   const ta_attn_layout* lay_in, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L) return TA_ERR_ARG;
   // LM with a short prompt: the whole sequence of a (clip, kv head) lives in LDS, one workgroup serves the GQA group
-  {
+  if (!lay_in) {
     const int grp = Hq / Hkv;
     static const bool gqa_off = [] { const char* e = getenv("TA355_ATTN_GQA"); return e && *e == '0'; }();
     if (!gqa_off && head_dim == 128 && causal && L <= 192 && grp * ((L + 31) / 32) <= 12) {
@@ -698,12 +718,20 @@ extern "C" int ta_attention_fwd(const void* Q, const void* K, const void* VT, vo
       return TA_OK;
     }
   }
+  const long hd = head_dim;
+  ta_attn_layout lay = {Hq * L * hd, L * hd, hd, Hkv * L * hd, L * hd, hd, Hkv * hd * Lp, hd * Lp, Lp};   // head-major images
+  if (lay_in) lay = *lay_in;
+  // Q / K rows are read as 16-B chunks; V^T chunks may sit at any element offset (narrower loads)
+  if (((lay.q_bs | lay.q_hs | lay.q_rs | lay.k_bs | lay.k_hs | lay.k_rs) & 7) || (((uintptr_t)Q | (uintptr_t)K) & 15)) return TA_ERR_ARG;
+  const long vor = lay.v_bs | lay.v_hs | lay.v_rs;
+  const uintptr_t vp = (uintptr_t)VT;
+  const int valign = (!(vor & 7) && !(vp & 15)) ? 0 : ((!(vor & 3) && !(vp & 7)) ? 1 : 2);
   // encoder (hd 64, S = 500, non-causal): 128 query rows per workgroup; LM (hd 128, short causal L): 64
   const int qsub = (head_dim == 64) ? 2 : 1;
   dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64 * qsub), B * Hkv)), blk(256);
 #define FWD(HD_, C_)                                                                                              \
   TA_LAUNCH((attn_fwd_kernel<HD_, C_, (HD_ == 64 ? 2 : 1)>), grid, blk, fwd_lds<HD_>(), st, (const bf16_t*)Q, (const bf16_t*)K, \
-                     (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, Lp, scale)
+                     (const bf16_t*)VT, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, Lp, scale, lay, valign)
   if (head_dim == 64 && !causal) FWD(64, false);
   else if (head_dim == 64 && causal) FWD(64, true);
   else if (head_dim == 128 && causal) FWD(128, true);

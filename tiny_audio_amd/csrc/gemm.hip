@@ -43,6 +43,10 @@ struct GemmArgs {
   // from sw_gu [M, 2F] and writes d(gate|up) to sw_dgu [M, 2F]  (plain row map only)
   const bf16_t* sw_gu; bf16_t* sw_dgu;
   int res_bf16;        // the residual is bf16 (same row map as C), not f32
+  // act == 2: partial rotary embedding in the epilogue (GLM-ASR q|k projection).  Heads are 64 columns; the first 32
+  // columns of every head hold the 16 rotation pairs INTERLEAVED (pair i = columns 2i, 2i+1), so both members of a pair
+  // sit in one lane; rope_tab [rope_rows][16][2] = (cos, sin) of pair i at position (logical row % rope_rows)
+  const float* rope_tab; int rope_rows;
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
 };
@@ -72,7 +76,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // exchanged between lane rows with v_permlane16_swap: afterwards lane g holds 8 consecutive columns
 // (16 * (j + (g & 1)) + 8 * (g >> 1) ...) and one store covers 64 contiguous bytes per row.
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
-__device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide) {
+__device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
+                                               int m) {
   uint2 o[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -86,6 +91,15 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       }
       if (ACT == 1) {
         v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
+      }
+      if (ACT == 2) {
+        const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
+        if (pc < 32) {
+          const float4 t = *(const float4*)(p.rope_tab + ((long)(m % p.rope_rows) * 16 + (pc >> 1)) * 2);   // c0 s0 c1 s1
+          const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+          v[0] = a0 * t.x - a1 * t.y; v[1] = a1 * t.x + a0 * t.y;
+          v[2] = a2 * t.z - a3 * t.w; v[3] = a3 * t.z + a2 * t.w;
+        }
       }
       if (HAS_RES) {
         if (p.res_bf16) {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide);
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m);
   }
 }
 
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m);
   }
 }
 
@@ -585,7 +599,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
                                    int act, int out_bf16, int splits, float* splitk_ws,
                                    const int* a_idx, const int* seg, const int* krange, const ta_gemm_opts* opts,
                                    hipStream_t st) {
-  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
   const ta_gemm_opts& o = opts ? *opts : none;
   const void* resb = o.residual_bf16;
   if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
@@ -608,6 +622,8 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = o.lda2;
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
   a.res_bf16 = resb != nullptr;
+  a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
+  if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64))) return TA_ERR_ARG;
   if (resb && splits > 1) return TA_ERR_ARG;
   if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;
   if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
@@ -637,6 +653,8 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   } else if (act == 1) {
     if (out_bf16) return hr ? launch_gemm<1, true, true>(a, st) : launch_gemm<1, true, false>(a, st);
     return hr ? launch_gemm<1, false, true>(a, st) : launch_gemm<1, false, false>(a, st);
+  } else if (act == 2) {
+    return launch_gemm<2, true, false>(a, st);
   }
   return TA_ERR_ARG;
 }

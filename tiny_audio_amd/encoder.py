@@ -108,18 +108,40 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         self._finalize()
         return self
 
+    @torch.no_grad()
+    def _derive_fused_qkv(self):
+        """Weight images of the fused q|k|v path (ta355.h, ta_enc_layer.wqk_il): q|k rows with every head's rotary pairs
+        interleaved, the v_proj bias folded through o_proj, and the (cos, sin) table in pair order."""
+        c, b = self.config, self._bufs
+        H, nh = c.hidden_size, c.num_attention_heads
+        hd = H // nh
+        dev = b["rope_cos"].device
+        p = torch.arange(hd, device=dev)
+        d_of_p = torch.where(p < 32, (p >> 1) + 16 * (p & 1), p)                       # column p of a head <- head dim
+        rows = (torch.arange(nh, device=dev)[:, None] * hd + d_of_p[None, :]).reshape(-1)
+        rows = torch.cat([rows, H + rows])
+        b["rope_il"] = torch.stack([b["rope_cos"], b["rope_sin"]], dim=-1).contiguous()   # [max_pos, 16, 2]
+        for i in range(c.num_hidden_layers):
+            q = f"layers.{i}."
+            b[q + "wqk_il"] = b[q + "wqkv"][rows].contiguous()
+            b[q + "bqk_il"] = b[q + "bqkv"][rows].contiguous()
+            b[q + "bo_fold"] = (b[q + "bo"] + b[q + "wo"].float() @ b[q + "bqkv"][2 * H:]).contiguous()
+
     def _finalize(self):
         c, b = self.config, self._bufs
         L = c.num_hidden_layers
+        if c.hidden_size // c.num_attention_heads == 64:
+            self._derive_fused_qkv()
         arr = (_lib.EncLayer * L)()
         for i in range(L):
             p = f"layers.{i}."
             for f, _ in _lib.EncLayer._fields_:
-                setattr(arr[i], f, b[p + f].data_ptr())
+                setattr(arr[i], f, b[p + f].data_ptr() if (p + f) in b else None)
         w = _lib.EncoderWeights(hidden=c.hidden_size, ffn=c.intermediate_size, n_layers=L, heads=c.num_attention_heads,
                                 n_mels=c.num_mel_bins, max_pos=c.max_position_embeddings, ln_eps=c.layer_norm_eps)
         for f in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "norm_w", "norm_b", "rope_cos", "rope_sin"):
             setattr(w, f, b[f].data_ptr())
+        w.rope_il = b["rope_il"].data_ptr() if "rope_il" in b else None
         w.layers = C.cast(arr, C.POINTER(_lib.EncLayer))
         self._layers_arr, self._w = arr, w
 

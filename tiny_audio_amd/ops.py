@@ -34,14 +34,18 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None):
+            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
-    k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile)."""
+    k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile);
+    rope=(table f32 [rows,16,2], rows) with act=2: interleaved partial rotary embedding in the epilogue (ta355.h)."""
     _req(A, BF16); _req(W, BF16)
     opts = None
-    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None:
+    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None:
         from ._lib import GemmOpts
         opts = GemmOpts()
+        if rope is not None:
+            _req(rope[0], F32)
+            opts.rope_tab, opts.rope_rows = ptr(rope[0]), int(rope[1])
         if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
             _req(residual_bf16, BF16)
             opts.residual_bf16 = ptr(residual_bf16)
@@ -131,6 +135,17 @@ def attention_fwd(Q, K, VT, L, causal, scale, kmask=None, want_lse=True):
     check(lib().ta_attention_fwd(ptr(Q), ptr(K), ptr(VT), ptr(O), ptr(lse), ptr(kmask), B, Hq, Hkv, L, Lp, hd,
                                  int(causal), scale, stream()), "ta_attention_fwd")
     return O, lse
+
+
+def attention_fwd_strided(Q, K, VT, B, Hq, Hkv, L, hd, causal, scale, layout, kmask=None):
+    """ta_attention_fwd_ex: operands described by element strides (q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs)."""
+    import ctypes as _C
+    from ._lib import AttnLayout
+    lay = AttnLayout(*[int(v) for v in layout])
+    O = torch.empty((B * L, Hq * hd), device=Q.device, dtype=BF16)
+    check(lib().ta_attention_fwd_ex(ptr(Q), ptr(K), ptr(VT), ptr(O), None, ptr(kmask), B, Hq, Hkv, L, pad64(L), hd,
+                                    int(causal), scale, _C.addressof(lay), stream()), "ta_attention_fwd_ex")
+    return O
 
 
 def attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, causal, scale, kmask=None):
