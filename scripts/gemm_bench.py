@@ -27,6 +27,27 @@ def timeit(fn, reps=reps, warm=3):
     return a.elapsed_time(b) / reps * 1e-3
 
 
+_flush = None
+
+
+def time_cold(fn, reps=10):
+    """each launch timed alone after a 1 GB write pass (L2 + infinity cache hold none of the operands)"""
+    global _flush
+    if _flush is None:
+        _flush = torch.empty(512 * 1024 * 1024, device=DEV, dtype=torch.int16)
+    tot = 0.0
+    for _ in range(reps):
+        _flush.fill_(1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        tot += a.elapsed_time(b)
+    return tot / reps * 1e-3
+
+
+if "--cold" in sys.argv:
+    timeit = lambda fn: time_cold(fn)
+
 res = {}
 if only in ("all", "gemm"):
     shapes = [  # name, M, N, K, out_bf16, act, residual
@@ -36,10 +57,16 @@ if only in ("all", "gemm"):
         ("lm_qkv", 6144, 4096, 1024, True, 0, False), ("lm_o", 6144, 1024, 2048, False, 0, True),
         ("lm_gu", 6144, 6144, 1024, True, 0, False), ("lm_down", 6144, 1024, 3072, False, 0, True),
         ("lm_dact", 6144, 3072, 1024, True, 0, False), ("lm_dxn_gu", 6144, 1024, 6144, False, 0, False),
+        # the LM's N <= 2048 GEMMs as the step runs them now (bf16 stream: bf16 out, bf16 residual in place)
+        ("lmb_o", 6144, 1024, 2048, True, 0, "bf16"), ("lmb_down", 6144, 1024, 3072, True, 0, "bf16"),
+        ("lmb_dao", 6144, 2048, 1024, True, 0, False), ("lmb_dxn_qkv", 6144, 1024, 4096, True, 0, False),
+        ("lmb_dxn_gu", 6144, 1024, 6144, True, 0, False),
         ("head_fwd", 1152, 151680, 1024, False, 0, False), ("sq4096", 4096, 4096, 4096, True, 0, False),
         ("sq8192", 8192, 8192, 8192, True, 0, False),
     ]
     variants = sys.argv[sys.argv.index("--variants") + 1].split(",") if "--variants" in sys.argv else [""]
+    if "--match" in sys.argv:
+        shapes = [s_ for s_ in shapes if sys.argv[sys.argv.index("--match") + 1] in s_[0]]
     for name, M, N, K, obf, act, hasres in shapes:
       for var in variants:
         os.environ["TA355_GROUP_M"] = var.split("g")[1] if "g" in var else ""
@@ -51,10 +78,11 @@ if only in ("all", "gemm"):
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(BF16)
         out = torch.empty(M, N, device=DEV, dtype=BF16 if obf else F32)
         bias = torch.randn(N, device=DEV) if act else None
-        resid = out if hasres else None
+        resid = out if hasres is True else None
+        resid_bf = out if hasres == "bf16" else None
         if hasres:
             out.zero_()
-        t = timeit(lambda: ops.gemm_nt(A, W, out=out, bias=bias, residual=resid, act=act))
+        t = timeit(lambda: ops.gemm_nt(A, W, out=out, bias=bias, residual=resid, residual_bf16=resid_bf, act=act))
         res[name_v] = round(2.0 * M * N * K / t / 1e12, 1)
         print(f"{name_v:14s} M={M:6d} N={N:6d} K={K:5d}  {t * 1e6:8.1f} us  {res[name_v]:7.1f} TF/s", flush=True)
         del A, W, out

@@ -470,7 +470,7 @@ def test_relu_and_mix():
     assert relerr(dob, ot.grad) < 1e-2 and relerr(dlg, lt.grad) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
 def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     """dX GEMM of down_proj with the SwiGLU backward in its epilogue == GEMM followed by ta_swiglu_bwd."""
     if variant is not None:
@@ -488,7 +488,7 @@ def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     assert relerr(ops.gemm_nt(dx, W, out_dtype=F32), dact) < 2e-3             # one-shot
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
 def test_gemm_bf16_residual_in_place(variant, monkeypatch):
     """x += A W^T + b with a bf16 residual stream aliased to the output (the encoder's residual GEMMs)."""
     if variant is not None:
@@ -538,7 +538,7 @@ def il_perm():
     return torch.where(p < 32, (p >> 1) + 16 * (p & 1), p)
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
 def test_gemm_rope_epilogue(variant, monkeypatch):
     """act = 2: q|k = rope(A W^T + b) with W's rows in the interleaved pair order == HF rotate-half rope on the plain
     projection, column-permuted (TF:models/glmasr/modeling_glmasr.py:153-168)."""

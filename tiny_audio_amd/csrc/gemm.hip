@@ -60,6 +60,7 @@ struct GemmArgs {
 #define TA355_RATE_256x256 0.9      /* simple double buffer: superseded by the ping-pong schedule */
 #define TA355_RATE_256x128 0.5      /* measured slower than 128x128 on every shape */
 #define TA355_RATE_256x256_PP 1.40  /* per unit tile area vs the 128x128 kernel, fitted on profiles/r01_f_gemm_variants.txt (lm_qkv 56 vs 62 us, sq8192 1330 vs 1050 TF/s) */
+#define TA355_RATE_96x128 0.93      /* 3x4 instead of 4x4 MFMAs per fragment set; estimate, to be refitted */
 #define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
@@ -150,8 +151,11 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 }
 __device__ __forceinline__ bool epilogue_wide_ok(const GemmArgs& p) { return p.wide != 0; }
 
-template <int ACT, bool OUT_BF16, bool HAS_RES>
+// BMT = 128, or 96 rows per tile (waves 2x2 of 48x64): M = 6144 x N = 1024 is then 512 tiles = every resident slot of the
+// chip (two workgroups per CU) instead of 384.
+template <int ACT, bool OUT_BF16, bool HAS_RES, int BMT = 128>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int MI = BMT / 32, WR = BMT / 2;       // 16-row fragments per wave, rows per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int gsize = min(p.tiles_m - first_m, GROUP_M);
   const int pm = first_m + (t % width) % gsize;
   const int pn = (t % width) / gsize;
-  const int m0 = pm * BM, n0 = pn * BN;
+  const int m0 = pm * BMT, n0 = pn * BN;
 
   const int nkt = p.K / BK;
   int kt_begin = (int)(((long)nkt * z) / p.splits);
@@ -187,15 +191,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // ---- per-thread DMA source pointers: 4 x 16 B chunks of A and of W per K-step
   const int lr = tid >> 3;
   const int clog = (tid & 7) ^ ((lr >> 1) & 7);
-  const char* a_src[4];
+  const char* a_src[MI];
   const char* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = i * 32 + lr;
-    int gm = rbase + min(m0 + r, Mact - 1);
-    if (p.a_idx) gm = p.a_idx[gm];
-    const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
-    a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
+    if (i < MI) {
+      int gm = rbase + min(m0 + r, Mact - 1);
+      if (p.a_idx) gm = p.a_idx[gm];
+      const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+      a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
+    }
     const int gn = min(n0 + r, p.N - 1);
     w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
   }
@@ -203,14 +209,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   // ---- per-lane fragment read offsets (bytes) inside a tile
   const int swz = l15 >> 1;
-  const int a_rd = (wm * 64 + l15) * 128;
+  const int a_rd = (wm * WR + l15) * 128;
   const int b_rd = (wn * 64 + l15) * 128;
   const int koff0 = ((0 + g) ^ swz) << 4;
   const int koff1 = ((4 + g) ^ swz) << 4;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -220,14 +226,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = i * 32 + lr;
-        a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + r, Mact - 1)) * p.lda2 + clog * 8);
+        if (i < MI) a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + r, Mact - 1)) * p.lda2 + clog * 8);
         w_src[i] = (const char*)(p.W2 + (long)min(n0 + r, p.N - 1) * p.K2 + clog * 8);
       }
     }
     ++next_tile;
     char* base = lds_w + buf * (2 * TILE_BYTES);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       glds16(a_src[i], base + i * 4096);
       a_src[i] += BK * 2;
     }
@@ -248,13 +254,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ko = kk ? koff1 : koff0;
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[MI], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(As + a_rd + i * 2048 + ko);
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(As + a_rd + i * 2048 + ko);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(Bs + b_rd + j * 2048 + ko);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
@@ -267,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ml = m0 + wm * 64 + i * 16 + l15;
+  for (int i = 0; i < MI; ++i) {
+    const int ml = m0 + wm * WR + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
@@ -500,7 +506,7 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
 
-// Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong,
+// Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 5 = 96x128 (same kernel), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong,
 // 4 = 256x320 ping-pong (N = 1280 / 3840 / 5120 divide exactly: M = 16000 x N = 1280 is 252 tiles = ONE round of 256 CUs).
 // Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
 // come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0..3 forces one (experiments, tests).
@@ -508,15 +514,16 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 4) return forced;
-  const double rate[5] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP};
-  const int bm[5] = {128, 256, 256, 256, 256}, bn[5] = {128, 256, 128, 256, 320}, slots[5] = {512, 256, 256, 256, 256};
+  if (forced >= 0 && forced <= 5) return forced;
+  static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
+  const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
+  const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
   int best = 0; double best_t = 1e300;
-  for (int v = 0; v < 5; ++v) {
+  for (int v = 0; v < (no96 ? 5 : 6); ++v) {
     const long tiles = (long)ta_cdiv(M, bm[v]) * ta_cdiv(N, bn[v]) * splits;
     const double rounds = (double)((tiles + slots[v] - 1) / slots[v]);
-    // a round of variant v costs (tile area / rate) per slot; v1 runs two tiles per CU concurrently
-    const double t = rounds * (double)bm[v] * bn[v] / rate[v] * (v == 0 ? 2.0 : 1.0);
+    // a round of variant v costs (tile area / rate) per slot; variants 0 and 5 run two tiles per CU concurrently
+    const double t = rounds * (double)bm[v] * bn[v] / rate[v] * ((v == 0 || v == 5) ? 2.0 : 1.0);
     if (t < best_t) { best_t = t; best = v; }
   }
   return best;
@@ -525,7 +532,7 @@ static int pick_variant(int M, int N, int splits) {
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int variant = pick_variant(a.M, a.N, a.splits);
-  const int bm = variant == 0 ? 128 : 256, bn = variant == 4 ? 320 : ((variant == 1 || variant == 3) ? 256 : 128);
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256), bn = variant == 4 ? 320 : ((variant == 1 || variant == 3) ? 256 : 128);
   a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   {
@@ -541,6 +548,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     (void)hipEventRecord(r.a, st);
   }
   if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
