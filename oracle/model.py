@@ -77,12 +77,21 @@ def asr_forward(batch, W, cfg, keep_cache=True, frame_keep_mask=None, moe_noise=
     return out
 
 
-def asr_backward(out, W, cfg):
+def asr_backward(out, W, cfg, batch=None):
     """Gradients of out['loss'] w.r.t. the projector parameters (encoder and LM frozen); with W['lora'] the adapter
-    gradients are returned under 'lora.<name>' keys as well (stage-2 training, BASELINE configs[4])."""
+    gradients are returned under 'lora.<name>' keys as well (stage-2 training, BASELINE configs[4]).
+    With cfg['freeze_language_model'] False (full decoder fine-tuning, configs/experiments/embedded.yaml:23) every LM
+    weight gradient is returned under 'language_model.<name>'; ``batch`` then supplies the input ids for the embedding
+    lookup's share of the tied embedding matrix (tiny_audio/asr_modeling.py:498)."""
     c = out["_cache"]
     lg = {} if W.get("lora") is not None else None
-    dx0 = qwen3.lm_backward_dx(out["_dlogits"], W["lm"], cfg["lm"], c["lc"], W.get("lora"), cfg.get("lora_scale", 0.0), lg)
+    wg = {} if not cfg.get("freeze_language_model", True) else None
+    dx0 = qwen3.lm_backward_dx(out["_dlogits"], W["lm"], cfg["lm"], c["lc"], W.get("lora"), cfg.get("lora_scale", 0.0), lg, wg)
+    if wg is not None:
+        ids = np.asarray(batch["input_ids"])
+        text = ~c["is_audio"]                               # audio rows were overwritten by masked_scatter: no embedding grad
+        ge = wg["model.embed_tokens.weight"]
+        np.add.at(ge, ids[text], dx0[text])
     idx = np.argwhere(c["is_audio"])
     dpacked = dx0[idx[:, 0], idx[:, 1]]
     B, N, D = c["y_shape"]
@@ -96,6 +105,8 @@ def asr_backward(out, W, cfg):
         grads = proj.moe_backward(dy, W["projector"], c["pc"], d_aux=1.0)
     if lg is not None:
         grads.update({"lora." + k: v for k, v in lg.items()})
+    if wg is not None:
+        grads.update({"language_model." + k: v for k, v in wg.items()})
     return grads, dx0
 
 
@@ -117,18 +128,27 @@ def adamw_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_de
         m = state.setdefault("m." + k, np.zeros_like(p))
         v = state.setdefault("v." + k, np.zeros_like(p))
         wd = 0.0 if (k in no_decay or k.endswith("bias") or "norm" in k) else weight_decay
-        p *= np.float32(1.0 - lr * wd)
+        lr_k = lr(k) if callable(lr) else lr             # per-parameter LR: the split groups of scripts/train.py:384-437
+        p *= np.float32(1.0 - lr_k * wd)
         m *= np.float32(b1); m += np.float32(1 - b1) * g
         v *= np.float32(b2); v += np.float32(1 - b2) * g * g
         mhat = m / np.float32(1 - b1 ** t)
         vhat = v / np.float32(1 - b2 ** t)
-        p -= np.float32(lr) * mhat / (np.sqrt(vhat) + np.float32(eps))
+        p -= np.float32(lr_k) * mhat / (np.sqrt(vhat) + np.float32(eps))
     return params
 
 
-def train_step(batch, W, cfg, state, lr=1e-3, max_grad_norm=1.0, weight_decay=0.0, **fw):
+def train_step(batch, W, cfg, state, lr=1e-3, max_grad_norm=1.0, weight_decay=0.0, decoder_lr=None, **fw):
+    """One optimizer step.  With cfg['freeze_language_model'] False the LM weights train too, at ``decoder_lr``
+    (configs/experiments/embedded.yaml:23-25)."""
     out = asr_forward(batch, W, cfg, training=True, **fw)
-    grads, _ = asr_backward(out, W, cfg)
+    grads, _ = asr_backward(out, W, cfg, batch)
     grads, gnorm = clip_grad_norm(grads, max_grad_norm)
-    adamw_step(W["projector"], grads, state, lr, weight_decay=weight_decay)
+    if cfg.get("freeze_language_model", True):
+        adamw_step(W["projector"], grads, state, lr, weight_decay=weight_decay)
+    else:
+        params = dict(W["projector"])
+        params.update({"language_model." + k: v for k, v in W["lm"].items()})
+        dlr = lr if decoder_lr is None else decoder_lr
+        adamw_step(params, grads, state, lambda k: dlr if k.startswith("language_model.") else lr, weight_decay=weight_decay)
     return float(out["loss"]), gnorm

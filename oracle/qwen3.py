@@ -24,6 +24,18 @@ def rms_bwd_dx(dy, x, r, w):
     return (r * (dn - xh * (dn * xh).mean(-1, keepdims=True))).astype(np.float32)
 
 
+def rms_bwd_dw(dy, x, r):
+    """d loss / d weight of Qwen3RMSNorm (y = w * x * r): sum over every leading axis."""
+    g = dy * (x * r)
+    return g.reshape(-1, g.shape[-1]).sum(0).astype(np.float32)
+
+
+def _acc(wgrads, name, g):
+    """Full decoder fine-tuning (freeze_language_model=False, tiny_audio/asr_modeling.py:251-253): collect d loss / d W."""
+    if wgrads is not None:
+        wgrads[name] = (wgrads[name] + g if name in wgrads else g).astype(np.float32)
+
+
 def silu(x):
     return x / (1.0 + np.exp(-x))
 
@@ -94,12 +106,15 @@ def layer_forward(x, w, p, cfg, cos, sin, allowed, lora=None, lora_scale=0.0):
     return x2.astype(np.float32), cache
 
 
-def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, grads=None):
-    """dL/dx for a frozen decoder layer (no base-weight gradients); with ``lora`` also the adapter gradients."""
+def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, grads=None, wgrads=None):
+    """dL/dx for a decoder layer; with ``lora`` also the adapter gradients, with ``wgrads`` (a dict) also the gradient
+    of every base weight of the layer (full decoder fine-tuning)."""
     B, L, D = dx2.shape
     w = {**w, **{p + n + ".weight": _eff(w, lora, p + n, lora_scale) for n in LORA_TARGETS}} if lora is not None else w
     flat = lambda a: a.reshape(-1, a.shape[-1])
     _lora_grads(grads, lora, p + "mlp.down_proj", lora_scale, flat(dx2).T @ flat(c["act"]))
+    if wgrads is not None:
+        _acc(wgrads, p + "mlp.down_proj.weight", flat(dx2).T @ flat(c["act"]))
     hq, hkv, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
     g = hq // hkv
     # MLP
@@ -110,9 +125,15 @@ def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, gr
     _lora_grads(grads, lora, p + "mlp.gate_proj", lora_scale, flat(dgt).T @ flat(c["xn2"]))
     _lora_grads(grads, lora, p + "mlp.up_proj", lora_scale, flat(dup).T @ flat(c["xn2"]))
     dxn2 = dgt @ w[p + "mlp.gate_proj.weight"] + dup @ w[p + "mlp.up_proj.weight"]
+    if wgrads is not None:
+        _acc(wgrads, p + "mlp.gate_proj.weight", flat(dgt).T @ flat(c["xn2"]))
+        _acc(wgrads, p + "mlp.up_proj.weight", flat(dup).T @ flat(c["xn2"]))
+        _acc(wgrads, p + "post_attention_layernorm.weight", rms_bwd_dw(dxn2, c["x1"], c["r_post"]))
     dx1 = dx2 + rms_bwd_dx(dxn2, c["x1"], c["r_post"], w[p + "post_attention_layernorm.weight"])
     # attention
     _lora_grads(grads, lora, p + "self_attn.o_proj", lora_scale, flat(dx1).T @ flat(c["ao"]))
+    if wgrads is not None:
+        _acc(wgrads, p + "self_attn.o_proj.weight", flat(dx1).T @ flat(c["ao"]))
     dao = (dx1 @ w[p + "self_attn.o_proj.weight"]).reshape(B, L, hq, hd).transpose(0, 2, 1, 3)
     kr = np.repeat(c["k"], g, axis=1)
     vr = np.repeat(c["v"], g, axis=1)
@@ -139,6 +160,13 @@ def layer_backward_dx(dx2, w, p, cfg, cos, sin, c, lora=None, lora_scale=0.0, gr
     _lora_grads(grads, lora, p + "self_attn.v_proj", lora_scale, flat(dv0).T @ flat(c["xn"]))
     dxn = (dq0 @ w[p + "self_attn.q_proj.weight"] + dk0 @ w[p + "self_attn.k_proj.weight"]
            + dv0 @ w[p + "self_attn.v_proj.weight"])
+    if wgrads is not None:
+        _acc(wgrads, p + "self_attn.q_norm.weight", rms_bwd_dw(dqn, c["q0"], c["rq"]))
+        _acc(wgrads, p + "self_attn.k_norm.weight", rms_bwd_dw(dkn, c["k0"], c["rk"]))
+        _acc(wgrads, p + "self_attn.q_proj.weight", flat(dq0).T @ flat(c["xn"]))
+        _acc(wgrads, p + "self_attn.k_proj.weight", flat(dk0).T @ flat(c["xn"]))
+        _acc(wgrads, p + "self_attn.v_proj.weight", flat(dv0).T @ flat(c["xn"]))
+        _acc(wgrads, p + "input_layernorm.weight", rms_bwd_dw(dxn, c["x"], c["r_in"]))
     dx = dx1 + rms_bwd_dx(dxn, c["x"], c["r_in"], w[p + "input_layernorm.weight"])
     return dx.astype(np.float32)
 
@@ -180,11 +208,17 @@ def causal_lm_loss(logits, labels, num_items_in_batch=None):
     return np.float32(loss), dlogits.reshape(B, L, V).astype(np.float32), int(valid.sum())
 
 
-def lm_backward_dx(dlogits, w, cfg, cache, lora=None, lora_scale=0.0, grads=None):
-    """d loss / d inputs_embeds through the frozen LM (and, with ``lora``/``grads``, the adapter gradients)."""
+def lm_backward_dx(dlogits, w, cfg, cache, lora=None, lora_scale=0.0, grads=None, wgrads=None):
+    """d loss / d inputs_embeds through the LM (and, with ``lora``/``grads``, the adapter gradients; with ``wgrads`` the
+    gradient of every LM weight -- the tied lm_head's share of ``model.embed_tokens.weight`` included, the input-lookup
+    share is added by the caller that owns the token ids)."""
     dhn = dlogits @ w["model.embed_tokens.weight"]
+    if wgrads is not None:
+        V = dlogits.shape[-1]
+        _acc(wgrads, "model.embed_tokens.weight", dlogits.reshape(-1, V).T @ cache["hn"].reshape(-1, cache["hn"].shape[-1]))
+        _acc(wgrads, "model.norm.weight", rms_bwd_dw(dhn, cache["x_final"], cache["r_f"]))
     dx = rms_bwd_dx(dhn, cache["x_final"], cache["r_f"], w["model.norm.weight"])
     for i in reversed(range(cfg["layers"])):
         dx = layer_backward_dx(dx, w, f"model.layers.{i}.", cfg, cache["cos"], cache["sin"],
-                               cache["layers"][i], lora, lora_scale, grads)
+                               cache["layers"][i], lora, lora_scale, grads, wgrads)
     return dx

@@ -29,7 +29,7 @@ sys.path.insert(0, "/root/reference")
 os.environ.setdefault("HF_HUB_OFFLINE", "1")
 
 from oracle import weights as OW  # noqa: E402
-from tests.golden.recipe import SMALL, logmel_waves, encoder_input, proj_input, lm_input, asr_tokens  # noqa: E402
+from tests.golden.recipe import SMALL, logmel_waves, encoder_input, proj_input, lm_input, asr_tokens, fullft_select  # noqa: E402
 
 torch.manual_seed(0)
 torch.set_grad_enabled(True)
@@ -215,7 +215,9 @@ def build_asr(ptype, pw, lm_weights=None, **cfg_kw):
         enc.requires_grad_(False); enc.eval(); return enc
 
     def _lm(cls, config, dtype):
-        lm.requires_grad_(False); lm.train(False); return lm
+        if getattr(config, "freeze_language_model", True):      # tiny_audio/asr_modeling.py:251-253
+            lm.requires_grad_(False); lm.train(False)
+        return lm
 
     def _tok(self, config):
         self.tokenizer = _StubTokenizer()
@@ -290,6 +292,55 @@ def gen_asr():
         losses.append(float(out.loss)); gnorms.append(float(gn))
     save("train3_small.npz", losses=np.array(losses, np.float32), gnorms=np.array(gnorms, np.float32),
          **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters()})
+
+
+# ----------------------------------------------------------------------------- 6b. full decoder fine-tuning (section 8(f) rank 4)
+def gen_fullft():
+    """freeze_language_model=False (configs/experiments/embedded.yaml:23): gradients of every trainable tensor after one
+    backward, then 3 steps of the split-group optimizer of scripts/train.py:384-437 (projector lr 1e-3, decoder lr 1e-4,
+    weight decay 0, clip 1.0)."""
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    batch = asr_batch()
+    tb = {k: t(v) for k, v in batch.items()}
+    model = build_asr("mlp", OW.init_mlp_projector(E, D, H), freeze_language_model=False)
+    model.train()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert any(n.startswith("language_model.model.layers.0.") for n in names) and "language_model.lm_head.weight" not in names
+    assert set(model.state_dict()) >= {"language_model.model.embed_tokens.weight", "projector.linear_1.weight"}   # :409-421
+    out = model(**tb)
+    out.loss.backward()
+    arrays = {"loss": out.loss.detach().numpy(), "n_trainable": np.int64(sum(p.numel() for p in model.parameters() if p.requires_grad))}
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if n.startswith("language_model."):
+            g = fullft_select(n[len("language_model."):], p.grad.numpy())
+            if g is not None:
+                arrays["g." + n] = g
+        else:
+            arrays["g." + n] = p.grad.numpy()
+    arrays["gnorm_all"] = np.float32(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.requires_grad)))
+    # 3 optimizer steps with the reference's four parameter groups
+    model = build_asr("mlp", OW.init_mlp_projector(E, D, H), freeze_language_model=False)
+    model.train()
+    dec = [p for n, p in model.named_parameters() if p.requires_grad and n.startswith("language_model.")]
+    oth = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("language_model.")]
+    opt = torch.optim.AdamW([{"params": oth, "lr": 1e-3, "weight_decay": 0.0}, {"params": dec, "lr": 1e-4, "weight_decay": 0.0}])
+    losses, gnorms = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        out = model(**tb)
+        out.loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 1.0)
+        opt.step()
+        losses.append(float(out.loss)); gnorms.append(float(gn))
+    arrays["losses"] = np.array(losses, np.float32); arrays["gnorms"] = np.array(gnorms, np.float32)
+    for n, p in model.named_parameters():
+        if p.requires_grad and n.startswith("language_model."):
+            v = fullft_select(n[len("language_model."):], p.detach().numpy())
+            if v is not None and (v.ndim == 1 or "layers.0.self_attn.q_proj" in n or "embed_tokens" in n):
+                arrays["w." + n] = v
+    save("fullft_small.npz", **arrays)
 
 
 # ----------------------------------------------------------------------------- 3b. QFormer projector (section 8(f) rank 4)
@@ -421,7 +472,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "generate", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "fullft", "generate", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

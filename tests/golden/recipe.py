@@ -95,3 +95,22 @@ def qformer_input(B=2, S=50, seed=31):
     n_out = (S + 14) // 15 * 3
     dy = np.random.RandomState(seed + 1).standard_normal((B, n_out, D)).astype(np.float32)
     return x, dy
+
+
+# ----------------------------------------------------------------------------- full decoder fine-tuning fixture
+FULLFT_KEEP = {   # parameter -> slice of its gradient / final value that is stored (the fixture stays small)
+    "model.layers.0.self_attn.q_proj.weight": (slice(0, 96), slice(None)),
+    "model.layers.0.self_attn.k_proj.weight": (slice(128, 160), slice(None)),
+    "model.layers.1.self_attn.v_proj.weight": (slice(0, 48), slice(None)),
+    "model.layers.0.self_attn.o_proj.weight": (slice(0, 64), slice(None)),
+    "model.layers.1.mlp.gate_proj.weight": (slice(0, 64), slice(None)),
+    "model.layers.0.mlp.up_proj.weight": (slice(400, 464), slice(None)),
+    "model.layers.1.mlp.down_proj.weight": (slice(0, 48), slice(None)),
+    "model.embed_tokens.weight": (slice(None, None, 8), slice(None)),
+}
+
+
+def fullft_select(name, arr):
+    if name in FULLFT_KEEP:
+        return arr[FULLFT_KEEP[name]]
+    return arr if arr.ndim == 1 else None           # every norm scale is kept whole

@@ -260,3 +260,52 @@ def test_train_three_steps(golden):
     for k in W["projector"]:
         d = np.abs(W["projector"][k] - g3["w." + k])
         assert d.mean() < 1e-7 and d.max() < 3e-4, (k, d.mean(), d.max())
+
+
+# ----------------------------------------------------------------------------- full decoder fine-tuning (8(f) rank 4)
+def _fullft_setup(golden):
+    g, W, cfg, batch = _asr_setup(golden, "mlp")
+    cfg = dict(cfg, freeze_language_model=False)
+    return golden("fullft_small.npz"), W, cfg, batch
+
+
+def test_fullft_gradients(golden):
+    """freeze_language_model=False: the gradient of EVERY LM weight (tied embedding: lm_head share + input-lookup share,
+    norm scales, q/k norms, the seven projections) and of the projector, against the reference's autograd."""
+    g, W, cfg, batch = _fullft_setup(golden)
+    out = OM.asr_forward(batch, W, cfg, training=True)
+    assert abs(float(out["loss"]) - float(g["loss"])) < 3e-5 * float(g["loss"])
+    grads, _ = OM.asr_backward(out, W, cfg, batch)
+    n_train = sum(v.size for v in W["projector"].values()) + sum(v.size for v in W["lm"].values())
+    assert n_train == int(g["n_trainable"])
+    total = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads.values()))
+    assert abs(total - float(g["gnorm_all"])) < 1e-4 * float(g["gnorm_all"])
+    seen = 0
+    for k in g.files:
+        if not k.startswith("g."):
+            continue
+        name = k[2:]
+        if name.startswith("language_model."):
+            mine = R.fullft_select(name[len("language_model."):], grads[name])
+        else:
+            mine = grads[name[len("projector."):]]
+        assert relerr(mine, g[k]) < 5e-4, (name, relerr(mine, g[k]))
+        seen += 1
+    assert seen >= 20
+
+
+def test_fullft_three_steps(golden):
+    """Split parameter groups (scripts/train.py:384-437): projector lr 1e-3, decoder lr 1e-4, clip 1.0 over all of them."""
+    g, W, cfg, batch = _fullft_setup(golden)
+    state, losses, gnorms = {}, [], []
+    for _ in range(3):
+        l, gn = OM.train_step(batch, W, cfg, state, lr=1e-3, decoder_lr=1e-4, max_grad_norm=1.0, weight_decay=0.0)
+        losses.append(l); gnorms.append(gn)
+    np.testing.assert_allclose(losses, g["losses"], rtol=3e-4)
+    np.testing.assert_allclose(gnorms, g["gnorms"], rtol=3e-3)
+    assert losses[2] < losses[0]
+    for k in g.files:
+        if k.startswith("w.language_model."):
+            name = k[len("w.language_model."):]
+            d = np.abs(R.fullft_select(name, W["lm"][name]) - g[k])
+            assert d.mean() < 2e-7 and d.max() < 3e-5, (name, d.mean(), d.max())       # travel: 3 steps * lr 1e-4
