@@ -165,7 +165,27 @@ typedef struct {
   const ta_lm_layer* layers;        /* host array */
   int lora_rank;                    /* 0 = no adapters; else r (8) */
   float lora_scale;                 /* alpha / r */
+  int train_base;                   /* 1 = full decoder fine-tuning (freeze_language_model=False, tiny_audio/asr_config.py:77,
+                                       configs/experiments/embedded.yaml:23): the tape also keeps what ta_lm_wgrads needs */
 } ta_lm_weights;
+
+/* Gradients of the LM's own weights (full decoder fine-tuning).  All f32, ACCUMULATED (+=) into the caller's buffers, which
+ * the caller zeroes at the start of an optimizer step (gradient accumulation over micro-batches then needs nothing else).
+ * dembed [vocab, D] receives both shares of the tied matrix: lm_head (dlogits^T h) and the input lookup (scatter-add of
+ * d inputs_embeds at the text positions; <audio> rows were overwritten by the projector output and get none). */
+typedef struct {
+  float *dwqkv;  /* [NQKV, D] rows = q | k | v */
+  float *dwo;    /* [D, heads*head_dim] */
+  float *dwgu;   /* [2F, D] rows = gate | up */
+  float *dwd;    /* [D, F] */
+  float *dln_in, *dln_post;   /* [D] */
+  float *dqn, *dkn;           /* [head_dim] */
+} ta_lm_layer_wgrads;
+typedef struct {
+  const ta_lm_layer_wgrads* layers;   /* host array [n_layers] */
+  float* dnorm;                       /* [D] */
+  float* dembed;                      /* [vocab, D] */
+} ta_lm_wgrads;
 
 long ta_lm_tape_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows);
 long ta_lm_workspace_bytes(const ta_lm_weights* w, int B, int L, int n_label_rows);
@@ -240,7 +260,7 @@ int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad
  * projector); d_embeds optional [B*L, D]; lora_grads: host array [n_layers] (required iff w->lora_rank > 0). */
 int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
                    const int* label_rows, int n_label_rows, float* d_audio, long n_audio_rows, float* d_embeds,
-                   const ta_lm_lora_grads* lora_grads, const void* tape, void* ws, long ws_bytes, hipStream_t st);
+                   const ta_lm_lora_grads* lora_grads, const ta_lm_wgrads* wgrads, const long* ids, const void* tape, void* ws, long ws_bytes, hipStream_t st);
 
 /* ============================================================================================
  * Primitive kernels (exported for the parity tests; also what the composites are built from)
@@ -305,6 +325,10 @@ int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_bf16, float*
 int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
                         const float* dres, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
 
+/* d loss / d weight of an RMSNorm (y = w * x * rstd): dw_accum[h] += sum_m dy[m,h] * x[m,h] * rstd[m]; dy and x are f32 or bf16 */
+int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* rstd, float* dw_accum, int M,
+                  int H, hipStream_t st);
+
 int ta_attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
                      int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, hipStream_t st);
 /* The same over caller-described operand layouts (element strides; NULL = the head-major defaults above):
@@ -329,7 +353,7 @@ int ta_lm_qkv_post_fwd(const void* qkv0, const float* qn_w, const float* kn_w, c
                        int B, int Hq, int Hkv, int L, int Lp, float eps, hipStream_t st);
 int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv0, const float* rq,
                        const float* rk, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
-                       const int* pos, void* dqkv, int B, int Hq, int Hkv, int L, hipStream_t st);
+                       const int* pos, void* dqkv, float* dqn_accum, float* dkn_accum, int B, int Hq, int Hkv, int L, hipStream_t st);   /* dqn/dkn_accum [128] or NULL: += the q_norm / k_norm weight gradients */
 int ta_attn_bwd_prep(const void* dO, const void* O, float* Delta, void* dOT, int B, int Hq, int L, int Lp,
                      hipStream_t st);
 
@@ -348,6 +372,9 @@ int ta_audio_index(const long* ids, const long* counts, int* src_row, int B, int
 int ta_embed_scatter(const long* ids, const int* src_row, const float* emb, const float* audio, float* x0,
                      void* x0_bf16, int n_rows, int D, long vocab, hipStream_t st);
 int ta_audio_grad_gather(const int* src_row, const float* dx0, float* d_audio, int n_rows, int D, hipStream_t st);
+/* input-lookup share of the embedding gradient: dembed[ids[m], :] += dx0[m, :] for every text row (src_row[m] < 0 or src_row NULL) */
+int ta_embed_grad_scatter(const long* ids, const int* src_row, const float* dx0, float* dembed, int n_rows, int D, long vocab,
+                          hipStream_t st);
 int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st);
 int ta_scatter_rows_f32(const float* in, const int* idx, float* out, int n, int D, hipStream_t st);
 int ta_bernoulli_keep(float* keep, long n, float keep_prob, unsigned long long seed, hipStream_t st);

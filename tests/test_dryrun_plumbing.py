@@ -142,6 +142,66 @@ def test_lora_stage2_plumbing(dry):
         ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16), device="cpu", init="none")
 
 
+def test_full_finetune_plumbing(dry, tmp_path):
+    """Section 8(f) rank 4: freeze_language_model=False -> the LM's fp32 masters are Parameters under ``language_model.``,
+    the state dict carries them under the reference's names, the kernels' norm / embedding pointers follow the masters into
+    the trainer's flat buffer, gradients land in Parameter.grad, decoder LR / no-decay groups apply."""
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    enc, lm = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4), OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=3, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, freeze_language_model=False)
+    m = ASRModel(cfg, device="cpu", init="random")
+    lmod = m.language_model
+    train = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    ft = [n for n in train if n.startswith("language_model.")]
+    assert sorted(ft) == sorted("language_model.ft_" + k for k in ("wqkv", "wo", "wgu", "wd", "ln_in_w", "ln_post_w", "qn_w", "kn_w", "norm_w", "embed"))
+    wl = OW.init_lm(lm, 1)
+    assert sum(train[n].numel() for n in ft) == sum(v.size for v in wl.values())
+    # the true Qwen3-0.6B: 596,049,920 parameters minus the resize to V = 151,670 rows
+    assert lmod._w.train_base == 1 and lmod._fp32_src is None
+    sd = m.state_dict()
+    assert sd["language_model.model.layers.2.self_attn.k_proj.weight"].shape == (256, 256)
+    assert "language_model.model.embed_tokens.weight" in sd and "projector.linear_1.weight" in sd
+    # round trip through the reference's names (the oracle's seeded weights): masters and bf16 images follow
+    m.load_state_dict({**{"language_model." + k: torch.from_numpy(v) for k, v in wl.items()},
+                       **{k: v for k, v in sd.items() if k.startswith("projector.")}})
+    back = lmod.ft_state_dict_hf()
+    for k, v in wl.items():
+        np.testing.assert_array_equal(back[k].numpy(), v)
+    assert torch.equal(lmod._bufs["layers.1.wd"], torch.from_numpy(wl["model.layers.1.mlp.down_proj.weight"]).to(torch.bfloat16))
+    assert torch.equal(lmod._bufs["layers.1.wd_t"], lmod._bufs["layers.1.wd"].t())
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
+    m.train()
+    dry.calls.clear()
+    out = m(**batch)
+    out.loss.backward()
+    assert dry.calls.count("ta_lm_backward") == 1
+    for n, p in train.items():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+    tr = ASRTrainer(m, TrainingArguments(learning_rate=1e-3, weight_decay=0.1), decoder_learning_rate=1e-4)
+    assert lmod.accumulate_into_grad and tr.flat.n >= sum(p.numel() for p in train.values())
+    dec = dict(zip(tr.flat.names, tr.flat.decay))
+    assert dec["language_model.ft_wqkv"] and dec["language_model.ft_embed"] and not dec["language_model.ft_ln_in_w"] \
+        and not dec["language_model.ft_qn_w"] and not dec["language_model.ft_norm_w"]
+    assert tr.group_hparams("language_model.ft_wd", True) == (1e-4, 0.1) and tr.group_hparams("projector.linear_1.weight", True) == (1e-3, 0.1)
+    tr.training_step(batch)                         # masters re-homed into the flat buffer -> pointers rebound, images rebuilt
+    assert lmod._w.embed_f32 == lmod.ft_embed.data_ptr() and lmod.ft_embed.data_ptr() >= tr.flat.flat_p.data_ptr()
+    assert lmod._layers_arr[2].qn_w == lmod.ft_qn_w.data_ptr() + 2 * 128 * 4
+    assert lmod._ft_versions is None                # optimizer step done: images are rebuilt by the next forward
+    tr.training_step(batch)
+    assert lmod._ft_versions is None or isinstance(lmod._ft_versions, tuple)
+    # checkpoint: the fine-tuned LM travels in model.safetensors (asr_modeling.py:409-421)
+    m.save_pretrained(tmp_path / "ck")
+    m2 = ASRModel.from_pretrained(tmp_path / "ck", device="cpu")
+    assert m2.language_model.train_base and torch.equal(m2.language_model.ft_wo, lmod.ft_wo)
+    with pytest.raises(NotImplementedError):
+        m.language_model.enable_lora()
+
+
 def test_qformer_plumbing(dry):
     """Section 8(f) rank 4: the QFormer projector inside ASRModel -- reference parameter names / count, 102 audio tokens for
     500 encoder frames, one full forward + backward + optimizer step through the primitive wrappers."""

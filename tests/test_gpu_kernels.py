@@ -245,9 +245,9 @@ def test_lm_qkv_post_fwd_bwd():
     B, Hq, Hkv, L, hd = 2, 4, 2, 70, 128
     NQKV = (Hq + 2 * Hkv) * hd
     x0 = rnd(B * L, NQKV, seed=1).to(BF16)
-    qn, kn = 1 + 0.1 * rnd(hd, seed=2), 1 + 0.1 * rnd(hd, seed=3)
+    qn, kn = (1 + 0.1 * rnd(hd, seed=2)).requires_grad_(True), (1 + 0.1 * rnd(hd, seed=3)).requires_grad_(True)
     cos, sin = rope_tables(256, hd, 1e6)
-    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn, kn, cos, sin, B, Hq, Hkv, L)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn.detach(), kn.detach(), cos, sin, B, Hq, Hkv, L)
     xf = x0.float().requires_grad_(True)
     xs = xf.reshape(B, L, Hq + 2 * Hkv, hd)
     c = torch.cat([cos[:L], cos[:L]], -1)[None, :, None]; s = torch.cat([sin[:L], sin[:L]], -1)[None, :, None]
@@ -267,8 +267,11 @@ def test_lm_qkv_post_fwd_bwd():
     dQ, dK, dV = rnd(B, Hq, L, hd, seed=5).to(BF16), rnd(B, Hkv, L, hd, seed=6).to(BF16), rnd(B, Hkv, L, hd, seed=7).to(BF16)
     (q_ref * dQ.float().transpose(1, 2)).sum().add((k_ref * dK.float().transpose(1, 2)).sum()).add(
         (v_ref * dV.float().transpose(1, 2)).sum()).backward()
-    dqkv = ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn, kn, cos, sin, B, Hq, Hkv, L)
+    dqn, dkn = torch.full((hd,), 1.0, device=DEV), torch.zeros(hd, device=DEV)
+    dqkv = ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn.detach(), kn.detach(), cos, sin, B, Hq, Hkv, L, dqn=dqn, dkn=dkn)
     assert relerr(dqkv, xf.grad) < 1e-2 and cos_sim(dqkv, xf.grad) > 0.9999
+    assert relerr(dqn - 1.0, qn.grad) < 2e-3 and relerr(dkn, kn.grad) < 2e-3       # q_norm / k_norm weight gradients (+=)
+    assert relerr(ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn.detach(), kn.detach(), cos, sin, B, Hq, Hkv, L), dqkv) == 0.0
 
 
 # ----------------------------------------------------------------------------- element-wise / movement
@@ -578,3 +581,29 @@ def test_attention_fwd_strided_layout(S):
     assert relerr(O, ref) < 1e-6, relerr(O, ref)
     ref32, _ = ref_attention(q.float(), k.float(), vh.float(), False, 0.125, None)
     assert relerr(O, ref32.transpose(1, 2).reshape(M, H)) < 2e-2
+
+
+# ----------------------------------------------------------------------------- trainable-LM helpers
+@pytest.mark.parametrize("dyb,xb", [(False, False), (True, True), (False, True)])
+def test_rmsnorm_dw(dyb, xb):
+    M, H = 333, 1024
+    dy, x = rnd(M, H, seed=1), rnd(M, H, seed=2, scale=2.0)
+    dy, x = (dy.to(BF16) if dyb else dy), (x.to(BF16) if xb else x)
+    r = torch.rsqrt((x.float() ** 2).mean(-1) + 1e-6)
+    dw = torch.full((H,), 0.5, device=DEV)
+    ops.rmsnorm_dw(dy, x, r, dw)
+    ref = 0.5 + (dy.float() * x.float() * r[:, None]).sum(0)
+    assert relerr(dw, ref) < 1e-4
+
+
+def test_embed_grad_scatter():
+    V, D, n = 50, 64, 40
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(0)).to(DEV)
+    src = torch.full((n,), -1, dtype=torch.int32, device=DEV); src[5:12] = torch.arange(7, dtype=torch.int32, device=DEV)
+    dx = rnd(n, D, seed=3)
+    de = torch.zeros(V, D, device=DEV)
+    ops.embed_grad_scatter(ids, src, dx, de)
+    ref = torch.zeros(V, D, device=DEV)
+    keep = src < 0
+    ref.index_add_(0, ids[keep], dx[keep])
+    assert relerr(de, ref) < 1e-5

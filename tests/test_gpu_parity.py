@@ -718,3 +718,94 @@ def test_asr_model_moe_vs_golden(golden):
     for k in [k[len("moe.g."):] for k in g.files if k.startswith("moe.g.")]:
         got = dict(m.projector.named_parameters())[k].grad
         assert cosine(npy(got), g["moe.g." + k]) > 0.995, k
+
+
+# ============================================================================ full decoder fine-tuning (8(f) rank 4)
+def _ft_grads_hf(m):
+    """Parameter.grad of the stacked masters, under the reference's names."""
+    lm = m.language_model
+    saved = [p.data for p in lm.ft_parameters()]
+    for p in lm.ft_parameters():
+        p.data = p.grad
+    try:
+        return {k: npy(v) for k, v in lm.ft_state_dict_hf().items()}
+    finally:
+        for p, d in zip(lm.ft_parameters(), saved):
+            p.data = d
+
+
+def test_full_finetune_vs_golden(golden):
+    """freeze_language_model=False on the reference's own fixture: one backward (every LM weight gradient) and 3 steps of
+    the split-group optimizer (projector lr 1e-3, decoder lr 1e-4), bf16 kernels vs the reference's fp32 autograd."""
+    g, gf = golden("asr_small.npz"), golden("fullft_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    mk = lambda: build_model(S["enc"], S["lm"], H, OW.init_encoder(S["enc"], 0), OW.init_lm(S["lm"], 1),
+                             OW.init_mlp_projector(E, D, H), audio_token_id=S["audio_token_id"], freeze_language_model=False)
+    ids, att, lab, counts = R.asr_tokens(g["counts"])
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.from_numpy(g["input_features"]),
+                 attention_mask=torch.from_numpy(att), labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts))
+    m = mk()
+    assert m.language_model.train_base and sum(p.numel() for p in m.parameters() if p.requires_grad) == int(gf["n_trainable"])
+    m.train()
+    out = m(**batch)
+    out.loss.backward()
+    assert abs(float(out.loss) - float(gf["loss"])) < 5e-3 * float(gf["loss"])
+    gl = _ft_grads_hf(m)
+    n = 0
+    for k in gf.files:
+        if not k.startswith("g.language_model."):
+            continue
+        name = k[len("g.language_model."):]
+        mine = R.fullft_select(name, gl[name])
+        assert cosine(mine, gf[k]) > 0.995 and relmax(mine, gf[k]) < 6e-2, (name, cosine(mine, gf[k]), relmax(mine, gf[k]))
+        n += 1
+    assert n >= 17
+    for k, prm in m.projector.named_parameters():
+        assert cosine(npy(prm.grad), gf["g.projector." + k]) > 0.999, k
+    m = mk(); m.train()
+    tr = ASRTrainer(m, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0), decoder_learning_rate=1e-4)
+    losses, gnorms = [], []
+    for _ in range(3):
+        tr.training_step(batch)
+        losses.append(tr.last_loss()); gnorms.append(tr.last_grad_norm())
+    np.testing.assert_allclose(losses, gf["losses"], rtol=5e-3)
+    np.testing.assert_allclose(gnorms, gf["gnorms"], rtol=3e-2)
+    assert losses[2] < losses[0]
+    sd = {k: npy(v) for k, v in m.language_model.ft_state_dict_hf().items()}
+    for k in gf.files:
+        if k.startswith("w.language_model."):
+            name = k[len("w.language_model."):]
+            d = np.abs(R.fullft_select(name, sd[name]) - gf[k])
+            assert d.mean() < 3e-5, (name, d.mean())        # 3 steps * lr 1e-4 of travel per element at most
+
+
+def test_full_finetune_true_width_vs_oracle():
+    """True Qwen3-0.6B widths (2 layers): every weight gradient of the trainable LM against the fp32 oracle, including the
+    tied embedding (lm_head share over the vocabulary + input-lookup share) and gradient accumulation over two calls."""
+    wE, wL = OW.init_encoder(TRUE_ENC, 0), OW.init_lm(TRUE_LM, 1)
+    wP = OW.init_mlp_projector(1280, 1024, 1024)
+    m = build_model(TRUE_ENC, TRUE_LM, 1024, wE, wL, wP, audio_token_id=AID, freeze_language_model=False)
+    b = _true_batch()
+    m.train()
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    out = m(**tb)
+    out.loss.backward()
+    W = dict(encoder=wE, lm=wL, projector={k: v.copy() for k, v in wP.items()})
+    cfg = dict(enc=TRUE_ENC, lm=TRUE_LM, projector_type="mlp", k=4, audio_token_id=AID, freeze_language_model=False)
+    ref = OM.asr_forward(b, W, cfg, training=True)
+    grads, _ = OM.asr_backward(ref, W, cfg, b)
+    assert abs(float(out.loss) - float(ref["loss"])) < 5e-3 * float(ref["loss"])
+    gl = _ft_grads_hf(m)
+    assert set(gl) == {k[len("language_model."):] for k in grads if k.startswith("language_model.")}
+    for k, v in gl.items():
+        r = grads["language_model." + k]
+        assert cosine(v, r) > 0.995, (k, cosine(v, r))
+        assert abs(np.linalg.norm(v) - np.linalg.norm(r)) < 3e-2 * np.linalg.norm(r), k
+    for k, prm in m.projector.named_parameters():
+        assert cosine(npy(prm.grad), grads[k]) > 0.999, k
+    # a second micro-batch accumulates (autograd adds the returned gradients)
+    out = m(**tb); out.loss.backward()
+    g2 = _ft_grads_hf(m)
+    for k in ("model.layers.1.mlp.down_proj.weight", "model.embed_tokens.weight", "model.layers.0.self_attn.q_norm.weight"):
+        assert relmax(g2[k], 2 * gl[k]) < 2e-2, k

@@ -80,7 +80,15 @@ class LmWeights(C.Structure):
                 ("max_pos", C.c_int), ("eps", C.c_float),
                 ("embed_f32", C.c_void_p), ("embed_bf16", C.c_void_p), ("embed_t_bf16", C.c_void_p),
                 ("norm_w", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float)]
+                ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float), ("train_base", C.c_int)]
+
+
+class LmLayerWgrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dwqkv", "dwo", "dwgu", "dwd", "dln_in", "dln_post", "dqn", "dkn")]
+
+
+class LmWgrads(C.Structure):
+    _fields_ = [("layers", C.POINTER(LmLayerWgrads)), ("dnorm", C.c_void_p), ("dembed", C.c_void_p)]
 
 
 # ----------------------------------------------------------------------------- header parsing

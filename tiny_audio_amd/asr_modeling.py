@@ -116,6 +116,10 @@ class ASRModel(nn.Module):
         self.language_model = Qwen3MI355X(config.text_config, device=device)              # :143
         self.audio_token_id = config.audio_token_id
         self.projector = self._create_projector(config).to(device=device, dtype=F32)      # :163
+        if not getattr(config, "freeze_language_model", True):
+            # full decoder fine-tuning (asr_modeling.py:251-253; embedded.yaml:23): the LM's fp32 masters become Parameters
+            # as soon as its weights exist (now for init="random", at load_state_dict_hf otherwise)
+            self.language_model.keep_fp32 = self.language_model.want_train_base = True
         if init == "random":
             self.audio_tower.random_init(seed)
             self.language_model.random_init(seed + 1)
@@ -140,11 +144,14 @@ class ASRModel(nn.Module):
             raise ValueError(f"Unknown projector_type: {projector_type}. Valid options: {list(PROJECTOR_CLASSES.keys())}")
         return cls(config)
 
-    # frozen sub-models hold plain device buffers, not Parameters: parameters()/state_dict() are projector-only
+    # frozen sub-models hold plain device buffers, not Parameters: parameters()/state_dict() cover the projector, the LoRA
+    # adapters and -- with freeze_language_model=False -- the LM's fp32 masters
     def state_dict(self, *args, **kwargs):
         sd = {f"projector.{k}": v for k, v in self.projector.state_dict().items()}
         if self.language_model.lora_rank:       # peft adapter naming under the reference's attribute name
             sd.update(self.language_model.export_lora_state_dict(prefix="language_model.base_model.model.model."))
+        if self.language_model.train_base:      # fine-tuned LM: saved with the projector (asr_modeling.py:409-421)
+            sd.update({"language_model." + k: v for k, v in self.language_model.ft_state_dict_hf().items()})
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -152,6 +159,8 @@ class ASRModel(nn.Module):
         out = self.projector.load_state_dict(sub, strict=strict)
         if self.language_model.lora_rank and any(".lora_A" in k for k in sd):
             self.language_model.load_lora_state_dict(sd)
+        if self.language_model.train_base and "language_model.model.embed_tokens.weight" in sd:
+            self.language_model.load_ft_state_dict_hf(sd)
         if hasattr(self.projector, "_pack_versions"):
             self.projector._pack_versions = None
         return out
@@ -222,7 +231,8 @@ class ASRModel(nn.Module):
         if audio is None:
             audio = torch.zeros((1, self.config.llm_dim), device=dev, dtype=F32)
         loss, nll, logits = FrozenLMLoss.apply(audio, self.language_model, ids, src_row, kmask, rows, targets, n_lab,
-                                               scale, bool(return_logits), *self.language_model.lora_parameters())
+                                               scale, bool(return_logits),
+                                               *(self.language_model.lora_parameters() or self.language_model.ft_parameters()))
         V = self.config.text_config.vocab_size
         logits = logits.reshape(B, L, -1)[:, :, :V] if return_logits else None
         aux = None

@@ -86,9 +86,12 @@ def load_pretrained(model_cls, pretrained_path: str, device="cuda", config: Opti
     mf = os.path.join(pretrained_path, MODEL_FILE)
     if os.path.exists(mf):
         sd = load_file(mf)
-        skipped = [k for k in sd if k.startswith("language_model.")]
-        if skipped:
-            raise NotImplementedError("full-decoder fine-tune checkpoints (language_model.* in model.safetensors) are not built")
+        lm_keys = [k for k in sd if k.startswith("language_model.") and ".lora_" not in k]
+        if lm_keys and not model.language_model.train_base:
+            # a fully fine-tuned decoder loaded for inference / as a frozen LM: its weights replace the base LM's
+            # (tiny_audio/asr_modeling.py:96-106 overlays them on the freshly built base model)
+            model.language_model.load_state_dict_hf({k[len("language_model."):]: v.to(torch.float32) for k, v in sd.items()
+                                                     if k in lm_keys})
         model.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()}, strict=False)
     af, ac = os.path.join(pretrained_path, ADAPTER_FILE), os.path.join(pretrained_path, ADAPTER_CONFIG_FILE)
     if getattr(config, "use_lora", False) and os.path.exists(ac):

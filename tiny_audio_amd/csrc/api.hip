@@ -8,6 +8,7 @@
 
 extern "C" int ta_version(void) { return 1; }
 
+#include <algorithm>
 #include "host_util.h"
 
 // ============================================================================ encoder
@@ -242,9 +243,11 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
     p.x1 = c.take<float>((size_t)d.M * d.D);
     p.r_post = c.take<float>((size_t)d.M);
     p.gu = c.take<bf16_t>((size_t)d.M * 2 * d.F);
-    if (w->lora_rank > 0) {
+    if (w->lora_rank > 0 || w->train_base) {         // inputs of the linears: adapter / weight gradients need them
       p.xn_s = c.take<bf16_t>((size_t)d.M * d.D); p.xn2_s = c.take<bf16_t>((size_t)d.M * d.D);
       p.act_s = c.take<bf16_t>((size_t)d.M * d.F);
+    }
+    if (w->lora_rank > 0) {
       p.xa_qkv = c.take<bf16_t>((size_t)d.M * 64); p.xa_o = c.take<bf16_t>((size_t)d.M * 64);
       p.xa_gu = c.take<bf16_t>((size_t)d.M * 64); p.xa_d = c.take<bf16_t>((size_t)d.M * 64);
       auto img = [&](LoraImg& g, int in, int N) {
@@ -264,8 +267,14 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
 struct LmWs {
   bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB;
   float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
+  // trainable LM: transposed bf16 images of one dW product's operands ([rows, Kp], Kp = tokens rounded up to 64) and
+  // the split-K slabs of the dW GEMMs
+  bf16_t *tA, *tB;
+  float* wsk;
   size_t bytes;
 };
+// split-K of a weight-gradient GEMM  dW[N_out, K_in] = dY^T X  (contraction over the tokens)
+inline int wgrad_splits(int n_out, int k_in, int kp) { return pick_splits(n_out, k_in, kp); }
 LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   const LmDims d = lm_dims(w, B, L);
   const int nl = n_lab > 0 ? n_lab : 1;
@@ -293,6 +302,17 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dyB = c.take<bf16_t>((size_t)d.M * 64);
   const int sp = pick_splits(nl, d.D, w->vocab_pad);
   s.skws = c.take<float>((size_t)ta_gemm_splitk_ws_bytes(nl, d.D, sp) / 4 + 4);
+  s.tA = s.tB = nullptr; s.wsk = nullptr;
+  if (w->train_base) {
+    const int Kp = pad64((int)d.M), Kl = pad64(nl), bq = d.nq * d.hd;
+    const size_t a_rows = (size_t)std::max(std::max(2 * d.F, d.NQKV), d.D), b_rows = (size_t)std::max(std::max(d.F, bq), d.D);
+    s.tA = c.take<bf16_t>(std::max(a_rows * Kp, (size_t)w->vocab_pad * Kl));     // also dlogits^T [vocab_pad, Kl]
+    s.tB = c.take<bf16_t>(std::max(b_rows * Kp, (size_t)d.D * Kl));
+    const int shp[4][2] = {{d.NQKV, d.D}, {d.D, bq}, {2 * d.F, d.D}, {d.D, d.F}};
+    size_t mx = 0;
+    for (auto& q : shp) mx = std::max(mx, (size_t)ta_gemm_splitk_ws_bytes(q[0], q[1], wgrad_splits(q[0], q[1], Kp)));
+    s.wsk = c.take<float>(mx / 4 + 4);
+  }
   s.bytes = c.total();
   return s;
 }
@@ -377,7 +397,8 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     LmLayerTape p = store[alias ? 0 : l];
     if (ext) { p.i_qkv = ext[l].g[0]; p.i_o = ext[l].g[1]; p.i_gu = ext[l].g[2]; p.i_d = ext[l].g[3]; }
     float* x_next = (l + 1 < w->n_layers) ? store[alias ? 0 : l + 1].x_in : x_final;
-    bf16_t* xn = lora ? p.xn_s : s.xn;
+    const bool keep = lora || (w->train_base && !alias);
+    bf16_t* xn = keep ? p.xn_s : s.xn;
     const bool rb = lm_res_bf16();
     auto norm = [&](const float* x, const float* gw, bf16_t* y, float* r) -> int {
       return rb ? ta_rmsnorm_fwd_bf16(x, gw, y, nullptr, r, M, d.D, w->eps, st) : ta_rmsnorm_fwd(x, gw, y, nullptr, r, M, d.D, w->eps, 0, st);
@@ -401,8 +422,8 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
     RC(res_gemm(p.ao, Lw.wo, p.x1, d.nq * d.hd, p.x_in));
-    bf16_t* xn2 = lora ? p.xn2_s : s.xn;
-    bf16_t* act = lora ? p.act_s : s.act;
+    bf16_t* xn2 = keep ? p.xn2_s : s.xn;
+    bf16_t* act = keep ? p.act_s : s.act;
     RC(norm(p.x1, Lw.ln_post_w, xn2, p.r_post));
     if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu));
     RC(gemm_opt(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
@@ -495,11 +516,13 @@ extern "C" int ta_lm_prefill(const ta_lm_weights* w, const long* ids, const int*
 
 extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
                               const int* label_rows, int n_lab, float* d_audio, long n_audio_rows, float* d_embeds,
-                              const ta_lm_lora_grads* lora_grads, const void* tape, void* ws, long ws_bytes, hipStream_t st) {
+                              const ta_lm_lora_grads* lora_grads, const ta_lm_wgrads* wg, const long* ids, const void* tape,
+                              void* ws, long ws_bytes, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (w->n_layers > MAX_LM_LAYERS) return TA_ERR_ARG;
   const bool lora = w->lora_rank > 0;
   if (lora && !lora_grads) return TA_ERR_ARG;
+  if (wg && (!w->train_base || lora || !wg->layers || (wg->dembed && !ids))) return TA_ERR_ARG;
   const LmDims d = lm_dims(w, B, L);
   const int M = (int)d.M;
   LmLayerTape store[MAX_LM_LAYERS];
@@ -541,6 +564,27 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
                      nullptr, 0, 0, sp, s.skws, st));
   if (hipMemsetAsync(s.dhn, 0, (size_t)M * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
   RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
+  // ---- weight gradients (full decoder fine-tuning): dW[N_out, K_in] += dY^T X as an NT GEMM over transposed bf16 images
+  const int Kp = pad64(M);
+  auto wgrad = [&](const bf16_t* dy, int n_out, const bf16_t* x, int k_in, float* dW) -> int {
+    if (!dW) return TA_OK;
+    RC(ta_transpose_to_bf16(dy, 0, n_out, 0, 0, s.tA, Kp, M, n_out, st));
+    RC(ta_transpose_to_bf16(x, 0, k_in, 0, 0, s.tB, Kp, M, k_in, st));
+    return ta_gemm_bf16_nt(s.tA, s.tB, dW, n_out, k_in, Kp, Kp, 0, 0, k_in, 0, 0, 0, nullptr, dW, 0, 0,
+                           wgrad_splits(n_out, k_in, Kp), s.wsk, st);
+  };
+  if (wg) {
+    // tied lm_head: dE[v, :] += sum over the labelled rows of dlogits[r, v] * hn[r, :]
+    if (wg->dembed) {
+      const int Kl = pad64(n_lab);
+      RC(ta_gather_rows_bf16(t.hn, label_rows, s.hl, n_lab, d.D, st));       // (the forward's copy lived in ITS workspace)
+      RC(ta_transpose_to_bf16(t.dlogits, 0, w->vocab_pad, 0, 0, s.tA, Kl, n_lab, w->vocab_pad, st));
+      RC(ta_transpose_to_bf16(s.hl, 0, d.D, 0, 0, s.tB, Kl, n_lab, d.D, st));
+      RC(ta_gemm_bf16_nt(s.tA, s.tB, wg->dembed, w->vocab, d.D, Kl, Kl, 0, 0, d.D, 0, 0, 0, nullptr, wg->dembed, 0, 0, 1,
+                         nullptr, st));
+    }
+    if (wg->dnorm) RC(ta_rmsnorm_dw(s.dhn, 0, t.x_final, lm_res_bf16(), t.r_f, wg->dnorm, M, d.D, st));
+  }
   float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
   float* dx_alt = s.dxb32;
   // dyb: the incoming gradient is bf16 (the two dX GEMMs that feed an RMSNorm backward write bf16 in that mode: it is
@@ -556,6 +600,8 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     const LmLayerTape& p = store[l];
     // ---- MLP: x2 = x1 + down(silu(gate) * up)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
+    const ta_lm_layer_wgrads* g = wg ? &wg->layers[l] : nullptr;
+    if (g) RC(wgrad(s.dxb, d.D, p.act_s, d.F, g->dwd));
     // Measured (same box, 3 runs each): fusing the SwiGLU backward into this GEMM's epilogue makes the step 0.4 ms SLOWER
     // (54.8 vs 54.3 ms) -- at one workgroup per CU nothing overlaps an epilogue, so bytes moved there (gate|up read,
     // d(gate|up) written in 32-B pieces) cost more than the separate streaming kernel at 6 TB/s.  Off unless asked for.
@@ -567,22 +613,28 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     }
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
+    if (g) RC(wgrad(s.dgu, 2 * d.F, p.xn2_s, d.D, g->dwgu));
     RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
+    if (g && g->dln_post) RC(ta_rmsnorm_dw(s.dxn, gb, p.x1, lm_res_bf16(), p.r_post, g->dln_post, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
     if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
+    if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
                         B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
-    RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv, B,
-                          d.nq, d.nkv, L, st));
+    RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv,
+                          g ? g->dqn : nullptr, g ? g->dkn : nullptr, B, d.nq, d.nkv, L, st));
+    if (g) RC(wgrad(s.dqkv, d.NQKV, p.xn_s, d.D, g->dwqkv));
     if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
     RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));
+    if (g && g->dln_in) RC(ta_rmsnorm_dw(s.dxn, gb, p.x_in, lm_res_bf16(), p.r_in, g->dln_in, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx));
   }
   if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return TA_ERR_LAUNCH;
   if (d_audio && src_row) RC(ta_audio_grad_gather(src_row, dx, d_audio, M, d.D, st));
+  if (wg && wg->dembed) RC(ta_embed_grad_scatter(ids, src_row, dx, wg->dembed, M, d.D, w->vocab, st));
   return TA_OK;
 }

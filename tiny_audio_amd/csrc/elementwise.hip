@@ -277,6 +277,28 @@ extern "C" int ta_audio_grad_gather(const int* src_row, const float* dx0, float*
   TA_LAUNCH(audio_grad_gather_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, src_row, dx0, d_audio, n_rows, D);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
+// input-lookup share of the embedding gradient (trainable LM): one wave per token row, float4 per lane-step
+__global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const long* __restrict__ ids, const int* __restrict__ src_row,
+                                                                 const float* __restrict__ dx0, float* __restrict__ dembed,
+                                                                 int n_rows, int D, long vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  if (src_row && src_row[row] >= 0) return;            // an <audio> position: its embedding row was overwritten
+  const long id = ids[row];
+  if (id < 0 || id >= vocab) return;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 g = *(const float4*)(dx0 + (long)row * D + c);
+    float* dst = dembed + id * D + c;
+    unsafeAtomicAdd(dst, g.x); unsafeAtomicAdd(dst + 1, g.y); unsafeAtomicAdd(dst + 2, g.z); unsafeAtomicAdd(dst + 3, g.w);
+  }
+}
+extern "C" int ta_embed_grad_scatter(const long* ids, const int* src_row, const float* dx0, float* dembed, int n_rows, int D,
+                                     long vocab, hipStream_t st) {
+  if (n_rows <= 0) return TA_OK;
+  if (D % 4) return TA_ERR_ARG;
+  TA_LAUNCH(embed_grad_scatter_kernel, dim3(ta_cdiv(n_rows, 4)), dim3(256), 0, st, ids, src_row, dx0, dembed, n_rows, D, vocab);
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
 extern "C" int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st) {
   if (n <= 0) return TA_OK;
   if (D % 8) return TA_ERR_ARG;

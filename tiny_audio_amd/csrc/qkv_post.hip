@@ -175,8 +175,11 @@ __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __re
                                                               const float* __restrict__ qn_w, const float* __restrict__ kn_w,
                                                               const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                               const int* __restrict__ pos, bf16_t* __restrict__ dqkv,
+                                                              float* __restrict__ dqn, float* __restrict__ dkn,
                                                               int Hq, int Hkv, int L) {
   constexpr int HD = 128;
+  __shared__ float wsum[4][HD];                      // per-wave partial q_norm / k_norm weight gradients (trainable LM)
+  float gw1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gw2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int tid = threadIdx.x, j = tid & 7;
   const int l0 = blockIdx.x * TOK_TILE, hh = blockIdx.y, b = blockIdx.z;
   const int sec = hh < Hq ? 0 : (hh < Hq + Hkv ? 1 : 2);
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __re
       for (int e = 0; e < 8; ++e) {
         const float dn1 = d1[e] * c[e] + d2[e] * sn[e], dn2 = d2[e] * c[e] - d1[e] * sn[e];     // RoPE^T
         x1[e] *= r; x2[e] *= r;                                                             // x-hat
+        if (live) { gw1[e] += dn1 * x1[e]; gw2[e] += dn2 * x2[e]; }                          // d loss / d norm weight
         d1[e] = dn1 * w1[e]; d2[e] = dn2 * w2[e];
         dot += d1[e] * x1[e] + d2[e] * x2[e];
       }
@@ -219,6 +223,19 @@ __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __re
       *(uint4*)(dst + 8 * j) = g1;
       *(uint4*)(dst + 64 + 8 * j) = g2;
     }
+  }
+  float* dwn = sec == 0 ? dqn : (sec == 1 ? dkn : nullptr);        // block-uniform
+  if (dwn) {
+    // lanes with the same j (stride 8) hold the same 16 dims: fold them, then the 4 waves through LDS, one atomic per dim
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = gw1[e], c2 = gw2[e];
+      a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 8, 64); c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+      if ((tid & 63) < 8) { wsum[tid >> 6][8 * j + e] = a; wsum[tid >> 6][64 + 8 * j + e] = c2; }
+    }
+    __syncthreads();
+    if (tid < HD) unsafeAtomicAdd(dwn + tid, wsum[0][tid] + wsum[1][tid] + wsum[2][tid] + wsum[3][tid]);
   }
 }
 
@@ -282,12 +299,12 @@ extern "C" int ta_lm_qkv_post_fwd(const void* qkv0, const float* qn_w, const flo
 
 extern "C" int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv0, const float* rq,
                                   const float* rk, const float* qn_w, const float* kn_w, const float* cosT,
-                                  const float* sinT, const int* pos, void* dqkv, int B, int Hq, int Hkv, int L,
-                                  hipStream_t st) {
+                                  const float* sinT, const int* pos, void* dqkv, float* dqn_accum, float* dkn_accum,
+                                  int B, int Hq, int Hkv, int L, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   TA_LAUNCH(lm_qkv_post_bwd_kernel, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
                      (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos,
-                     (bf16_t*)dqkv, Hq, Hkv, L);
+                     (bf16_t*)dqkv, dqn_accum, dkn_accum, Hq, Hkv, L);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

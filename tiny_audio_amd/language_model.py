@@ -40,6 +40,11 @@ class Qwen3MI355X(torch.nn.Module):
         self._layers_arr = None
         self.lora_rank = 0
         self._lora_bound = None
+        self.train_base = False          # full decoder fine-tuning (freeze_language_model=False)
+        self.want_train_base = False     # ... requested before the weights exist: enabled by _finalize
+        self._ft_bound = None
+        self._ft_versions = None
+        self.accumulate_into_grad = False   # trainer opt-in: weight gradients are added straight into Parameter.grad
 
     # ------------------------------------------------------------------ LoRA (stage 2; asr_modeling.py:289-301)
     def _lora_dims(self):
@@ -59,6 +64,8 @@ class Qwen3MI355X(torch.nn.Module):
         """peft ``LoraConfig(r, lora_alpha, target_modules=all 7 linears, bias='none')`` on every decoder layer:
         lora_A ~ kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(in)), lora_B = 0, y += (alpha/r) B A x.  The trainable
         fp32 masters are 8 Parameters [n_layers, ...] in the stacked group layout of include/ta355.h."""
+        if self.train_base or self.want_train_base:
+            raise NotImplementedError("LoRA on top of a trainable base LM is not built")
         if rank != 8:
             raise NotImplementedError("the fused adapter tile is built for lora_rank=8 (the reference default)")
         if dropout:
@@ -137,6 +144,122 @@ class Qwen3MI355X(torch.nn.Module):
                     setattr(self._layers_arr[i], f"{ab}_{g}", p.data_ptr() + i * step)
         self._lora_bound = key
 
+    # ------------------------------------------------------------------ full decoder fine-tuning (8(f) rank 4)
+    # (kind, per-layer struct field or None, needs bf16 images, decays)
+    FT_KINDS = (("wqkv", True), ("wo", True), ("wgu", True), ("wd", True), ("ln_in_w", False), ("ln_post_w", False),
+                ("qn_w", False), ("kn_w", False))
+
+    def ft_parameters(self):
+        """The fp32 masters of the trainable LM: 8 stacked per-layer Parameters [n_layers, ...] + final norm + embedding."""
+        if not self.train_base:
+            return []
+        return [getattr(self, "ft_" + k) for k, _ in self.FT_KINDS] + [self.ft_norm_w, self.ft_embed]
+
+    @torch.no_grad()
+    def enable_full_finetune(self):
+        """freeze_language_model=False (tiny_audio/asr_config.py:77; configs/experiments/embedded.yaml:23): every LM weight
+        trains.  Masters are fp32 Parameters (stacked over the layers, q|k|v and gate|up fused like the kernels' images);
+        the kernels keep reading bf16 images (W and W^T) that ``refresh_images`` rebuilds after an optimizer step, the
+        norm scales and the embedding table are read from the masters directly."""
+        if self.lora_rank:
+            raise NotImplementedError("LoRA on top of a trainable base LM is not built")
+        if self._w is None:
+            raise _lib.Ta355Error("load or initialise the LM weights before enable_full_finetune()")
+        c, b = self.config, self._bufs
+        Lyr = c.num_hidden_layers
+        src = getattr(self, "_fp32_src", None) or {}
+        for kind, _img in self.FT_KINDS:
+            rows = [src.get(f"layers.{i}.{kind}", b[f"layers.{i}.{kind}"]).to(F32) for i in range(Lyr)]
+            p = torch.nn.Parameter(torch.stack(rows, 0).contiguous())
+            p._no_decay = not _img                      # norm scales: the no-decay group (scripts/train.py:397-432)
+            setattr(self, "ft_" + kind, p)
+        self.ft_norm_w = torch.nn.Parameter(b["norm_w"].to(F32).clone()); self.ft_norm_w._no_decay = True
+        self.ft_embed = torch.nn.Parameter(b["embed_f32"].clone())
+        self._fp32_src = None
+        self.train_base = True
+        self._w.train_base = 1
+        self._ft_bound = self._ft_versions = None
+        self._bind_ft()
+        return self
+
+    def _bind_ft(self):
+        """Point the kernels at the masters they read directly (norm scales, embedding) -- a flat-buffer optimizer may have
+        re-homed ``.data`` -- and rebuild the bf16 images if any master changed since they were built."""
+        ps = self.ft_parameters()
+        key = tuple(p.data_ptr() for p in ps)
+        if key != self._ft_bound:
+            for p in ps:
+                assert p.dtype == F32 and p.is_contiguous()
+            for kind in ("ln_in_w", "ln_post_w", "qn_w", "kn_w"):
+                p = getattr(self, "ft_" + kind)
+                step = p[0].numel() * 4
+                for i in range(self.config.num_hidden_layers):
+                    setattr(self._layers_arr[i], kind, p.data_ptr() + i * step)
+            self._w.norm_w = self.ft_norm_w.data_ptr()
+            self._w.embed_f32 = self.ft_embed.data_ptr()
+            self._ft_bound = key
+            self._ft_versions = None
+        ver = tuple(p._version for p in ps)
+        if ver != self._ft_versions:
+            self.refresh_images()
+
+    @torch.no_grad()
+    def refresh_images(self):
+        """bf16 W / W^T images of the four matrices of every layer and of the tied embedding, from the fp32 masters
+        (in place: the kernels' pointers stay valid).  Call after every optimizer step that writes the masters through
+        raw pointers; torch optimizers are detected through the Parameters' version counters."""
+        b = self._bufs
+        for kind, img in self.FT_KINDS:
+            if not img:
+                continue
+            m = getattr(self, "ft_" + kind)
+            for i in range(self.config.num_hidden_layers):
+                wb = b[f"layers.{i}.{kind}"]
+                wb.copy_(m[i])
+                b[f"layers.{i}.{kind}_t"].copy_(wb.t())
+        V = self.config.vocab_size
+        b["embed_bf16"][:V].copy_(self.ft_embed)
+        b["embed_t_bf16"].copy_(b["embed_bf16"].t())
+        self._ft_versions = tuple(p._version for p in self.ft_parameters())
+
+    def ft_state_dict_hf(self):
+        """The masters under the reference's parameter names (``model.layers.N.self_attn.q_proj.weight`` ...; tiny_audio/asr_modeling.py:409-421;
+        the tied ``lm_head.weight`` alias of the embedding is not repeated: safetensors refuses shared storage)."""
+        c = self.config
+        nq, nkv, hd, F_ = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.intermediate_size
+        sd = {"model.embed_tokens.weight": self.ft_embed.detach(), "model.norm.weight": self.ft_norm_w.detach()}
+        for i in range(c.num_hidden_layers):
+            p = f"model.layers.{i}."
+            a = p + "self_attn."
+            w = self.ft_wqkv.detach()[i]
+            sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"] = w[: nq * hd], w[nq * hd:(nq + nkv) * hd], w[(nq + nkv) * hd:]
+            sd[a + "o_proj.weight"] = self.ft_wo.detach()[i]
+            gu = self.ft_wgu.detach()[i]
+            sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = gu[:F_], gu[F_:]
+            sd[p + "mlp.down_proj.weight"] = self.ft_wd.detach()[i]
+            sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = self.ft_ln_in_w.detach()[i], self.ft_ln_post_w.detach()[i]
+            sd[a + "q_norm.weight"], sd[a + "k_norm.weight"] = self.ft_qn_w.detach()[i], self.ft_kn_w.detach()[i]
+        return sd
+
+    @torch.no_grad()
+    def load_ft_state_dict_hf(self, sd):
+        """Inverse of ``ft_state_dict_hf`` (keys may carry a ``language_model.`` prefix; ``lm_head.weight`` is ignored:
+        it is the embedding)."""
+        c = self.config
+        g = lambda k: torch.as_tensor(sd[k] if k in sd else sd["language_model." + k]).to(device=self.device_, dtype=F32)
+        self.ft_embed.copy_(g("model.embed_tokens.weight")); self.ft_norm_w.copy_(g("model.norm.weight"))
+        for i in range(c.num_hidden_layers):
+            p = f"model.layers.{i}."
+            a = p + "self_attn."
+            self.ft_wqkv[i].copy_(torch.cat([g(a + "q_proj.weight"), g(a + "k_proj.weight"), g(a + "v_proj.weight")], 0))
+            self.ft_wo[i].copy_(g(a + "o_proj.weight"))
+            self.ft_wgu[i].copy_(torch.cat([g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")], 0))
+            self.ft_wd[i].copy_(g(p + "mlp.down_proj.weight"))
+            self.ft_ln_in_w[i].copy_(g(p + "input_layernorm.weight")); self.ft_ln_post_w[i].copy_(g(p + "post_attention_layernorm.weight"))
+            self.ft_qn_w[i].copy_(g(a + "q_norm.weight")); self.ft_kn_w[i].copy_(g(a + "k_norm.weight"))
+        self.refresh_images()
+        return self
+
     # ------------------------------------------------------------------ weights
     def _rope_tables(self):
         c = self.config
@@ -144,8 +267,14 @@ class Qwen3MI355X(torch.nn.Module):
         freqs = torch.arange(c.max_position_embeddings, dtype=torch.float32)[:, None] * inv[None, :]
         return freqs.cos().contiguous(), freqs.sin().contiguous()
 
+    keep_fp32 = False     # set before loading weights that will be fine-tuned: the fp32 originals seed the masters
+
     def _pack_matrix(self, name, w):
         """w fp32 [out, in] on device -> bf16 copy + transposed bf16 copy."""
+        if self.keep_fp32:
+            if getattr(self, "_fp32_src", None) is None:
+                self._fp32_src = {}
+            self._fp32_src[name] = w
         wb = w.to(BF16).contiguous()
         self._bufs[name] = wb
         self._bufs[name + "_t"] = wb.t().contiguous()
@@ -224,6 +353,9 @@ class Qwen3MI355X(torch.nn.Module):
         if self.lora_rank:
             w.lora_rank, w.lora_scale = self.lora_rank, float(self.lora_alpha) / self.lora_rank
         self._layers_arr, self._w, self._lora_bound = arr, w, None
+        if self.train_base or self.want_train_base:      # (re)seed the masters from the weights just loaded
+            self.train_base = False
+            self.enable_full_finetune()
 
     def export_state_dict_hf(self):
         """Back to the reference's parameter names as fp32 numpy (used by bench.py's CPU-baseline leg)."""
@@ -259,6 +391,8 @@ class Qwen3MI355X(torch.nn.Module):
         dev = self.device_
         if self.lora_rank:
             self._bind_lora()
+        if self.train_base:
+            self._bind_ft()
         tape = torch.empty(L_.ta_lm_tape_bytes(C.byref(self._w), B, L, n_label_rows), device=dev, dtype=torch.uint8)
         ws = torch.empty(L_.ta_lm_workspace_bytes(C.byref(self._w), B, L, n_label_rows), device=dev, dtype=torch.uint8)
         loss = torch.zeros(1, device=dev, dtype=F32)
@@ -269,20 +403,22 @@ class Qwen3MI355X(torch.nn.Module):
                                          ptr(nll), ptr(logits), ptr(tape), ptr(ws), ws.numel(), stream()),
                    "ta_lm_forward_loss")
         ctx = dict(tape=tape, ws=ws, B=B, L=L, src_row=src_row, kmask=kmask, pos=pos, label_rows=label_rows,
-                   n_label_rows=n_label_rows)
+                   n_label_rows=n_label_rows, ids=input_ids)
         return loss, nll, logits, ctx
 
     def backward_from_ctx(self, ctx, n_audio_rows, want_d_embeds=False, want_d_audio=True):
-        """-> (d_audio f32 [n_audio_rows, D] or None, d_embeds f32 [B*L, D] or None, LoRA grads (list of 8, the order
-        of ``lora_parameters()``) or None) for d(loss) = 1."""
+        """-> (d_audio f32 [n_audio_rows, D] or None, d_embeds f32 [B*L, D] or None, trainable-LM gradients or None) for
+        d(loss) = 1.  The third item is the list of adapter gradients (order of ``lora_parameters()``) with LoRA, the list
+        of weight gradients (order of ``ft_parameters()``) with a trainable base LM -- or ``[None] * 10`` when
+        ``accumulate_into_grad`` is set and they were added straight into ``Parameter.grad``."""
         D, dev = self.config.hidden_size, self.device_
         d_audio = torch.empty((n_audio_rows, D), device=dev, dtype=F32) if want_d_audio else None
         d_emb = torch.empty((ctx["B"] * ctx["L"], D), device=dev, dtype=F32) if want_d_embeds else None
-        lg, lg_arr = None, None
+        lg, lg_arr, wg, keep = None, None, None, None
+        nl = self.config.num_hidden_layers
         if self.lora_rank:
             self._bind_lora()
             lg = [torch.empty_like(p) for p in self.lora_parameters()]
-            nl = self.config.num_hidden_layers
             lg_arr = (_lib.LmLoraGrads * nl)()
             k = 0
             for g, _ in LORA_GROUPS:
@@ -291,10 +427,26 @@ class Qwen3MI355X(torch.nn.Module):
                     for i in range(nl):
                         setattr(lg_arr[i], f"d{ab}_{g}", lg[k].data_ptr() + i * step)
                     k += 1
+        if self.train_base:
+            ps = self.ft_parameters()
+            direct = self.accumulate_into_grad and all(p.grad is not None and p.grad.is_contiguous() for p in ps)
+            bufs = [p.grad for p in ps] if direct else [torch.zeros_like(p) for p in ps]
+            arr = (_lib.LmLayerWgrads * nl)()
+            for (kind, _), g in zip(self.FT_KINDS, bufs):
+                field = {"wqkv": "dwqkv", "wo": "dwo", "wgu": "dwgu", "wd": "dwd", "ln_in_w": "dln_in", "ln_post_w": "dln_post",
+                         "qn_w": "dqn", "kn_w": "dkn"}[kind]
+                step = g[0].numel() * 4
+                for i in range(nl):
+                    setattr(arr[i], field, g.data_ptr() + i * step)
+            wg = _lib.LmWgrads(layers=C.cast(arr, C.POINTER(_lib.LmLayerWgrads)), dnorm=bufs[8].data_ptr(), dembed=bufs[9].data_ptr())
+            keep = (arr, bufs)
+            lg = [None] * len(ps) if direct else bufs
         _lib.check(_lib.lib().ta_lm_backward(C.byref(self._w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
                                              ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
-                                             ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr, ptr(ctx["tape"]),
+                                             ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr,
+                                             None if wg is None else C.byref(wg), ptr(ctx.get("ids")), ptr(ctx["tape"]),
                                              ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
+        del keep
         return d_audio, d_emb, lg
 
 
@@ -345,6 +497,8 @@ class Qwen3MI355X(torch.nn.Module):
         shape = (c.num_hidden_layers, B, c.num_key_value_heads, Lmax, c.head_dim)
         kc, vc = torch.empty(shape, dtype=BF16, device=dev), torch.empty(shape, dtype=BF16, device=dev)
         lora_img = None
+        if self.train_base:
+            self._bind_ft()
         if self.lora_rank:
             self._bind_lora()
             lora_img = torch.empty(L_.ta_lm_lora_image_bytes(C.byref(self._w)), dtype=torch.uint8, device=dev)
@@ -433,6 +587,6 @@ class FrozenLMLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_nll, _g_logits):
         d_audio, _, lg = ctx.lm.backward_from_ctx(ctx.c, ctx.n_audio, want_d_audio=ctx.needs_input_grad[0])
         ctx.c = None
-        lora = tuple(g * g_loss for g in lg)[: ctx.n_lora] if lg is not None else ()
+        lora = tuple(None if g is None else g * g_loss for g in lg)[: ctx.n_lora] if lg is not None else ()
         lora = lora + (None,) * (ctx.n_lora - len(lora))
         return (None if d_audio is None else d_audio * g_loss,) + (None,) * 9 + lora

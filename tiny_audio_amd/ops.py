@@ -170,12 +170,28 @@ def lm_qkv_post_fwd(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, eps=1e-6, pos=N
     return Q, K, V, QT, KT, VT, rq, rk
 
 
-def lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, pos=None):
+def lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, pos=None, dqn=None, dkn=None):
+    """dqn / dkn f32 [128]: += the q_norm / k_norm weight gradients (trainable LM)."""
     dqkv = torch.empty_like(qkv0)
     check(lib().ta_lm_qkv_post_bwd(ptr(dQ), ptr(dK), ptr(dV), ptr(qkv0), ptr(rq), ptr(rk), ptr(qn_w), ptr(kn_w),
-                                   ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv, L, stream()),
+                                   ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), ptr(dqn), ptr(dkn), B, Hq, Hkv, L, stream()),
           "ta_lm_qkv_post_bwd")
     return dqkv
+
+
+def rmsnorm_dw(dy, x, rstd, dw):
+    """dw[h] += sum_m dy[m,h] * x[m,h] * rstd[m]   (dy, x: f32 or bf16 [M, H])"""
+    M, H = x.shape
+    check(lib().ta_rmsnorm_dw(ptr(dy), int(dy.dtype == BF16), ptr(x), int(x.dtype == BF16), ptr(rstd), ptr(dw), M, H, stream()),
+          "ta_rmsnorm_dw")
+    return dw
+
+
+def embed_grad_scatter(ids, src_row, dx0, dembed):
+    n, D = dx0.shape
+    check(lib().ta_embed_grad_scatter(ptr(ids), ptr(src_row), ptr(dx0), ptr(dembed), n, D, dembed.shape[0], stream()),
+          "ta_embed_grad_scatter")
+    return dembed
 
 
 def enc_qkv_post(qkv, cosT, sinT, B, H, S):

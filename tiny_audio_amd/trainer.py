@@ -82,7 +82,7 @@ class FlatTrainable:
                 p.data = self.flat_p[o:o + s].view_as(p)
                 p.grad = self.flat_g[o:o + s].view_as(p)
         # decay on weight matrices only; norm scales and biases get 0 (scripts/train.py:397-432)
-        self.decay = [not (n.endswith("bias") or "norm" in n.split(".")[-2:][0] or p.ndim < 2)
+        self.decay = [not (n.endswith("bias") or "norm" in n.split(".")[-2:][0] or p.ndim < 2 or getattr(p, "_no_decay", False))
                       for n, p in zip(self.names, self.params)]
 
     @property
@@ -122,6 +122,9 @@ class ASRTrainer:
         self.decoder_learning_rate, self.decoder_weight_decay = decoder_learning_rate, decoder_weight_decay
         self.projector_weight_decay = projector_weight_decay
         self.flat = FlatTrainable(list(model.named_parameters()))
+        lm = getattr(model, "language_model", None)
+        if lm is not None and getattr(lm, "train_base", False):
+            lm.accumulate_into_grad = True      # d(loss) is 1 here: weight gradients go straight into the flat buffer
         self.sqnorm = torch.zeros(1, device=self.flat.flat_p.device, dtype=torch.float32)
         self.global_step = 0
         self._micro = 0
@@ -130,6 +133,9 @@ class ASRTrainer:
         proj = getattr(self.model, "projector", None)
         if proj is not None and hasattr(proj, "_pack_versions"):
             proj._pack_versions = None          # the HIP optimizer writes masters behind autograd's version counter
+        lm = getattr(self.model, "language_model", None)
+        if lm is not None and getattr(lm, "train_base", False):
+            lm._ft_versions = None              # bf16 W / W^T images are rebuilt before the next forward
 
     def training_step(self, batch: dict):
         """One micro-batch: forward + backward of SUM-CE; optimizer step every gradient_accumulation_steps.
