@@ -46,12 +46,15 @@ def parse():
                     help="frozen LM shape: Qwen3-0.6B (north_star) or Qwen3-1.7B (hidden 2048, ffn 6144: transcription.yaml:14-16)")
     ap.add_argument("--lora", action="store_true",
                     help="BASELINE configs[4]: stage 2 -- frozen projector + rank-8 LoRA adapters on all 196 Qwen3 linears")
+    ap.add_argument("--full-ft", action="store_true",
+                    help="full decoder fine-tuning (configs/experiments/embedded.yaml): freeze_language_model=False, MLP projector "
+                         "H=2048, decoder lr 1e-4; every LM weight trains (0.6 B fp32 masters, AdamW, bf16 W / W^T images rebuilt per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=3072):
+def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=3072, full_ft=False):
     """BASELINE.md section 3 (2*MAC, dense).  lm_head is counted at the positions actually computed."""
     conv = 0.983 + 4.915
     enc = 32 * (2 * 500 * 4 * 1280 ** 2 + 4 * 500 ** 2 * 1280 + 4 * 500 * 1280 * 5120) / 1e9
@@ -60,7 +63,10 @@ def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=307
     lm_body = 28 * (2 * L * (D * 2048 + 2 * D * 1024 + 2048 * D + 3 * D * F) + 2 * L * L * 2048) / 1e9   # 16 q / 8 kv heads x 128
     head_rows = (L if full_logits else 0) + n_label
     head = 2 * head_rows * D * V / 1e9 + 2 * n_label * D * V / 1e9                        # fwd (+ labelled dH backward)
-    return conv + enc + proj_f + proj_b + 2 * lm_body + head
+    lm_w = 0.0
+    if full_ft:     # weight gradients: one more pass over every linear (no attention term) + the tied head's dE at the labelled rows
+        lm_w = 28 * (2 * L * (D * 2048 + 2 * D * 1024 + 2048 * D + 3 * D * F)) / 1e9 + 2 * n_label * D * V / 1e9
+    return conv + enc + proj_f + proj_b + 2 * lm_body + head + lm_w
 
 
 def main():
@@ -83,7 +89,9 @@ def main():
     from oracle import weights as OW
 
     text = dict(hidden_size=2048, intermediate_size=6144) if a.lm == "1.7b" else None
-    cfg = ASRConfig(text_config=text, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
+    if a.full_ft:
+        a.proj_hidden = 2048 if a.proj_hidden == 1024 else a.proj_hidden
+    cfg = ASRConfig(text_config=text, freeze_language_model=not a.full_ft, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
                     use_lora=a.lora, freeze_projector=a.lora)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
@@ -91,7 +99,8 @@ def main():
     fe = LogMelFeatureExtractor(128, dev)
     trainer = ASRTrainer(model, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0,
                                                   warmup_steps=500, max_steps=50000, lr_scheduler_type="polynomial",
-                                                  lr_scheduler_kwargs={"power": 0.5}))
+                                                  lr_scheduler_kwargs={"power": 0.5}),
+                         decoder_learning_rate=1e-4 if a.full_ft else None)
     B, L, V = a.batch, a.seq_len, cfg.text_config.vocab_size
     # synthetic inputs of SURVEY.md 8(d), resident in HBM: wav = 0.1 * N(0,1), 160000 samples per clip
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
@@ -166,17 +175,18 @@ def main():
                         "hbm_kernels": hbm_kernel_rates(B, L, cfg, fe, wav, lens)}
 
     cpu = None
-    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024 and a.lm == "0.6b":
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024 and a.lm == "0.6b" and not a.full_ft:
         cpu = cpu_baseline(model, cfg, L)
 
     if rank == 0:
         D_, F_ = cfg.text_config.hidden_size, cfg.text_config.intermediate_size
-        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden, D=D_, F=F_)
+        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden, D=D_, F=F_, full_ft=a.full_ft)
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
-               "config": {"workload": ("configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
+               "config": {"workload": ("embedded.yaml: full decoder fine-tuning, MLP projector (H=%d) + every LM weight" % a.proj_hidden if a.full_ft else
+                                       "configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
                                        else ("configs[1]: MLP projector (H=%d, D=%d)" % (a.proj_hidden, D_)) if a.projector == "mlp" else
                                        "QFormer projector (2 layers, 16 heads, windows of 15 -> 3 queries, 102 audio tokens)" if a.projector == "qformer" else
                                        "MOSA projector (2 stride-2 convs, 4 dense experts of width 4096)" if a.projector == "mosa" else

@@ -80,6 +80,44 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const T* __restr
   }
 }
 
+// Same contract, 16-byte accesses on both sides (needs ld_in, in_bs, C, ld_out multiples of 8): a 64 x 64 tile goes
+// through LDS; a thread loads 8 consecutive columns of one row and stores 8 consecutive rows of one column.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_to_bf16_vec_kernel(const T* __restrict__ in, long ld_in, long in_bs, int in_rpb,
+                                                                    bf16_t* __restrict__ out, long ld_out, int R, int C) {
+  constexpr int P = 72;                               // LDS row pitch (elements): 144 B, 16-B aligned
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64 * P];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ch = tid + it * 256, r = ch >> 3, cc = ch & 7;
+    const int gr = r0 + r, gc = c0 + cc * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < R && gc < C) {
+      const long off = (long)(gr / in_rpb) * in_bs + (long)(gr % in_rpb) * ld_in + gc;
+      if constexpr (sizeof(T) == 4) {
+        const float4 a = *(const float4*)((const float*)in + off), b = *(const float4*)((const float*)in + off + 4);
+        v = make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+      } else {
+        v = *(const uint4*)((const bf16_t*)in + off);
+      }
+    }
+    *(uint4*)(tile + r * P + cc * 8) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ch = tid + it * 256, c = ch >> 3, rc = ch & 7;
+    const int gc = c0 + c, gr = r0 + rc * 8;
+    if (gc < C && gr < ld_out) {
+      union { uint4 v; bf16_t e[8]; } u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u.e[j] = tile[(rc * 8 + j) * P + c];
+      *(uint4*)(out + (long)gc * ld_out + gr) = u.v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- encoder input layout
 // feats f32 [B, C, T] -> bf16 time-major [B, T+2, C] with zero rows 0 and T+1 (conv padding=1)
 __global__ __launch_bounds__(256) void feats_to_tm_kernel(const float* __restrict__ f, bf16_t* __restrict__ out, int C, int T) {
@@ -238,6 +276,15 @@ extern "C" int ta_transpose_to_bf16(const void* in, int in_is_f32, long ld_in, l
   if (ld_out < R) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(C, 64), ta_cdiv(ld_out, 64));
   if (in_rpb <= 0) in_rpb = R;
+  if (!((ld_in | in_bs | (long)C | ld_out) & 7) && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
+    if (in_is_f32)
+      TA_LAUNCH((transpose_to_bf16_vec_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, in_bs, in_rpb,
+                (bf16_t*)out, ld_out, R, C);
+    else
+      TA_LAUNCH((transpose_to_bf16_vec_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, in_bs, in_rpb,
+                (bf16_t*)out, ld_out, R, C);
+    TA_CHECK_LAUNCH(); return TA_OK;
+  }
   if (in_is_f32)
     TA_LAUNCH((transpose_to_bf16_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, in_bs, in_rpb,
                        (bf16_t*)out, ld_out, R, C);

@@ -295,33 +295,42 @@ extern "C" int ta_rmsnorm_bwd(const float* dy, const float* x, const float* rstd
 
 
 // ---------------------------------------------------------------------------- RMSNorm weight gradient (trainable LM)
-// dw[h] += sum_m dy[m,h] * x[m,h] * rstd[m].  One workgroup = 16 rows x all columns (thread = 4 consecutive columns per
-// 1024-column pass); partial sums go out as one atomic per column per workgroup.
+// dw[h] += sum_m dy[m,h] * x[m,h] * rstd[m].  One workgroup = 32 rows x 256 columns: 4 row slots x 64 lanes of 4 columns,
+// 8 rows per thread with the loads of a row pair in flight together; the 4 slots fold through LDS, one atomic per column.
 template <bool DY_BF16, bool X_BF16>
 __global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                          const float* __restrict__ rstd, float* __restrict__ dw, int M, int H) {
-  const int r0 = blockIdx.x * 16, r1 = min(r0 + 16, M);
-  for (int c = threadIdx.x * 4; c < H; c += 1024) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const long off = (long)r * H + c;
-      float g[4], v[4];
-      if (DY_BF16) { const uint2 u = *(const uint2*)((const bf16_t*)dy + off); g[0] = bf2f((bf16_t)(u.x & 0xffff)); g[1] = bf2f((bf16_t)(u.x >> 16)); g[2] = bf2f((bf16_t)(u.y & 0xffff)); g[3] = bf2f((bf16_t)(u.y >> 16)); }
-      else { const float4 u = *(const float4*)((const float*)dy + off); g[0] = u.x; g[1] = u.y; g[2] = u.z; g[3] = u.w; }
-      if (X_BF16) { const uint2 u = *(const uint2*)((const bf16_t*)x + off); v[0] = bf2f((bf16_t)(u.x & 0xffff)); v[1] = bf2f((bf16_t)(u.x >> 16)); v[2] = bf2f((bf16_t)(u.y & 0xffff)); v[3] = bf2f((bf16_t)(u.y >> 16)); }
-      else { const float4 u = *(const float4*)((const float*)x + off); v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w; }
-      const float rs = rstd[r];
-      a0 += g[0] * v[0] * rs; a1 += g[1] * v[1] * rs; a2 += g[2] * v[2] * rs; a3 += g[3] * v[3] * rs;
+  __shared__ float part[4][256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + tx * 4, r0 = blockIdx.x * 32;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  auto ld4 = [&](const void* p, bool bf, long off, float* o) {
+    if (bf) { const uint2 u = *(const uint2*)((const bf16_t*)p + off); o[0] = bf2f((bf16_t)(u.x & 0xffff)); o[1] = bf2f((bf16_t)(u.x >> 16)); o[2] = bf2f((bf16_t)(u.y & 0xffff)); o[3] = bf2f((bf16_t)(u.y >> 16)); }
+    else { const float4 u = *(const float4*)((const float*)p + off); o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; }
+  };
+  if (c < H) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const int ra = r0 + ty + 4 * i, rb = ra + 4;
+      float g0[4], v0[4], g1[4], v1[4];
+      const bool ia = ra < M, ib = rb < M;
+      if (ia) { ld4(dy, DY_BF16, (long)ra * H + c, g0); ld4(x, X_BF16, (long)ra * H + c, v0); }
+      if (ib) { ld4(dy, DY_BF16, (long)rb * H + c, g1); ld4(x, X_BF16, (long)rb * H + c, v1); }
+      if (ia) { const float rs = rstd[ra]; for (int k = 0; k < 4; ++k) a[k] += g0[k] * v0[k] * rs; }
+      if (ib) { const float rs = rstd[rb]; for (int k = 0; k < 4; ++k) a[k] += g1[k] * v1[k] * rs; }
     }
-    unsafeAtomicAdd(dw + c, a0); unsafeAtomicAdd(dw + c + 1, a1); unsafeAtomicAdd(dw + c + 2, a2); unsafeAtomicAdd(dw + c + 3, a3);
   }
+  for (int k = 0; k < 4; ++k) part[ty][tx * 4 + k] = a[k];
+  __syncthreads();
+  const int cc = blockIdx.y * 256 + threadIdx.x;
+  if (cc < H) unsafeAtomicAdd(dw + cc, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 extern "C" int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* rstd, float* dw_accum,
                              int M, int H, hipStream_t st) {
   if (M <= 0 || H <= 0) return TA_OK;
   if (H & 3) return TA_ERR_ARG;
-  dim3 grid(ta_cdiv(M, 16)), blk(256);
+  dim3 grid(ta_cdiv(M, 32), ta_cdiv(H, 256)), blk(256);
   if (dy_is_bf16 && x_is_bf16) TA_LAUNCH((rmsnorm_dw_kernel<true, true>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);
   else if (dy_is_bf16) TA_LAUNCH((rmsnorm_dw_kernel<true, false>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);
   else if (x_is_bf16) TA_LAUNCH((rmsnorm_dw_kernel<false, true>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);

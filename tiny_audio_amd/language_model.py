@@ -209,17 +209,23 @@ class Qwen3MI355X(torch.nn.Module):
         (in place: the kernels' pointers stay valid).  Call after every optimizer step that writes the masters through
         raw pointers; torch optimizers are detected through the Parameters' version counters."""
         b = self._bufs
+        gpu = self.device_.type == "cuda" and not _lib.DRY_RUN
+        L_ = _lib.lib() if gpu else None
+
+        def images(master, wb, wt):                      # fp32 [N, K] -> bf16 [N, K] and bf16 [K, N]
+            if not gpu:
+                wb.copy_(master); wt.copy_(wb.t()); return
+            N, K = master.shape
+            _lib.check(L_.ta_cast_f32_bf16(ptr(master), ptr(wb), master.numel(), stream()), "ta_cast_f32_bf16")
+            _lib.check(L_.ta_transpose_to_bf16(ptr(master), 1, K, 0, 0, ptr(wt), wt.shape[1], N, K, stream()), "ta_transpose_to_bf16")
         for kind, img in self.FT_KINDS:
             if not img:
                 continue
             m = getattr(self, "ft_" + kind)
             for i in range(self.config.num_hidden_layers):
-                wb = b[f"layers.{i}.{kind}"]
-                wb.copy_(m[i])
-                b[f"layers.{i}.{kind}_t"].copy_(wb.t())
+                images(m[i], b[f"layers.{i}.{kind}"], b[f"layers.{i}.{kind}_t"])
         V = self.config.vocab_size
-        b["embed_bf16"][:V].copy_(self.ft_embed)
-        b["embed_t_bf16"].copy_(b["embed_bf16"].t())
+        images(self.ft_embed, b["embed_bf16"][:V], b["embed_t_bf16"])       # rows V..vocab_pad stay zero in both images
         self._ft_versions = tuple(p._version for p in self.ft_parameters())
 
     def ft_state_dict_hf(self):
