@@ -18,6 +18,7 @@
 //   "col tiles"  [HD rows][64]   8-B granules XOR-swizzled by the row -> conflict-free ds_read_b64 halves
 //                (first version padded rows to 144 B: SQ_LDS_BANK_CONFLICT showed 30 % conflict cycles)
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/ta355.h"
 
@@ -196,10 +197,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
   RowStage<HD> ks_reg; ColStage<HD> vs_reg; int mk_reg = 1;
   ks_reg.load(Kb, lay.k_rs, 0, L, tid);
-  vs_reg.load(Vb, lay.v_rs, 0, tid, valign);
+  vs_reg.load(Vb, lay.v_rs, 0, tid, valign & 3);
   if (kmask && tid < 64) mk_reg = (tid < L) ? kmask[(long)b * L + tid] : 0;
 
-  for (int t = 0; t < ntiles; ++t) {
+  // The tile body exists twice: MASKED = false has no masking code at all (the compiler otherwise hoists the index
+  // compares of the masked path in front of the branch: ~40 VALU per tile in a VALU-bound loop), MASKED = true is the
+  // general one.  Tiles [0, nfull) are complete, unmasked and (causal) entirely below the diagonal for every query here.
+  auto tile = [&](const int t, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int key0 = t * KV_TILE;
     ks_reg.store(Ks, tid);
     vs_reg.store(Vs, tid);
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     __syncthreads();
     if (t + 1 < ntiles) {
       ks_reg.load(Kb, lay.k_rs, key0 + KV_TILE, L, tid);
-      vs_reg.load(Vb, lay.v_rs, key0 + KV_TILE, tid, valign);
+      vs_reg.load(Vb, lay.v_rs, key0 + KV_TILE, tid, valign & 3);
       if (kmask && tid < 64) { const int kk = key0 + KV_TILE + tid; mk_reg = (kk < L) ? kmask[(long)b * L + kk] : 0; }
     }
     // ---- S^T = K Q^T for both query sub-tiles
@@ -228,8 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int sub = 0; sub < QSUB; ++sub) {
       const int qrow = q0 + sub * 16 + l15;
-      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (!CAUSAL || key0 + KV_TILE - 1 <= q0 + sub * 16);
-      if (!full) {                                   // wave-uniform; selects, no per-element branches
+      if constexpr (MASKED) {                        // selects, no per-element branches
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           const int4 mk = *(const int4*)(Ms + kt * 16 + g * 4);
@@ -280,7 +284,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       }
     }
     __syncthreads();
-  }
+  };
+  int nfull = (kmask == nullptr) ? L / KV_TILE : 0;
+  if (CAUSAL) nfull = min(nfull, (qt * QROWS) / KV_TILE);      // keys of tiles below the first query row of the workgroup
+  nfull = min(nfull, ntiles);
+  if (valign & 4) nfull = 0;                                   // experiment (TA355_ATTN_NOPEEL=1): every tile takes the general body
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  for (int t = nfull; t < ntiles; ++t) tile(t, std::true_type{});
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
     const int qrow = q0 + sub * 16 + l15;
@@ -725,7 +735,8 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
   if (((lay.q_bs | lay.q_hs | lay.q_rs | lay.k_bs | lay.k_hs | lay.k_rs) & 7) || (((uintptr_t)Q | (uintptr_t)K) & 15)) return TA_ERR_ARG;
   const long vor = lay.v_bs | lay.v_hs | lay.v_rs;
   const uintptr_t vp = (uintptr_t)VT;
-  const int valign = (!(vor & 7) && !(vp & 15)) ? 0 : ((!(vor & 3) && !(vp & 7)) ? 1 : 2);
+  int valign = (!(vor & 7) && !(vp & 15)) ? 0 : ((!(vor & 3) && !(vp & 7)) ? 1 : 2);
+  { const char* e = getenv("TA355_ATTN_NOPEEL"); if (e && *e == '1') valign |= 4; }
   // encoder (hd 64, S = 500, non-causal): 128 query rows per workgroup; LM (hd 128, short causal L): 64
   const int qsub = (head_dim == 64) ? 2 : 1;
   dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64 * qsub), B * Hkv)), blk(256);
