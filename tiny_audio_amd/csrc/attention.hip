@@ -129,13 +129,10 @@ __device__ __forceinline__ bf16x8 read_colfrag(const char* tile, int row, int c0
 // ============================================================================ forward
 // cross-lane combines over the 4 lane groups (g = lane>>4) that share a query column, on the VALU (no LDS round trip):
 // permlane16_swap(x,x) leaves {own, partner(xor 16)} in the two results, permlane32_swap likewise for xor 32.
-// 3-input max as ONE instruction (fmaxf chains compile to v_max_f32 plus a canonicalising v_max x,x per operand
-// under the kernel's IEEE mode; the scores here are finite or -inf, never NaN)
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// 3-input max: the compiler fuses the two maxnum calls into one v_max3_f32.  (An inline-asm v_max3_f32 here was WRONG: the
+// hazard recognizer does not see inside asm, and once no other VALU work separated it from the QK^T MFMAs it read their
+// accumulators before the matrix pipe had written them -- a stale, smaller row maximum, i.e. run-to-run 1-ulp noise.)
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float group_max(float x) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
