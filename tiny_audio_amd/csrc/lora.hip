@@ -5,6 +5,7 @@
 //   Acat_g [64, in_g]  rows [j*r, (j+1)*r) = A of member j, remaining rows zero (64 = one GEMM K-tile)
 //   Bext_g [N_g, 64]   rows of member j carry B_j in columns [j*r, (j+1)*r), zero elsewhere
 // so the adapted linear is ONE extra K-tile of the frozen GEMM:  y = [x | xa] [W | Bext]^T  with  xa = x (s Acat)^T.
+#include <cstdlib>
 #include "common.h"
 #include "internal.h"
 
@@ -161,6 +162,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) b[cb] = *(const lbf16x8*)(wp + (long)cb * 16 * K + kk);
   }
+  // (a 4-deep ring for the X fragments measured the same 6.2 us per 1024 columns of K: the kernel is not latency-bound
+  // on its HBM stream)
   for (; kk < K; kk += STEP) {
     const int kn = kk + STEP;
     if (kn < K) {
@@ -211,7 +214,15 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
                         int r, int b0, int b1, hipStream_t st) {
   if (R > 32 || R <= 0 || ldy != 64 || Cn % 8) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  const int rows = 128;
+  // rows per workgroup: every workgroup ends with 256 x R float atomics, so fewer, longer row chunks are better as long
+  // as ~512 workgroups remain (Cn = 6144: 288 rows -> 22 x 24 workgroups and 2.1 M atomics instead of 4.7 M)
+  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
+  int rows = 128;
+  {
+    const long want = (long)M * ta_cdiv(Cn, 256) / 512;
+    if (want > rows) rows = (int)((want + 31) / 32 * 32);
+    if (rows_env > 0) rows = rows_env;
+  }
   TA_LAUNCH(lora_tn_mfma_kernel, dim3(ta_cdiv(Cn, 256), ta_cdiv(M, rows)), dim3(256), 0, st, (const bf16_t*)X, Cn, (const bf16_t*)Y,
             R, out, so_c, so_j, M, post, r, b0, b1, rows);
   TA_CHECK_LAUNCH();
