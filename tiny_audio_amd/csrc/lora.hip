@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void lora_pack_a_kernel(const float* __restric
   if (idx >= (long)64 * Cn) return;
   const int j = (int)(idx / Cn), c = (int)(idx % Cn);
   const bf16_t v = j < R ? f2bf(in[idx] * scale) : (bf16_t)0;
-  out[idx] = v;
+  out[(((long)(c >> 5) * 64 + j) << 5) + (c & 31)] = v;        // k-step-major blocks [Cn/32][64][32] (see lora_skinny_nt_kernel)
   outT[(long)c * 64 + j] = v;
 }
 // B master fp32 [N, r] -> Bext image bf16 [N, 64] (row n of member j owns columns [j*r, (j+1)*r)) and transpose [64, N]
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restric
   const int jj = j - (n < b0 ? 0 : (n < b1 ? 1 : 2)) * r;
   const bf16_t v = (jj >= 0 && jj < r) ? f2bf(in[(long)n * r + jj]) : (bf16_t)0;
   out[idx] = v;
-  outT[(long)j * N + n] = v;
+  outT[(((long)(n >> 5) * 64 + j) << 5) + (n & 31)] = v;       // [N/32][64][32]
 }
 
 // out[c*so_c + (j - jlo(c))*so_j] += post * sum_m X[m, c] * Y[m, j],  j < R <= 32;  X bf16 [M, C], Y bf16 [M, 64].
@@ -153,32 +153,48 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
   const int ra = min(m0 + i, M - 1), rb = min(m0 + 16 + i, M - 1);       // clamped rows are never stored
   const bf16_t* xa = X + (long)ra * K + g * 8;
   const bf16_t* xb = X + (long)rb * K + g * 8;
-  const bf16_t* wp = W + (long)i * K + g * 8;
-  constexpr int STEP = SK_WAVES * 32;
-  lbf16x8 a0, a1, b[4], na0, na1, nb[4];
-  int kk = wave * 32;
-  if (kk < K) {
-    a0 = *(const lbf16x8*)(xa + kk); a1 = *(const lbf16x8*)(xb + kk);
+  // W is stored in k-step-major blocks [K/32][64][32]: the four fragment loads of one k-step read 4 KB contiguously.
+  // (Row-major [64, K] put all 64 rows of a k-step K*2 bytes apart -- a multiple of 4 KB for every K of the model, i.e.
+  // on ONE L2 channel, with every workgroup asking for the same lines at the same time.)
+  const bf16_t* wp = W + (long)i * 32 + g * 8;
+  // Every workgroup walks its k-steps from a different starting point (rot): X rows are K*2 bytes apart too, so
+  // workgroups in lock step would all sit on the same two L2 channels.
+  const int nsteps = K / 32;
+  const int ns = nsteps > wave ? (nsteps - wave + SK_WAVES - 1) / SK_WAVES : 0;      // k-steps of this wave
+  const int rot = ns ? (int)((blockIdx.x * 7u) % (unsigned)ns) : 0;
+  auto kof = [&](int sidx) { int q = sidx + rot; if (q >= ns) q -= ns; return (wave + SK_WAVES * q) * 32; };
+  constexpr int PF = 3;
+  lbf16x8 xr[PF][2], wr[PF][4];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) b[cb] = *(const lbf16x8*)(wp + (long)cb * 16 * K + kk);
-  }
-  // (a 4-deep ring for the X fragments measured the same 6.2 us per 1024 columns of K: the kernel is not latency-bound
-  // on its HBM stream)
-  for (; kk < K; kk += STEP) {
-    const int kn = kk + STEP;
-    if (kn < K) {
-      na0 = *(const lbf16x8*)(xa + kn); na1 = *(const lbf16x8*)(xb + kn);
+  for (int p = 0; p < PF; ++p)
+    if (p < ns) {
+      const int kp = kof(p);
+      xr[p][0] = *(const lbf16x8*)(xa + kp); xr[p][1] = *(const lbf16x8*)(xb + kp);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) nb[cb] = *(const lbf16x8*)(wp + (long)cb * 16 * K + kn);
+      for (int cb = 0; cb < 4; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kp >> 5) * 64 + cb * 16) * 32);
     }
+  for (int s0 = 0; s0 < ns; s0 += PF) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-      acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[cb], acc[0][cb], 0, 0, 0);
-      acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[1][cb], 0, 0, 0);
+    for (int p = 0; p < PF; ++p) {
+      const int sc = s0 + p;
+      if (sc < ns) {                                 // wave-uniform
+        const lbf16x8 a0 = xr[p][0], a1 = xr[p][1];
+        lbf16x8 b[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) b[cb] = wr[p][cb];
+        if (sc + PF < ns) {                          // refill this ring slot
+          const int kf = kof(sc + PF);
+          xr[p][0] = *(const lbf16x8*)(xa + kf); xr[p][1] = *(const lbf16x8*)(xb + kf);
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kf >> 5) * 64 + cb * 16) * 32);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[cb], acc[0][cb], 0, 0, 0);
+          acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[1][cb], 0, 0, 0);
+        }
+      }
     }
-    a0 = na0; a1 = na1;
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) b[cb] = nb[cb];
   }
 #pragma unroll
   for (int rbk = 0; rbk < 2; ++rbk)
