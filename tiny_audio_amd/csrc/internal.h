@@ -4,6 +4,8 @@
 #include "common.h"
 
 // bf16 images of one adapter group: s*Acat [64,in], its transpose [in,64], Bext [N,64], its transpose [64,N]
+// a: s*Acat [64, in] and bt: Bext^T [64, N], both in k-step-major blocks [K/32][64][32] (W operands of ta_i_lora_skinny_nt);
+// at [in, 64] and b [N, 64] row-major (K extensions of the frozen GEMMs)
 struct LoraImg { bf16_t *a, *at, *b, *bt; };
 struct ta_i_lora_layer_imgs { LoraImg g[4]; };   // qkv, o, gate|up, down
 

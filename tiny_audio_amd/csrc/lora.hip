@@ -12,7 +12,8 @@
 // The fp32 MASTERS keep the exact peft parameter count: la_g [members*r, in_g] (member A's stacked on rows) and
 // lb_g [N_g, r] (member B's stacked on rows).  The 64-wide bf16 images are rebuilt from them every forward.
 
-// A master fp32 [R, in] -> s*A image bf16 [64, in] (rows >= R zero) and its transpose [in, 64]
+// A master fp32 [R, in] -> s*A image bf16 [64, in] (rows >= R zero), stored in k-step-major blocks [in/32][64][32] (the
+// skinny-NT kernel's W operand), and its plain transpose [in, 64]
 // blockIdx.y = layer: the masters and the images of consecutive layers are `in_ls` floats / `out_ls` bf16 apart
 __global__ __launch_bounds__(256) void lora_pack_a_kernel(const float* __restrict__ in, float scale, bf16_t* __restrict__ out,
                                                           bf16_t* __restrict__ outT, int R, int Cn, long in_ls, long out_ls) {
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void lora_pack_a_kernel(const float* __restric
   out[(((long)(c >> 5) * 64 + j) << 5) + (c & 31)] = v;        // k-step-major blocks [Cn/32][64][32] (see lora_skinny_nt_kernel)
   outT[(long)c * 64 + j] = v;
 }
-// B master fp32 [N, r] -> Bext image bf16 [N, 64] (row n of member j owns columns [j*r, (j+1)*r)) and transpose [64, N]
+// B master fp32 [N, r] -> Bext image bf16 [N, 64] (row n of member j owns columns [j*r, (j+1)*r)) and its transpose
+// [64, N] stored in blocks [N/32][64][32] likewise
 __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
                                                           bf16_t* __restrict__ outT, int N, int r, int b0, int b1, long in_ls,
                                                           long out_ls) {
