@@ -6,6 +6,7 @@
 //   Bext_g [N_g, 64]   rows of member j carry B_j in columns [j*r, (j+1)*r), zero elsewhere
 // so the adapted linear is ONE extra K-tile of the frozen GEMM:  y = [x | xa] [W | Bext]^T  with  xa = x (s Acat)^T.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "internal.h"
 
@@ -47,11 +48,17 @@ __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restric
 // operand).  The work is HBM-bound (X is read exactly once, arithmetic is 64 flop/byte), so the transposed reads
 // are free.  D[j, c] = sum_k Yt[j, k] X[k, c]: A operand from Y, B operand from X; lane (i, g) owns c = i,
 // j = 4g + reg of each 16x16 block.  Wave w of the block owns columns [64w, 64w+64) of the 256-column strip.
-// LDS bank mapping: rows are 512 B (X) / 128 B (Y) apart, so the four row groups g of one read would share banks; the
-// 32-B column group index is XOR-ed with g = (row >> 3) & 3 to spread them.
+// LDS bank mapping: rows are 512 B (X) / 128 B (Y) apart, so the four rows of one transposed read would share banks; the
+// 32-B column group index is XOR-ed with (row & 3) to spread them.
 // With r > 0 only the member block of column c (member boundaries b0, b1; block structure of Bext) is kept and
 // lands at j - jlo, i.e. directly in the [N, r] master layout.  grid (ceil(C/256), chunks of 128 rows); out zeroed.
 typedef __attribute__((ext_vector_type(8))) short lbf16x8;
+typedef __attribute__((ext_vector_type(4))) short lbf16x4;
+// LDS transpose read of gfx950 (semantics measured with scripts/probe/tr_probe.hip): in every group of 16 lanes, lane L
+// receives element (L & 3) of the 8-byte chunks addressed by lanes (L >> 2) + 4 j, j = 0..3.
+__device__ __forceinline__ lbf16x4 tr_read(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) lbf16x4*)p);
+}
 typedef __attribute__((ext_vector_type(4))) float lf32x4;
 
 __global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
@@ -69,52 +76,64 @@ __global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restr
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 px[4], py;
-  auto fetch = [&](int m0) {
+  // Two register stages: the tile two steps ahead is requested while the current one is multiplied (with one stage the loop
+  // ran at one memory latency per 32-row tile).
+  uint4 px[2][4], py[2];
+  auto fetch = [&](int m0, int st_) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int id = tid + q * 256, row = id >> 5, ch = id & 31;
       const int m = m0 + row, c = c0 + ch * 8;
-      px[q] = (m < m_end && c < Cn) ? *(const uint4*)(X + (long)m * Cn + c) : make_uint4(0, 0, 0, 0);
+      px[st_][q] = (m < m_end && c < Cn) ? *(const uint4*)(X + (long)m * Cn + c) : make_uint4(0, 0, 0, 0);
     }
     const int row = tid >> 3, ch = tid & 7, m = m0 + row;
-    py = m < m_end ? *(const uint4*)(Y + (long)m * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+    py[st_] = m < m_end ? *(const uint4*)(Y + (long)m * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
   };
-  auto stash = [&]() {
+  auto stash = [&](int st_) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int id = tid + q * 256, row = id >> 5, ch = id & 31;
-      const int sg = (ch >> 1) ^ ((row >> 3) & 3);
-      *(uint4*)(sx + row * 256 + sg * 16 + (ch & 1) * 8) = px[q];
+      const int sg = (ch >> 1) ^ (row & 3);
+      *(uint4*)(sx + row * 256 + sg * 16 + (ch & 1) * 8) = px[st_][q];
     }
     const int row = tid >> 3, ch = tid & 7;
-    const int sg = (ch >> 1) ^ ((row >> 3) & 3);
-    *(uint4*)(sy + row * 64 + sg * 16 + (ch & 1) * 8) = py;
+    const int sg = (ch >> 1) ^ (row & 3);
+    *(uint4*)(sy + row * 64 + sg * 16 + (ch & 1) * 8) = py[st_];
   };
-
-  fetch(m_begin);
-  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+  auto tile = [&](int m0, auto stage_tag) {
+    constexpr int S_ = decltype(stage_tag)::value;
     __syncthreads();                     // previous tile fully consumed
-    stash();
+    stash(S_);
     __syncthreads();
-    if (m0 + 32 < m_end) fetch(m0 + 32); // next tile's global loads fly while this one is multiplied
+    if (m0 + 64 < m_end) fetch(m0 + 64, S_);   // refill this stage: two tiles ahead
+    // transposed fragments with ds_read_b64_tr_b16: within a 16-lane group, lane n points at the 4-element chunk
+    // (row 8g + (n >> 2) [+4], columns 4 (n & 3) ..) of a [4 rows][16 columns] block and receives the 4 rows of column n --
+    // two reads give the 8 consecutive k of one MFMA operand (the scalar version needed 8 ds_read_u16 per operand).
+    const int trow = g * 8 + (i >> 2), tcol = (i & 3) * 4;
     lbf16x8 a[2];
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
       if (jb < jblocks) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[jb][e] = (short)sy[(g * 8 + e) * 64 + ((jb ^ g) * 16) + i];
+        const lbf16x4 lo = tr_read(sy + trow * 64 + ((jb ^ (trow & 3)) * 16) + tcol);
+        const lbf16x4 hi = tr_read(sy + (trow + 4) * 64 + ((jb ^ ((trow + 4) & 3)) * 16) + tcol);
+        a[jb] = (lbf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       const int cg = wave * 4 + cb;
-      lbf16x8 b;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) b[e] = (short)sx[(g * 8 + e) * 256 + ((cg ^ g) * 16) + i];
+      const lbf16x4 lo = tr_read(sx + trow * 256 + ((cg ^ (trow & 3)) * 16) + tcol);
+      const lbf16x4 hi = tr_read(sx + (trow + 4) * 256 + ((cg ^ ((trow + 4) & 3)) * 16) + tcol);
+      const lbf16x8 b = (lbf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb)
         if (jb < jblocks) acc[jb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jb], b, acc[jb][cb], 0, 0, 0);
     }
+  };
+  fetch(m_begin, 0);
+  if (m_begin + 32 < m_end) fetch(m_begin + 32, 1);
+  for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+    tile(m0, std::integral_constant<int, 0>{});
+    if (m0 + 32 < m_end) tile(m0 + 32, std::integral_constant<int, 1>{});
   }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
