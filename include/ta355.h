@@ -300,6 +300,7 @@ typedef struct {
   const void* residual_bf16;
   const void* swiglu_gu; void* swiglu_dgu;
   const float* rope_tab; int rope_rows;
+  int w_blocked;   /* W is given as [N/64][K/64][64][64] blocks (N % 64 == 0): each 64-row x 64-column K tile 8 KB contiguous */
 } ta_gemm_opts;
 int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
                         long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,

@@ -82,7 +82,9 @@ if only in ("all", "gemm"):
         resid_bf = out if hasres == "bf16" else None
         if hasres:
             out.zero_()
-        t = timeit(lambda: ops.gemm_nt(A, W, out=out, bias=bias, residual=resid, residual_bf16=resid_bf, act=act))
+        wb = "--wblocked" in sys.argv
+        Wx = W.view(N // 64, 64, K // 64, 64).permute(0, 2, 1, 3).contiguous() if wb else W
+        t = timeit(lambda: ops.gemm_nt(A, Wx, M, N, K, out=out, bias=bias, residual=resid, residual_bf16=resid_bf, act=act, w_blocked=wb))
         res[name_v] = round(2.0 * M * N * K / t / 1e12, 1)
         print(f"{name_v:14s} M={M:6d} N={N:6d} K={K:5d}  {t * 1e6:8.1f} us  {res[name_v]:7.1f} TF/s", flush=True)
         del A, W, out

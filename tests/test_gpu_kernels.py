@@ -627,3 +627,17 @@ def test_attention_fwd_is_deterministic():
     for _ in range(10):
         o2, _ = ops.attention_fwd(ql, kl, vlT, 192, True, 128 ** -0.5, None)
         assert torch.equal(o2, r2)
+
+
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
+def test_gemm_w_blocked(variant, monkeypatch):
+    """W handed over as [N/64][K/64][64][64] blocks (8 KB contiguous per K tile of 64 rows) == the row-major call."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    M, N, K = 700, 1280, 384
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    bias = rnd(N, seed=3)
+    Wb = W.view(N // 64, 64, K // 64, 64).permute(0, 2, 1, 3).contiguous()
+    ref = ops.gemm_nt(A, W, bias=bias, act=1)
+    out = ops.gemm_nt(A, Wb, M, N, K, bias=bias, act=1, w_blocked=True)
+    assert torch.equal(out, ref)

@@ -63,7 +63,7 @@ class LmLayer(C.Structure):
 
 class GemmOpts(C.Structure):
     _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
-                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int)]
+                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int)]
 
 
 class AttnLayout(C.Structure):

@@ -49,6 +49,7 @@ struct GemmArgs {
   const float* rope_tab; int rope_rows;
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
+  int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
 };
 
 #define BM 128
@@ -203,8 +204,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
     }
     const int gn = min(n0 + r, p.N - 1);
-    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+    w_src[i] = p.w_blocked ? (const char*)(p.W + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
+                           : (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
   }
+  const int w_step = p.w_blocked ? 8192 : BK * 2;      // bytes to the next K tile of the same rows
   char* lds_w = smem + wave * 1024;   // + buf*2*TILE + (A:0 | W:TILE) + i*4096, lane*16 added by the DMA
 
   // ---- per-lane fragment read offsets (bytes) inside a tile
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       glds16(w_src[i], base + TILE_BYTES + i * 4096);
-      w_src[i] += BK * 2;
+      w_src[i] += w_step;
     }
   };
 
@@ -351,8 +354,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int gn = min(n0 + i * 64 + lr, p.N - 1);
-    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+    w_src[i] = p.w_blocked ? (const char*)(p.W + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
+                           : (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
   }
+  const int w_step = p.w_blocked ? 8192 : BK * 2;
   char* lds_w = smem + wave * 1024;
 
   const int swz = l15 >> 1;
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto dma_a = [&](char* base, int i) { glds16(a_src[i], base + i * 8192); a_src[i] += BK * 2; };
-  auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += BK * 2; };
+  auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += w_step; };
   auto ext_switch = [&](int tile) {                 // call before staging K-tile `tile`
     if (p.A2 && tile == nkt) {
 #pragma unroll
@@ -607,7 +612,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
                                    int act, int out_bf16, int splits, float* splitk_ws,
                                    const int* a_idx, const int* seg, const int* krange, const ta_gemm_opts* opts,
                                    hipStream_t st) {
-  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
   const ta_gemm_opts& o = opts ? *opts : none;
   const void* resb = o.residual_bf16;
   if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
@@ -631,6 +636,8 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
   a.res_bf16 = resb != nullptr;
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
+  a.w_blocked = o.w_blocked ? 1 : 0;
+  if (a.w_blocked && ((N & 63) || xA2 || krange || a_idx)) return TA_ERR_ARG;
   if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64))) return TA_ERR_ARG;
   if (resb && splits > 1) return TA_ERR_ARG;
   if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;

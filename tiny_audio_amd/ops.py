@@ -34,15 +34,16 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None):
+            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None, w_blocked=False):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile);
     rope=(table f32 [rows,16,2], rows) with act=2: interleaved partial rotary embedding in the epilogue (ta355.h)."""
     _req(A, BF16); _req(W, BF16)
     opts = None
-    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None:
+    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None or w_blocked:
         from ._lib import GemmOpts
         opts = GemmOpts()
+        opts.w_blocked = int(bool(w_blocked))      # W given as [N/64][K/64][64][64] blocks (pass N and K explicitly)
         if rope is not None:
             _req(rope[0], F32)
             opts.rope_tab, opts.rope_rows = ptr(rope[0]), int(rope[1])
