@@ -214,7 +214,7 @@ class Qwen3MI355X(torch.nn.Module):
 
         def images(master, wb, wt):                      # fp32 [N, K] -> bf16 [N, K] and bf16 [K, N]
             if not gpu:
-                wb.copy_(master); wt.copy_(wb.t()); return
+                wb.copy_(master); wt[:, :master.shape[0]].copy_(wb.t()); return
             N, K = master.shape
             _lib.check(L_.ta_cast_f32_bf16(ptr(master), ptr(wb), master.numel(), stream()), "ta_cast_f32_bf16")
             _lib.check(L_.ta_transpose_to_bf16(ptr(master), 1, K, 0, 0, ptr(wt), wt.shape[1], N, K, stream()), "ta_transpose_to_bf16")
