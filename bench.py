@@ -166,9 +166,23 @@ def main():
             tms, tfl, nl = C.c_double(), C.c_double(), C.c_long()
             lib.ta_profile_gemm_collect(C.byref(tms), C.byref(tfl), C.byref(nl))
             achieved = tfl.value / (tms.value * 1e-3) / 1e12 if tms.value > 0 else 0.0
+            # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process, so the value is the one
+            # measured on THIS workload with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes over bench.py at the
+            # default configuration, FETCH x 2 per the guide's gfx950 correction: scripts/gpu_pmc.sh + summarize_pmc.py,
+            # committed as profiles/pmc_gemm_traffic_b32_mlp.json); null for any other configuration.
+            traffic, traffic_src = None, None
+            tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_gemm_traffic_b32_mlp.json")
+            default_cfg = (B == 32 and a.projector == "mlp" and not a.lora and not a.full_ft and a.proj_hidden == 1024
+                           and a.lm == "0.6b" and a.seq_len == 192)
+            if default_cfg and os.path.exists(tj):
+                with open(tj) as fh:
+                    tr = json.load(fh)
+                if abs(tr["launches"] / 2 - nl.value / 2) <= 2:            # same launch count per step as the measured run
+                    traffic = round((tr["fetch_mb_per_launch"] + tr["write_mb_per_launch"]) * 1e6)
+                    traffic_src = "profiles/pmc_gemm_traffic_b32_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
             roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all tile / epilogue variants)", "bound": "mfma",
                         "achieved": round(achieved, 1), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "launches_per_step": nl.value // 2, "avg_launch_us": round(tms.value * 1e3 / max(nl.value, 1), 2),
                         "gemm_ms_per_step": round(tms.value / 2, 3),
                         "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3),
