@@ -59,6 +59,14 @@ typedef struct {
   const void* wqk_il;
   const float* bqk_il;
   const float* bo_fold;
+  /* Optional, on top of the three above: both LayerNorms of the layer folded into the GEMMs that follow them
+   * (ta_gemm_opts.lnf_*), so that no normalised copy of the residual stream is ever written:
+   *   wqk_ln = bf16(gamma1 o wqk_il), c1_qk = row sums of wqk_ln, c2_qk = wqk_il beta1 + bqk_il          [2H]
+   *   wv_ln  = bf16(gamma1 o Wv),     c1_v  = row sums of wv_ln;  its constant Wv beta1 + b_v goes through o_proj:
+   *   bo_fold2 = bo + Wo (Wv beta1 + b_v)                                                                 [H]
+   *   w1_ln  = bf16(gamma2 o W1),     c1_1  = row sums of w1_ln,  c2_1 = W1 beta2 + b1                    [F] */
+  const void *wqk_ln, *wv_ln, *w1_ln;
+  const float *c1_qk, *c2_qk, *c1_v, *c1_1, *c2_1, *bo_fold2;
 } ta_enc_layer;
 
 typedef struct {
@@ -301,6 +309,12 @@ typedef struct {
   const void* swiglu_gu; void* swiglu_dgu;
   const float* rope_tab; int rope_rows;
   int w_blocked;   /* W is given as [N/64][K/64][64][64] blocks (N % 64 == 0): each 64-row x 64-column K tile 8 KB contiguous */
+  /* LayerNorm folded into the GEMM (nn.LayerNorm in front of a frozen linear, TF:models/glmasr/modeling_glmasr.py:249-270):
+   * A holds the un-normalised rows x, W' = gamma o W.  lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from
+   * ta_layernorm_stats, lnf_c1[j] = sum_k W'[j,k]; the bias argument carries c2 = W beta + b.
+   *   lnf_mode 1 (rows of C are tokens; act 1 or 2):        C = act(acc rstd[m] + (-mean rstd)[m] c1[n] + bias[n])
+   *   lnf_mode 2 (columns of C are tokens; act 0, bf16 out): C = acc rstd[n] + (-mean rstd)[n] c1[m] */
+  const float* lnf_stats; const float* lnf_c1; int lnf_mode;
 } ta_gemm_opts;
 int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
                         long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,
@@ -326,6 +340,8 @@ int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_bf16, float*
 int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
                         const float* dres, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
 
+/* LayerNorm statistics only: stats[row] = (rstd, -mean * rstd) of x [M, H] (f32 or bf16), for ta_gemm_opts.lnf_* */
+int ta_layernorm_stats(const void* x, int x_is_bf16, float* stats, int M, int H, float eps, hipStream_t st);
 /* d loss / d weight of an RMSNorm (y = w * x * rstd): dw_accum[h] += sum_m dy[m,h] * x[m,h] * rstd[m]; dy and x are f32 or bf16 */
 int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* rstd, float* dw_accum, int M,
                   int H, hipStream_t st);

@@ -641,3 +641,26 @@ def test_gemm_w_blocked(variant, monkeypatch):
     ref = ops.gemm_nt(A, W, bias=bias, act=1)
     out = ops.gemm_nt(A, Wb, M, N, K, bias=bias, act=1, w_blocked=True)
     assert torch.equal(out, ref)
+
+
+def test_layernorm_stats_and_folded_gemm():
+    """nn.LayerNorm folded into the GEMM behind it (ta_gemm_opts.lnf_*): rows-are-tokens (GELU epilogue) and
+    columns-are-tokens (the V^T = Wv x^T product) against LayerNorm + linear in fp32."""
+    M, H, N = 520, 1280, 384
+    x = (rnd(M, H, seed=1, scale=1.5) + 0.7).to(BF16)                       # non-zero mean: the -mean*rstd*c1 term matters
+    g, be = 1 + 0.2 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    W, b = rnd(N, H, seed=4, scale=1 / math.sqrt(H)).to(BF16), 0.1 * rnd(N, seed=5)
+    st = ops.layernorm_stats(x)
+    xf = x.float()
+    mu, var = xf.mean(-1), xf.var(-1, unbiased=False)
+    assert relerr(st[:, 0], torch.rsqrt(var + 1e-5)) < 1e-5 and relerr(st[:, 1], -mu * torch.rsqrt(var + 1e-5)) < 1e-5
+    Wg = (W.float() * g[None, :]).to(BF16)
+    c1 = Wg.float().sum(1).contiguous()
+    c2 = (W.float() @ be + b).contiguous()
+    xn = torch.nn.functional.layer_norm(xf, (H,), g, be, 1e-5)
+    ref = torch.nn.functional.gelu(xn @ W.float().T + b)
+    out = ops.gemm_nt(x, Wg, bias=c2, act=1, ln_fold=(st, c1, 1))
+    assert relerr(out, ref) < 1.5e-2, relerr(out, ref)
+    refT = (xn - be) @ W.float().T                                         # V^T form: the beta / bias constant is folded elsewhere
+    outT = ops.gemm_nt(Wg, x, out_dtype=BF16, ln_fold=(st, c1, 2))          # [N, M]
+    assert relerr(outT, refT.T) < 1.5e-2, relerr(outT, refT.T)

@@ -31,7 +31,8 @@ class Ta355Error(RuntimeError):
 # ----------------------------------------------------------------------------- structs (must mirror ta355.h)
 class EncLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo",
-                                          "w1", "b1", "w2", "b2", "wqk_il", "bqk_il", "bo_fold")]
+                                          "w1", "b1", "w2", "b2", "wqk_il", "bqk_il", "bo_fold",
+                                          "wqk_ln", "wv_ln", "w1_ln", "c1_qk", "c2_qk", "c1_v", "c1_1", "c2_1", "bo_fold2")]
 
 
 class EncoderWeights(C.Structure):
@@ -63,7 +64,8 @@ class LmLayer(C.Structure):
 
 class GemmOpts(C.Structure):
     _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
-                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int)]
+                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int),
+                ("lnf_stats", C.c_void_p), ("lnf_c1", C.c_void_p), ("lnf_mode", C.c_int)]
 
 
 class AttnLayout(C.Structure):

@@ -16,6 +16,7 @@ namespace {
 struct EncWs {
   bf16_t *x0, *x1, *xn, *qkv, *q, *k, *vt, *ao, *hf;
   float* xr;
+  float* stats;        // [M][2] LayerNorm statistics of the folded-LN path
   size_t bytes;
 };
 EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
@@ -33,6 +34,7 @@ EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
   e.vt = c.take<bf16_t>((size_t)B * H * Sp);
   e.ao = c.take<bf16_t>((size_t)M * H);
   e.hf = c.take<bf16_t>((size_t)M * w->ffn);
+  e.stats = c.take<float>((size_t)M * 2 + 8);
   e.bytes = c.total();
   return e;
 }
@@ -77,8 +79,34 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   // M % 8 == 0 (the V^T GEMM has N = ldc = M).  TA355_ENC_QKV_FUSED=0 keeps the three-kernel path.
   const char* fz = getenv("TA355_ENC_QKV_FUSED");             // read per call: the tests compare both paths
   const bool fused = !(fz && *fz == '0') && w->rope_il && (M % 8) == 0;
+  // TA355_ENC_LN_FOLD=1 (experiment, off): LayerNorms folded into the GEMMs behind them.  Measured 0.3 ms SLOWER per step
+  // (52.6 vs 52.3 ms): the two statistics passes plus the extra per-fragment loads / FMAs of three un-overlapped GEMM
+  // epilogues cost more than the two LayerNorm kernels (19 us each) they replace.
+  const char* lz = getenv("TA355_ENC_LN_FOLD");
+  const bool lnfold = lz && *lz == '1';
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_enc_layer& L = w->layers[l];
+    const bool fold = fused && lnfold && rb && L.wqk_ln && L.wv_ln && L.w1_ln && L.c1_qk && L.c2_qk && L.c1_v && L.c1_1 &&
+                      L.c2_1 && L.bo_fold2;
+    if (fold) {
+      // Both LayerNorms live in the GEMMs that follow them: only the row statistics are computed (one read of the bf16
+      // stream, 8 bytes written per row), the GEMMs read the stream itself against gamma-scaled weights.
+      RC(ta_layernorm_stats(e.xr, 1, e.stats, M, H, w->ln_eps, st));
+      ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S;
+      o.lnf_stats = e.stats; o.lnf_c1 = L.c1_qk; o.lnf_mode = 1;
+      RC(gemm_opt(e.xr, L.wqk_ln, e.qkv, M, 2 * H, H, L.c2_qk, nullptr, 2, 1, o, st));
+      bf16_t* vt = e.qkv + (size_t)M * 2 * H;
+      ta_gemm_opts ov = opts_none(); ov.lnf_stats = e.stats; ov.lnf_c1 = L.c1_v; ov.lnf_mode = 2;
+      RC(gemm_opt(L.wv_ln, e.xr, vt, H, M, H, nullptr, nullptr, 0, 1, ov, st));
+      const ta_attn_layout lay = {(long)S * 2 * H, 64, 2L * H, (long)S * 2 * H, 64, 2L * H, S, 64L * M, M};
+      RC(ta_attention_fwd_ex(e.qkv, e.qkv + H, vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, &lay, st));
+      RC(res_gemm(e.ao, L.wo, H, L.bo_fold2));
+      RC(ta_layernorm_stats(e.xr, 1, e.stats, M, H, w->ln_eps, st));
+      ta_gemm_opts o1 = opts_none(); o1.lnf_stats = e.stats; o1.lnf_c1 = L.c1_1; o1.lnf_mode = 1;
+      RC(gemm_opt(e.xr, L.w1_ln, e.hf, M, F, H, L.c2_1, nullptr, 1, 1, o1, st));
+      RC(res_gemm(e.hf, L.w2, F, L.b2));
+      continue;
+    }
     RC(ln(L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr));
     if (fused && L.wqk_il && L.bqk_il && L.bo_fold) {
       // q|k = rope(xn Wqk^T + b) straight from the GEMM epilogue (token-major [M, 2H], heads' rotary pairs interleaved),

@@ -50,6 +50,11 @@ struct GemmArgs {
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
   int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
+  // LayerNorm folded into this GEMM: A is the UN-normalised row x, W' = gamma o W, and the epilogue applies
+  //   mode 1 (rows are tokens):    v = acc * rstd[m] + (-mean rstd)[m] * c1[n]   (then bias = c2, activation, ...)
+  //   mode 2 (columns are tokens): v = acc * rstd[n] + (-mean rstd)[n] * c1[m]   (the V^T = Wv x^T product)
+  // lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from ta_layernorm_stats; lnf_c1[j] = sum_k W'[j, k]
+  const float* lnf_stats; const float* lnf_c1; int lnf_mode;
 };
 
 #define BM 128
@@ -87,6 +92,18 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     const bool in = n < p.N;
     f32x4 v = acc[j];
     if (in) {
+      if (ACT != 0 && p.lnf_mode == 1) {              // (only the GELU / rope instantiations carry the row form)
+        const float2 st = ((const float2*)p.lnf_stats)[m];
+        const float4 c = *(const float4*)(p.lnf_c1 + n);
+        v[0] = v[0] * st.x + st.y * c.x; v[1] = v[1] * st.x + st.y * c.y;
+        v[2] = v[2] * st.x + st.y * c.z; v[3] = v[3] * st.x + st.y * c.w;
+      }
+      if (ACT == 0 && OUT_BF16 && !HAS_RES && p.lnf_mode == 2) {
+        const float4 s0 = *(const float4*)(p.lnf_stats + 2 * (long)n), s1 = *(const float4*)(p.lnf_stats + 2 * (long)n + 4);
+        const float c = p.lnf_c1[m];
+        v[0] = v[0] * s0.x + s0.y * c; v[1] = v[1] * s0.z + s0.w * c;
+        v[2] = v[2] * s1.x + s1.y * c; v[3] = v[3] * s1.z + s1.w * c;
+      }
       if (p.bias) {
         const float4 b = *(const float4*)(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -612,7 +629,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
                                    int act, int out_bf16, int splits, float* splitk_ws,
                                    const int* a_idx, const int* seg, const int* krange, const ta_gemm_opts* opts,
                                    hipStream_t st) {
-  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
   const ta_gemm_opts& o = opts ? *opts : none;
   const void* resb = o.residual_bf16;
   if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
@@ -637,6 +654,12 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.res_bf16 = resb != nullptr;
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
   a.w_blocked = o.w_blocked ? 1 : 0;
+  a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
+  if (a.lnf_mode) {
+    const bool row_ok = a.lnf_mode == 1 && act != 0;
+    const bool col_ok = a.lnf_mode == 2 && act == 0 && out_bf16 && !residual && (N % 4) == 0;
+    if (!o.lnf_stats || !o.lnf_c1 || !(row_ok || col_ok) || splits > 1 || seg || a_idx) return TA_ERR_ARG;
+  }
   if (a.w_blocked && ((N & 63) || xA2 || krange || a_idx)) return TA_ERR_ARG;
   if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64))) return TA_ERR_ARG;
   if (resb && splits > 1) return TA_ERR_ARG;

@@ -338,3 +338,53 @@ extern "C" int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int 
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
+
+
+// ---------------------------------------------------------------------------- LayerNorm statistics only
+// stats[row] = (rstd, -mean * rstd): what a GEMM epilogue needs to apply the LayerNorm that was folded into its weights
+// (ta_gemm_opts.lnf_*): y = rstd * (x W'^T) - mean * rstd * c1 + c2.  Reads the row once, writes 8 bytes.
+template <int MAXV, bool IN_BF16>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const void* __restrict__ x, float* __restrict__ stats, int M, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63, nv = H >> 2;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      if (IN_BF16) {
+        const uint2 u = ((const uint2*)((const bf16_t*)x + (long)row * H))[c];
+        v[i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
+      } else {
+        v[i] = ((const float4*)((const float*)x + (long)row * H))[c];
+      }
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + cq * cq + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+  if (lane == 0) ((float2*)stats)[row] = make_float2(rstd, -mean * rstd);
+}
+
+extern "C" int ta_layernorm_stats(const void* x, int x_is_bf16, float* stats, int M, int H, float eps, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  dim3 grid(ta_cdiv(M, 4)), blk(256);
+#define LNS_CALL(V)                                                                                       \
+  if (x_is_bf16) TA_LAUNCH((ln_stats_kernel<V, true>), grid, blk, 0, st, x, stats, M, H, eps);            \
+  else TA_LAUNCH((ln_stats_kernel<V, false>), grid, blk, 0, st, x, stats, M, H, eps);
+  DISPATCH_MAXV(H, LNS_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -126,6 +127,20 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
             b[q + "wqk_il"] = b[q + "wqkv"][rows].contiguous()
             b[q + "bqk_il"] = b[q + "bqkv"][rows].contiguous()
             b[q + "bo_fold"] = (b[q + "bo"] + b[q + "wo"].float() @ b[q + "bqkv"][2 * H:]).contiguous()
+            if os.environ.get("TA355_ENC_LN_FOLD") != "1":      # experiment (measured slower): images only on request
+                continue
+            # both LayerNorms folded into the GEMMs behind them (ta355.h, ta_enc_layer.wqk_ln ...)
+            g1, be1, g2, be2 = b[q + "ln1_w"], b[q + "ln1_b"], b[q + "ln2_w"], b[q + "ln2_b"]
+            wqk, wv, w1 = b[q + "wqk_il"].float(), b[q + "wqkv"][2 * H:].float(), b[q + "w1"].float()
+            b[q + "wqk_ln"] = (wqk * g1[None, :]).to(BF16).contiguous()
+            b[q + "c1_qk"] = b[q + "wqk_ln"].float().sum(1).contiguous()
+            b[q + "c2_qk"] = (wqk @ be1 + b[q + "bqk_il"]).contiguous()
+            b[q + "wv_ln"] = (wv * g1[None, :]).to(BF16).contiguous()
+            b[q + "c1_v"] = b[q + "wv_ln"].float().sum(1).contiguous()
+            b[q + "bo_fold2"] = (b[q + "bo"] + b[q + "wo"].float() @ (wv @ be1 + b[q + "bqkv"][2 * H:])).contiguous()
+            b[q + "w1_ln"] = (w1 * g2[None, :]).to(BF16).contiguous()
+            b[q + "c1_1"] = b[q + "w1_ln"].float().sum(1).contiguous()
+            b[q + "c2_1"] = (w1 @ be2 + b[q + "b1"]).contiguous()
 
     def _finalize(self):
         c, b = self.config, self._bufs

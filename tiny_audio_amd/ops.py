@@ -34,16 +34,18 @@ def _req(t, dtype=None):
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None, w_blocked=False):
+            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None, w_blocked=False, ln_fold=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile);
     rope=(table f32 [rows,16,2], rows) with act=2: interleaved partial rotary embedding in the epilogue (ta355.h)."""
     _req(A, BF16); _req(W, BF16)
     opts = None
-    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None or w_blocked:
+    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None or w_blocked or ln_fold is not None:
         from ._lib import GemmOpts
         opts = GemmOpts()
         opts.w_blocked = int(bool(w_blocked))      # W given as [N/64][K/64][64][64] blocks (pass N and K explicitly)
+        if ln_fold is not None:                    # (stats f32 [tokens, 2], c1 f32, mode 1 = rows are tokens | 2 = columns)
+            opts.lnf_stats, opts.lnf_c1, opts.lnf_mode = ptr(ln_fold[0]), ptr(ln_fold[1]), int(ln_fold[2])
         if rope is not None:
             _req(rope[0], F32)
             opts.rope_tab, opts.rope_rows = ptr(rope[0]), int(rope[1])
@@ -178,6 +180,14 @@ def lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, B, Hq, Hkv
                                    ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), ptr(dqn), ptr(dkn), B, Hq, Hkv, L, stream()),
           "ta_lm_qkv_post_bwd")
     return dqkv
+
+
+def layernorm_stats(x, eps=1e-5):
+    """-> f32 [M, 2] = (rstd, -mean * rstd) per row of x (f32 or bf16)."""
+    M, H = x.shape
+    st = torch.empty((M, 2), device=x.device, dtype=F32)
+    check(lib().ta_layernorm_stats(ptr(x), int(x.dtype == BF16), ptr(st), M, H, eps, stream()), "ta_layernorm_stats")
+    return st
 
 
 def rmsnorm_dw(dy, x, rstd, dw):
