@@ -200,9 +200,15 @@ def _load():
         # process would end up with two HIP runtimes (ours from /opt/rocm, torch's from the wheel) and device
         # pointers / streams allocated by one would be invalid in the other (launch failures).
         import torch  # noqa: F401
-        handle = C.CDLL(SO_PATH)
+        # TA355_LIB=<path>: load another build of the same ABI (A/B of two kernel versions inside one gpurun visit)
+        handle = C.CDLL(os.environ.get("TA355_LIB") or SO_PATH)
         for name, (ret, argtypes) in parse_header().items():
-            fn = getattr(handle, name)        # AttributeError if the header declares something not exported
+            try:
+                fn = getattr(handle, name)    # AttributeError if the header declares something not exported
+            except AttributeError:
+                if os.environ.get("TA355_LIB"):   # an older build under A/B may lack the newest entry points
+                    continue
+                raise
             fn.restype = ret
             fn.argtypes = argtypes
         _LIB = handle

@@ -85,6 +85,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
                                                int m) {
+  // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
+  // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
+  // merely present behind a run-time flag.
+  constexpr bool LNF_ROW = ACT == 3 || ACT == 4, LNF_COL = ACT == 5;
+  constexpr bool SWIGLU = ACT == 6;                 // fused SwiGLU backward (ta_gemm_opts.swiglu_*), its own instantiation too
+  constexpr int BASE = ACT == 3 ? 1 : (ACT == 4 ? 2 : ((ACT == 5 || ACT == 6) ? 0 : ACT));
   uint2 o[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -92,13 +98,13 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     const bool in = n < p.N;
     f32x4 v = acc[j];
     if (in) {
-      if (ACT != 0 && p.lnf_mode == 1) {              // (only the GELU / rope instantiations carry the row form)
+      if (LNF_ROW) {
         const float2 st = ((const float2*)p.lnf_stats)[m];
         const float4 c = *(const float4*)(p.lnf_c1 + n);
         v[0] = v[0] * st.x + st.y * c.x; v[1] = v[1] * st.x + st.y * c.y;
         v[2] = v[2] * st.x + st.y * c.z; v[3] = v[3] * st.x + st.y * c.w;
       }
-      if (ACT == 0 && OUT_BF16 && !HAS_RES && p.lnf_mode == 2) {
+      if (LNF_COL) {
         const float4 s0 = *(const float4*)(p.lnf_stats + 2 * (long)n), s1 = *(const float4*)(p.lnf_stats + 2 * (long)n + 4);
         const float c = p.lnf_c1[m];
         v[0] = v[0] * s0.x + s0.y * c; v[1] = v[1] * s0.z + s0.w * c;
@@ -108,10 +114,10 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         const float4 b = *(const float4*)(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      if (ACT == 1) {
+      if (BASE == 1) {
         v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
       }
-      if (ACT == 2) {
+      if (BASE == 2) {
         const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
         if (pc < 32) {
           const float4 t = *(const float4*)(p.rope_tab + ((long)(m % p.rope_rows) * 16 + (pc >> 1)) * 2);   // c0 s0 c1 s1
@@ -131,7 +137,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         }
       }
     }
-    if (OUT_BF16 && p.sw_gu) {                                  // block-uniform
+    if (SWIGLU) {
       if (in) {
         const long go = roff * 2 + n;                            // row m of [M, 2F]: roff = m * F
         const uint2 gv = *(const uint2*)(p.sw_gu + go), uv = *(const uint2*)(p.sw_gu + go + p.N);
@@ -157,7 +163,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
-  if (OUT_BF16 && wide && !p.sw_gu) {
+  if (OUT_BF16 && wide && !SWIGLU) {
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
@@ -685,6 +691,10 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     return TA_OK;
   }
   const bool hr = residual != nullptr;
+  if (a.sw_gu) return launch_gemm<6, true, false>(a, st);                               // validated above: act 0, bf16, plain
+  if (a.lnf_mode == 2) return launch_gemm<5, true, false>(a, st);                       // validated above: act 0, bf16 out, no residual
+  if (a.lnf_mode == 1 && act == 1 && out_bf16 && !hr) return launch_gemm<3, true, false>(a, st);
+  if (a.lnf_mode == 1 && act != 2) return TA_ERR_ARG;
   if (act == 0) {
     if (out_bf16) return hr ? launch_gemm<0, true, true>(a, st) : launch_gemm<0, true, false>(a, st);
     return hr ? launch_gemm<0, false, true>(a, st) : launch_gemm<0, false, false>(a, st);
@@ -692,7 +702,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     if (out_bf16) return hr ? launch_gemm<1, true, true>(a, st) : launch_gemm<1, true, false>(a, st);
     return hr ? launch_gemm<1, false, true>(a, st) : launch_gemm<1, false, false>(a, st);
   } else if (act == 2) {
-    return launch_gemm<2, true, false>(a, st);
+    return a.lnf_mode == 1 ? launch_gemm<4, true, false>(a, st) : launch_gemm<2, true, false>(a, st);
   }
   return TA_ERR_ARG;
 }
