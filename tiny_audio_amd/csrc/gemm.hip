@@ -177,7 +177,9 @@ __device__ __forceinline__ bool epilogue_wide_ok(const GemmArgs& p) { return p.w
 
 // BMT = 128, or 96 rows per tile (waves 2x2 of 48x64): M = 6144 x N = 1024 is then 512 tiles = every resident slot of the
 // chip (two workgroups per CU) instead of 384.
-template <int ACT, bool OUT_BF16, bool HAS_RES, int BMT = 128>
+// KEXT: the K extension of ta_gemm_opts.a2/w2 (LoRA) is compiled in (its pointer switch sits in the main loop: 0.3 ms per
+// step for every GEMM when it was a run-time test)
+template <int ACT, bool OUT_BF16, bool HAS_RES, int BMT = 128, bool KEXT = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int MI = BMT / 32, WR = BMT / 2;       // 16-row fragments per wave, rows per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
   if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
-  if (p.A2) kt_end = nkt + p.K2 / BK;              // K extension (host guarantees splits == 1, no krange)
+  if (KEXT) kt_end = nkt + p.K2 / BK;              // K extension (host guarantees splits == 1, no krange)
   int Mact = p.M, rbase = 0;
   if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }   // block-uniform: before any barrier
 
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   int next_tile = kt_begin;
   auto stage = [&](int buf) {
-    if (p.A2 && next_tile == nkt) {                // switch both operands to the extension
+    if (KEXT && next_tile == nkt) {                // switch both operands to the extension
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = i * 32 + lr;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 // Hazards: every wave drains its own DMA (vmcnt 0) at the end of L(t,1), i.e. before barrier 4t+3 (group 0) /
 // 4t+4 (group 1), and the first read of tile t+1 is after barrier 4t+4; the last reads of tile t-1 (group 1's
 // L(t-1,1)) retire (lgkmcnt 0) before barrier 4t, and the first DMA into that buffer is issued after it.
-template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool PP>
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool PP, bool KEXT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   constexpr int BM2 = 256;
   constexpr int NT = BN2 / 64;                 // n-fragments per wave
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
   if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
-  if (p.A2) kt_end = nkt + p.K2 / BK;
+  if (KEXT) kt_end = nkt + p.K2 / BK;
   int Mact = p.M, rbase = 0;
   if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
 
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   auto dma_a = [&](char* base, int i) { glds16(a_src[i], base + i * 8192); a_src[i] += BK * 2; };
   auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += w_step; };
   auto ext_switch = [&](int tile) {                 // call before staging K-tile `tile`
-    if (p.A2 && tile == nkt) {
+    if (KEXT && tile == nkt) {
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + i * 64 + lr, Mact - 1)) * p.lda2 + clog * 8);
@@ -575,7 +577,19 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
     (void)hipEventRecord(r.a, st);
   }
-  if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  if (a.A2) {
+    if constexpr (ACT == 0) {                     // the K extension exists for plain linears only (LoRA)
+      if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 128, true>), dim3(grid), dim3(256), 0, st, a);
+      else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96, true>), dim3(grid), dim3(256), 0, st, a);
+      else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
+      else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
+    } else {
+      return TA_ERR_ARG;
+    }
+  }
+  else if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
