@@ -50,6 +50,7 @@ struct GemmArgs {
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
   int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
+  int a_plain, c_plain; // the row map is the identity (one batch): skips two integer divisions per row in prologue / epilogue
   // LayerNorm folded into this GEMM: A is the UN-normalised row x, W' = gamma o W, and the epilogue applies
   //   mode 1 (rows are tokens):    v = acc * rstd[m] + (-mean rstd)[m] * c1[n]   (then bias = c2, activation, ...)
   //   mode 2 (columns are tokens): v = acc * rstd[n] + (-mean rstd)[n] * c1[m]   (the V^T = Wv x^T product)
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     if (i < MI) {
       int gm = rbase + min(m0 + r, Mact - 1);
       if (p.a_idx) gm = p.a_idx[gm];
-      const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+      const long aoff = p.a_plain ? (long)gm * p.lda : (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
       a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
     }
     const int gn = min(n0 + r, p.N - 1);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int ml = m0 + wm * WR + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
-    const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
+    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
     epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m);
   }
 }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   for (int i = 0; i < NA; ++i) {
     int gm = rbase + min(m0 + i * 64 + lr, Mact - 1);
     if (p.a_idx) gm = p.a_idx[gm];
-    const long aoff = (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+    const long aoff = p.a_plain ? (long)gm * p.lda : (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
     a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
   }
 #pragma unroll
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     const int ml = m0 + wm * 128 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
-    const long roff = p.c_off + (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc;
+    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
     epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m);
   }
 }
@@ -668,6 +669,8 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.lda = lda; a.a_rpb = a_rpb > 0 ? a_rpb : M; a.a_bs = a_bs;
   a.ldc = ldc; a.c_rpb = c_rpb > 0 ? c_rpb : (seg ? 0x7fffffff : M); a.c_bs = c_bs; a.c_off = c_off;
   if (seg && a_rpb <= 0) a.a_rpb = 0x7fffffff;
+  a.a_plain = (a.a_rpb >= M && (!seg || a.a_rpb == 0x7fffffff)) ? 1 : 0;       // rows < a_rpb: quotient 0, remainder = row
+  a.c_plain = (a.c_rpb >= M && (!seg || a.c_rpb == 0x7fffffff)) ? 1 : 0;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = o.lda2;
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;

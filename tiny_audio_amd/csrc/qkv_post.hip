@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void lm_qkv_post_fwd_kernel(const bf16_t* __re
 
 // ---------------------------------------------------------------------------- LM backward
 // dQ/dK/dV head-major -> dqkv token-major [B*L, (Hq+2Hkv)*128]; same octet-per-row mapping as the forward.
+template <bool WGRAD>      // WGRAD: also accumulate the q_norm / k_norm weight gradients (trainable LM)
 __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __restrict__ dQ, const bf16_t* __restrict__ dK,
                                                               const bf16_t* __restrict__ dV, const bf16_t* __restrict__ qkv0,
                                                               const float* __restrict__ rq, const float* __restrict__ rk,
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __re
       for (int e = 0; e < 8; ++e) {
         const float dn1 = d1[e] * c[e] + d2[e] * sn[e], dn2 = d2[e] * c[e] - d1[e] * sn[e];     // RoPE^T
         x1[e] *= r; x2[e] *= r;                                                             // x-hat
-        if (live) { gw1[e] += dn1 * x1[e]; gw2[e] += dn2 * x2[e]; }                          // d loss / d norm weight
+        if (WGRAD && live) { gw1[e] += dn1 * x1[e]; gw2[e] += dn2 * x2[e]; }                 // d loss / d norm weight
         d1[e] = dn1 * w1[e]; d2[e] = dn2 * w2[e];
         dot += d1[e] * x1[e] + d2[e] * x2[e];
       }
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void lm_qkv_post_bwd_kernel(const bf16_t* __re
     }
   }
   float* dwn = sec == 0 ? dqn : (sec == 1 ? dkn : nullptr);        // block-uniform
-  if (dwn) {
+  if (WGRAD && dwn) {
     // lanes with the same j (stride 8) hold the same 16 dims: fold them, then the 4 waves through LDS, one atomic per dim
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -302,9 +303,14 @@ extern "C" int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV
                                   const float* sinT, const int* pos, void* dqkv, float* dqn_accum, float* dkn_accum,
                                   int B, int Hq, int Hkv, int L, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
-  TA_LAUNCH(lm_qkv_post_bwd_kernel, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
-                     (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos,
-                     (bf16_t*)dqkv, dqn_accum, dkn_accum, Hq, Hkv, L);
+  if (dqn_accum || dkn_accum)
+    TA_LAUNCH(lm_qkv_post_bwd_kernel<true>, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
+              (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos,
+              (bf16_t*)dqkv, dqn_accum, dkn_accum, Hq, Hkv, L);
+  else
+    TA_LAUNCH(lm_qkv_post_bwd_kernel<false>, dim3(ta_cdiv(L, 64), Hq + 2 * Hkv, B), dim3(256), 0, st, (const bf16_t*)dQ,
+              (const bf16_t*)dK, (const bf16_t*)dV, (const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos,
+              (bf16_t*)dqkv, dqn_accum, dkn_accum, Hq, Hkv, L);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
