@@ -197,6 +197,13 @@ class Qwen3MI355X(torch.nn.Module):
                     setattr(self._layers_arr[i], kind, p.data_ptr() + i * step)
             self._w.norm_w = self.ft_norm_w.data_ptr()
             self._w.embed_f32 = self.ft_embed.data_ptr()
+            # the buffer table follows the masters too (the initial copies are dropped: the embedding alone is 0.6 GB)
+            b = self._bufs
+            b["embed_f32"], b["norm_w"] = self.ft_embed.data, self.ft_norm_w.data
+            for kind in ("ln_in_w", "ln_post_w", "qn_w", "kn_w"):
+                m = getattr(self, "ft_" + kind).data
+                for i in range(self.config.num_hidden_layers):
+                    b[f"layers.{i}.{kind}"] = m[i]
             self._ft_bound = key
             self._ft_versions = None
         ver = tuple(p._version for p in ps)
@@ -368,6 +375,8 @@ class Qwen3MI355X(torch.nn.Module):
         c, b = self.config, self._bufs
         nq, nkv, hd, F = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.intermediate_size
         f = lambda t: t.detach().float().cpu().numpy()
+        if self.train_base:                       # fine-tuned: the fp32 masters, not the bf16 images
+            return {k: f(v) for k, v in self.ft_state_dict_hf().items()}
         sd = {"model.embed_tokens.weight": f(b["embed_f32"]), "model.norm.weight": f(b["norm_w"])}
         for i in range(c.num_hidden_layers):
             p, q = f"model.layers.{i}.", f"layers.{i}."
