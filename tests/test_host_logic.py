@@ -324,3 +324,57 @@ def test_split_parameter_groups():
     assert hp["language_model.lora_la_qkv"] == (1e-4, 0.01)
     tr2 = ASRTrainer(M(), TrainingArguments(learning_rate=1e-3, weight_decay=0.1))
     assert tr2.group_hparams("language_model.lora_la_qkv", True) == (1e-3, 0.1) and tr2.group_hparams("projector.weight", True) == (1e-3, 0.1)
+
+
+# ----------------------------------------------------------------------------- trainer under world_size 2 (gloo, dry-run kernels)
+def _trainer_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import weights as OW
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    _lib.DRY_RUN = True                      # every kernel launch is a marshalling-only stub: this exercises the host path
+    enc = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4)
+    lm = OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2)
+    kw = dict(use_lora=True, freeze_projector=True) if mode == "lora" else (dict(freeze_language_model=False) if mode == "fullft" else {})
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_hidden_dim=128, audio_token_id=999, **kw)
+    torch.manual_seed(0)
+    m = ASRModel(cfg, device="cpu", init="random")
+    tr = ASRTrainer(m, TrainingArguments(gradient_accumulation_steps=2), decoder_learning_rate=1e-4)
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22 + rank)      # ranks hold different token counts
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
+    m.train()
+    tr.training_step(batch)                  # micro-step 1: no collective yet
+    assert tr.global_step == 0
+    before = float(tr.flat.count_slot)
+    tr.training_step(batch)                  # micro-step 2: all-reduce of [grads | count | loss], optimizer step
+    step, cnt = tr.global_step, float(tr.flat.count_slot)
+    # the gradient values of a dry run are uninitialised memory: check the collective itself on stand-in values
+    from tiny_audio_amd.trainer import allreduce_flat
+    tr.flat.flat_g.zero_(); tr.flat.grads.fill_(float(rank + 1))
+    allreduce_flat(tr.flat.flat_g)
+    q.put((rank, step, tr.flat.n, cnt, before, float(tr.flat.grads[0]), float(tr.flat.grads[-1])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["mlp", "lora", "fullft"])
+def test_trainer_two_ranks_flat_allreduce(mode):
+    """(e) data parallel through the real ASRTrainer: gradient accumulation defers the collective to the last micro-step,
+    every trainable tensor (projector / LoRA adapters / the whole LM) travels in ONE flat buffer with the token count."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, s0, n0, c0, b0, g0a, g0b), (r1, s1, n1, c1, b1, g1a, g1b) = res
+    assert s0 == s1 == 1 and n0 == n1 and c0 == c1
+    assert c0 == 2 * 22 + 2 * 23                     # both micro-steps of both ranks: the global label-token count
+    assert b0 == 22.0 and b1 == 23.0                 # ... which was still local before the collective
+    assert g0a == g1a == g0b == g1b == 3.0           # SUM over ranks of the stand-in gradients (1 + 2), first and last element
