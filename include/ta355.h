@@ -321,6 +321,12 @@ int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int
                         int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
                         const int* krange, const ta_gemm_opts* opts, hipStream_t st);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
+/* "TN" product (contraction over the ROWS of both row-major operands): out f32 [Ny, Nx] (+)= Y[M, Ny]^T X[M, Nx] -- the
+ * weight gradient dW = dY^T X of a linear layer (full decoder fine-tuning) without transposing dY and X first.
+ * Ny, Nx multiples of 8; ws: ta_gemm_bf16_tn_ws_bytes(M, Ny, Nx) bytes of scratch (row-chunk partial sums). */
+long ta_gemm_bf16_tn_ws_bytes(int M, int Ny, int Nx);
+int ta_gemm_bf16_tn(const void* Y, const void* X, float* out, int M, int Ny, int Nx, int accumulate, void* ws, long ws_bytes,
+                    hipStream_t st);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */
 int ta_profile_gemm(int enable);

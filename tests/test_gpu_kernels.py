@@ -664,3 +664,17 @@ def test_layernorm_stats_and_folded_gemm():
     refT = (xn - be) @ W.float().T                                         # V^T form: the beta / bias constant is folded elsewhere
     outT = ops.gemm_nt(Wg, x, out_dtype=BF16, ln_fold=(st, c1, 2))          # [N, M]
     assert relerr(outT, refT.T) < 1.5e-2, relerr(outT, refT.T)
+
+
+@pytest.mark.parametrize("M,Ny,Nx", [(6144, 1024, 2048), (700, 136, 264), (95, 128, 256), (6144, 4096, 1024)])
+def test_gemm_tn(M, Ny, Nx):
+    """out (+)= Y^T X over row-major bf16 operands (the weight-gradient product): full tiles, ragged rows / columns,
+    accumulation into an existing gradient."""
+    Y, X = rnd(M, Ny, seed=1, dtype=BF16), rnd(M, Nx, seed=2, dtype=BF16)
+    ref = Y.float().T @ X.float()
+    out = ops.gemm_tn(Y, X)
+    assert relerr(out, ref) < 2e-3, relerr(out, ref)
+    base = rnd(Ny, Nx, seed=3)
+    acc = base.clone()
+    ops.gemm_tn(Y, X, out=acc, accumulate=True)
+    assert relerr(acc, base + ref) < 2e-3

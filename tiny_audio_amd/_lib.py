@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
+SOURCES = ["gemm.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
            "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "api.hip"]
 
 

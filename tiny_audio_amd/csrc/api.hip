@@ -338,7 +338,10 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
     s.tB = c.take<bf16_t>(std::max(b_rows * Kp, (size_t)d.D * Kl));
     const int shp[4][2] = {{d.NQKV, d.D}, {d.D, bq}, {2 * d.F, d.D}, {d.D, d.F}};
     size_t mx = 0;
-    for (auto& q : shp) mx = std::max(mx, (size_t)ta_gemm_splitk_ws_bytes(q[0], q[1], wgrad_splits(q[0], q[1], Kp)));
+    for (auto& q : shp) {
+      mx = std::max(mx, (size_t)ta_gemm_splitk_ws_bytes(q[0], q[1], wgrad_splits(q[0], q[1], Kp)));
+      mx = std::max(mx, (size_t)ta_gemm_bf16_tn_ws_bytes((int)d.M, q[0], q[1]));
+    }
     s.wsk = c.take<float>(mx / 4 + 4);
   }
   s.bytes = c.total();
@@ -618,8 +621,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
   // ---- weight gradients (full decoder fine-tuning): dW[N_out, K_in] += dY^T X as an NT GEMM over transposed bf16 images
   const int Kp = pad64(M);
+  // TA355_WGRAD_TN: 0 = always two transposes + the NT GEMM, 2 = always the TN kernel (csrc/gemm_tn.hip), 1 (default) = TN
+  // where it measured faster at M = 6144 (q|k|v 85 vs 93 us, o 58 vs 69; gate|up 151 vs 127 and down 88 vs 78 stay NT)
+  static const int tn_mode = [] { const char* e = getenv("TA355_WGRAD_TN"); return e && *e ? atoi(e) : 1; }();
   auto wgrad = [&](const bf16_t* dy, int n_out, const bf16_t* x, int k_in, float* dW) -> int {
     if (!dW) return TA_OK;
+    if (tn_mode == 2 || (tn_mode == 1 && n_out <= 4096 && k_in <= 2048))
+      return ta_gemm_bf16_tn(dy, x, dW, M, n_out, k_in, 1, s.wsk, ta_gemm_bf16_tn_ws_bytes(M, n_out, k_in), st);
     RC(ta_transpose_to_bf16(dy, 0, n_out, 0, 0, s.tA, Kp, M, n_out, st));
     RC(ta_transpose_to_bf16(x, 0, k_in, 0, 0, s.tB, Kp, M, k_in, st));
     return ta_gemm_bf16_nt(s.tA, s.tB, dW, n_out, k_in, Kp, Kp, 0, 0, k_in, 0, 0, 0, nullptr, dW, 0, 0,

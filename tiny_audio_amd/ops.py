@@ -75,6 +75,20 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
     return out
 
 
+def gemm_tn(Y, X, out=None, accumulate=False):
+    """out f32 [Ny, Nx] (+)= Y[M, Ny]^T @ X[M, Nx]  (bf16 operands; the weight-gradient product dW = dY^T X)."""
+    _req(Y, BF16); _req(X, BF16)
+    M, Ny = Y.shape
+    Nx = X.shape[1]
+    if out is None:
+        out = torch.zeros((Ny, Nx), device=Y.device, dtype=F32)
+        accumulate = False
+    ws = torch.empty(max(lib().ta_gemm_bf16_tn_ws_bytes(M, Ny, Nx), 16), device=Y.device, dtype=torch.uint8)
+    check(lib().ta_gemm_bf16_tn(ptr(Y), ptr(X), ptr(out), M, Ny, Nx, int(bool(accumulate)), ptr(ws), ws.numel(), stream()),
+          "ta_gemm_bf16_tn")
+    return out
+
+
 def layernorm(x, w, b, eps=1e-5, rowscale=None, out_bf16=True, out_f32=False):
     if x.dtype == BF16:
         M, H = x.shape
