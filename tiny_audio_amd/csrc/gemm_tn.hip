@@ -14,6 +14,7 @@
 // Y columns: 8 x 4 accumulator blocks), a chunk of rows per workgroup (grid.z), partial sums to f32 slabs that
 // splitk-style reduce into out.  LDS rows are 256 B (Y) / 512 B (X) apart, so the 32-byte column group index is XOR-ed
 // with (row & 3): the four rows of one transposed read land on 4 x 8 distinct banks.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -134,7 +135,8 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int nz, long s
 
 static int tn_chunks(int M, int Ny, int Nx) {
   const long tiles = (long)ta_cdiv(Nx, TN_BX) * ta_cdiv(Ny, TN_BY);
-  long z = (512 + tiles - 1) / tiles;                  // ~512 workgroups (two per CU)
+  static const long target = [] { const char* e = getenv("TA355_TN_WGS"); return e && *e ? atol(e) : 512L; }();   // experiment knob
+  long z = (target + tiles - 1) / tiles;               // ~512 workgroups (two per CU)
   const long zmax = ta_cdiv(M, 64);
   if (z > zmax) z = zmax;
   if (z < 1) z = 1;
