@@ -127,20 +127,42 @@ def hipcc_path():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 every kernel source into one shared object (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 every kernel source into one shared object (cross-compiles without a GPU).
+    Sources are compiled to objects in parallel (csrc/build/, only those older than their inputs) and then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "host_util.h"), HEADER]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "host_util.h"), HEADER]
+    deps = srcs + hdrs
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made
     # the attention kernels shuttle every score / output fragment through v_accvgpr_read/write around the softmax.
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-shared", "-fPIC", *srcs, "-o", SO_PATH]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
+            return obj, None
+        cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (None if r.returncode == 0 else r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as pool:
+        results = list(pool.map(compile_one, srcs))
+    errs = [e for _, e in results if e]
+    if errs:
+        raise Ta355Error("hipcc failed:\n" + "\n".join(errs))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _ in results], "-o", SO_PATH]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise Ta355Error("hipcc failed:\n" + r.stdout + r.stderr)
+        raise Ta355Error("hipcc link failed:\n" + r.stdout + r.stderr)
     return SO_PATH
 
 
