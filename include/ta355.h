@@ -264,11 +264,15 @@ int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad
                       long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax, int B,
                       int* n_unfinished, hipStream_t st);
 
-/* d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written; NULL = not wanted, e.g. frozen
- * projector); d_embeds optional [B*L, D]; lora_grads: host array [n_layers] (required iff w->lora_rank > 0). */
+/* loss.backward() through the LM (replaces autograd over Qwen3ForCausalLM, tiny_audio/asr_modeling.py:517-533).
+ * d_audio f32 [n_audio_rows, D] (zeroed, then rows referenced by src_row written; NULL = not wanted, e.g. frozen
+ * projector); d_embeds optional [B*L, D]; lora_grads: host array [n_layers] (required iff w->lora_rank > 0, zeroed and
+ * written); wgrads: NULL for a frozen LM, else the weight-gradient buffers of ta_lm_wgrads (w->train_base must be 1; they
+ * are ACCUMULATED into) together with ids [B, L] i64, the token ids of the forward (input-lookup share of the embedding). */
 int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask, const int* pos, int B, int L,
                    const int* label_rows, int n_label_rows, float* d_audio, long n_audio_rows, float* d_embeds,
-                   const ta_lm_lora_grads* lora_grads, const ta_lm_wgrads* wgrads, const long* ids, const void* tape, void* ws, long ws_bytes, hipStream_t st);
+                   const ta_lm_lora_grads* lora_grads, const ta_lm_wgrads* wgrads, const long* ids, const void* tape, void* ws,
+                   long ws_bytes, hipStream_t st);
 
 /* ============================================================================================
  * Primitive kernels (exported for the parity tests; also what the composites are built from)
