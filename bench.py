@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- training-step audio-seconds/second of the tiny-audio projector-training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  The driver launches the ranks itself (python -m torch.distributed.run ... bench.py
+--gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment); a plain `python bench.py --gpus N`
+re-launches itself the same way.  The line then carries `n_gpus` = N, `rccl_ranks` (counted by an actual all-reduce)
+and `allreduce.ms_exposed_per_step`.
 
 One "step" = one full optimizer step of BASELINE.json configs[1]: B synthetic 10 s / 16 kHz clips per GPU ->
 GPU log-mel -> frozen GLM-ASR encoder (32 layers) -> MLP projector (H=D=1024) -> frozen Qwen3-0.6B (28 layers,
@@ -10,7 +15,8 @@ projector (dW) -> flat gradient all-reduce (RCCL, N>1) -> global-norm clip + Ada
 ids) are resident in HBM before the timed region; random-init weights at the true shapes (no checkpoints offline).
 
 The single JSON line carries `roofline` (dominant kernel = the MFMA GEMM, timed in situ with HIP events on
-its launch stream) and, at N=1, `cpu_baseline` (the numpy oracle timed on the host cores on one clip).
+its launch stream), `logits_full` (the same step with the reference's [B, L, V] logits materialised, timed in the same
+run) and, at N=1, `cpu_baseline` (the numpy oracle timed on the host cores on one clip: median of 3 after a warm-up).
 """
 import argparse
 import json
@@ -50,6 +56,8 @@ def parse():
                     help="full decoder fine-tuning (configs/experiments/embedded.yaml): freeze_language_model=False, MLP projector "
                          "H=2048, decoder lr 1e-4; every LM weight trains (0.6 B fp32 masters, AdamW, bf16 W / W^T images rebuilt per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-logits-full", action="store_true", help="skip the extra timed leg with materialised outputs.logits")
+    ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: all-reduce synchronously on the compute stream")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -69,24 +77,49 @@ def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=307
     return conv + enc + proj_f + proj_b + 2 * lm_body + head + lm_w
 
 
+def relaunch_if_needed(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one rank per GPU under
+    torch.distributed.run (what the driver does itself) and hand its exit code back."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    n = torch.cuda.device_count()
+    if n < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} GPU(s) visible on this node")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     a = parse()
+    relaunch_if_needed(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the ta355 hot path has no CPU fallback)")
+    if world != max(a.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)            # RCCL over xGMI
-    from tiny_audio_amd import _lib
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                    # an actual collective: the number of ranks RCCL connected
+        rccl_ranks = int(probe.item())
+        if rccl_ranks != world:
+            raise SystemExit(f"RCCL all-reduce saw {rccl_ranks} ranks, expected {world}")
+    from tiny_audio_amd import _lib, ops
     from tiny_audio_amd.asr_config import ASRConfig
     from tiny_audio_amd.asr_modeling import ASRModel
     from tiny_audio_amd.asr_processing import LogMelFeatureExtractor
+    from tiny_audio_amd.synthetic import token_batch
     from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
-    from oracle import weights as OW
 
     text = dict(hidden_size=2048, intermediate_size=6144) if a.lm == "1.7b" else None
     if a.full_ft:
@@ -97,58 +130,70 @@ def main():
     model = ASRModel(cfg, device=dev, init="random", seed=0)
     model.train()
     fe = LogMelFeatureExtractor(128, dev)
+    # N > 1: the flat-gradient all-reduce is launched asynchronously and its optimizer update applied after the NEXT step's
+    # frozen-encoder forward (trainer.py), so the collective runs under ~half a step of compute
+    overlap = world > 1 and not a.sync_allreduce
     trainer = ASRTrainer(model, TrainingArguments(learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0,
                                                   warmup_steps=500, max_steps=50000, lr_scheduler_type="polynomial",
                                                   lr_scheduler_kwargs={"power": 0.5}),
-                         decoder_learning_rate=1e-4 if a.full_ft else None)
+                         decoder_learning_rate=1e-4 if a.full_ft else None, overlap_allreduce=overlap, time_allreduce=world > 1)
     B, L, V = a.batch, a.seq_len, cfg.text_config.vocab_size
     # synthetic inputs of SURVEY.md 8(d), resident in HBM: wav = 0.1 * N(0,1), 160000 samples per clip
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
     wav = 0.1 * torch.randn(B, 160000, device=dev, generator=g)
     lens = torch.full((B,), 160000, device=dev, dtype=torch.int64)
     n_audio = int(model.projector.get_output_length(500))         # 125 for the frame-stacking projectors, 102 for the QFormer
-    ids, att, lab, counts = OW.synthetic_tokens(B, n_audio, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    ids, att, lab, counts, n_lab = token_batch(B, n_audio, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
     ids_d, att_d, lab_d = (torch.from_numpy(x).to(dev) for x in (ids, att, lab))
     counts_d = torch.from_numpy(counts).to(dev)
-    from tiny_audio_amd import ops
-    rows, tg, n = ops.label_rows(lab_d)
-    n_lab = int(n.item())
-    label_meta = (rows, tg, n_lab)                                # the collator knows label positions on the host
 
-    def step():
+    def step(full_logits=False):
         feats, _mask = fe.extract(wav, lens)                      # K1 on the GPU, inside the timed step
+        # label positions: the device kernel runs inside the step; their COUNT is host knowledge of whoever built the
+        # labels (the collator builds them on the CPU), which saves the one device->host sync of the reference's path
+        rows, tg, _n = ops.label_rows(lab_d)
         batch = dict(input_ids=ids_d, input_features=feats, attention_mask=att_d, labels=lab_d,
-                     audio_token_counts=counts_d, label_meta=label_meta)
-        if a.logits == "full":
-            trainer.flat.zero_grad() if trainer._micro == 0 else None
-            out = model(**batch, num_items_in_batch=1.0, return_logits=True)
-            out.loss.backward()
-            with torch.no_grad():
-                trainer.flat.count_slot.add_(float(out.n_label_tokens)); trainer.flat.loss_slot.add_(out.loss.detach().reshape(1))
-            trainer.optimizer_step()
-        else:
-            trainer.training_step(batch)
+                     audio_token_counts=counts_d, label_meta=(rows, tg, n_lab))
+        trainer.training_step(batch, return_logits=full_logits)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(n_steps, n_warm, **kw):
+        for _ in range(n_warm):
+            step(**kw)
+        trainer.flush()
+        trainer.allreduce_exposed_ms()                            # reset the event list
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(**kw)
+        trainer.flush()                                           # every optimizer update of the K steps is inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    full = a.logits == "full"
+    dt = timed(a.steps, a.warmup, full_logits=full)
+    ar_ms = trainer.allreduce_exposed_ms() / max(a.steps, 1) if world > 1 else 0.0
     loss = trainer.last_loss()
     ms = dt / a.steps * 1e3
     value = world * B * 10.0 * a.steps / dt
+
+    # the same step with the reference's materialised outputs.logits [B, L, V] (bf16), on record beside the default line
+    logits_full = None
+    if not full and not a.no_logits_full:
+        k2 = max(1, min(a.steps, 4))
+        dt2 = timed(k2, 1, full_logits=True)
+        logits_full = {"ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(world * B * 10.0 * k2 / dt2, 1), "steps": k2,
+                       "note": "additionally writes outputs.logits [B, L, V] bf16 every step, as the reference's forward does"}
+        trainer.last_logits = None
 
     roofline = None
     if not a.no_roofline:
@@ -159,7 +204,8 @@ def main():
         if rank == 0:
             lib.ta_profile_gemm(1)
         for _ in range(2):
-            step()
+            step(full_logits=full)
+        trainer.flush()
         barrier()
         if rank == 0:
             lib.ta_profile_gemm(0)
@@ -194,11 +240,11 @@ def main():
 
     if rank == 0:
         D_, F_ = cfg.text_config.hidden_size, cfg.text_config.intermediate_size
-        gf = algorithmic_gflop_per_clip(L, V, 36, a.logits == "full", H=a.proj_hidden, D=D_, F=F_, full_ft=a.full_ft)
+        gf = algorithmic_gflop_per_clip(L, V, n_lab // B, full, H=a.proj_hidden, D=D_, F=F_, full_ft=a.full_ft)
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-               "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes)",
+               "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes; the same batch every step)",
                "config": {"workload": ("embedded.yaml: full decoder fine-tuning, MLP projector (H=%d) + every LM weight" % a.proj_hidden if a.full_ft else
                                        "configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
                                        else ("configs[1]: MLP projector (H=%d, D=%d)" % (a.proj_hidden, D_)) if a.projector == "mlp" else
@@ -206,12 +252,19 @@ def main():
                                        "MOSA projector (2 stride-2 convs, 4 dense experts of width 4096)" if a.projector == "mosa" else
                                        "configs[3]: shared+sparse MoE projector (4 experts, top-2, H=D=1024)") +
                                       " bf16, GLM-ASR-Nano encoder 32L + Qwen3-%s 28L, "
-                                      "10 s / 16 kHz clips, L=%d, 36 label tokens/clip" % (a.lm.upper(), L),
+                                      "10 s / 16 kHz clips, L=%d, %d label tokens/clip" % (a.lm.upper(), L, n_lab // B),
                           "clips_per_gpu": B, "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
                           "logits": a.logits, "audio_token_dropout": a.dropout,
                           "algorithmic_gflop_per_clip": round(gf, 1),
                           "step_tflops": round(gf * world * B / (ms * 1e-3) / 1e3, 1)},
-               "final_loss": round(loss, 4), "roofline": roofline, "cpu_baseline": cpu}
+               "final_loss": round(loss, 4),
+               "rccl_ranks": rccl_ranks,
+               "allreduce": None if world == 1 else {
+                   "ms_exposed_per_step": round(ar_ms, 4), "elements": trainer.flat.n + trainer.flat.EXTRA,
+                   "mode": "async on RCCL's stream, update applied after the next step's frozen-encoder forward" if overlap
+                           else "synchronous on the compute stream",
+                   "note": "events on the compute stream around the collective (sync) / around the wait for it (async)"},
+               "logits_full": logits_full, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -240,18 +293,19 @@ def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
     Me, H = B * 500, cfg.audio_config.hidden_size
     Ml, D, F = B * L, cfg.text_config.hidden_size, cfg.text_config.intermediate_size
     xe = torch.randn(Me, H, device=dev).to(torch.bfloat16); we, be = torch.ones(H, device=dev), torch.zeros(H, device=dev)
-    xl = torch.randn(Ml, D, device=dev); wl = torch.ones(D, device=dev)
+    xl = torch.randn(Ml, D, device=dev).to(torch.bfloat16); wl = torch.ones(D, device=dev)
     gu = torch.randn(Ml, 2 * F, device=dev).to(torch.bfloat16)
     out = {"layernorm_kernel (encoder, bf16 residual stream in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 4),
-           "rmsnorm_fwd_kernel (LM, f32 in -> bf16 out)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 6),
+           "rmsnorm_fwd_kernel (LM, bf16 residual stream in -> bf16 out: the variant the step runs)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 4 + Ml * 4),
            "swiglu_fwd_kernel (LM, bf16 gate|up -> bf16)": rate(lambda: ops.swiglu_fwd(gu, F), Ml * F * 6),
            "logmel (f32 wav -> f32 [128, 1000]; exact-f32 DFT on v_mfma_f32_16x16x4_f32: matrix-core-bound, not HBM-bound)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000), reps=5)}
     return out
 
 
-def cpu_baseline(model, cfg, L):
+def cpu_baseline(model, cfg, L, reps=3):
     """The numpy oracle (a 'port': the reference's Python cannot travel) timed on the host cores on a bounded
-    sample: ONE 10 s clip, one full-depth training step (forward + backward), fp32, same weights as the GPU model."""
+    sample: ONE 10 s clip, one full-depth training step (forward + backward), fp32, same weights as the GPU model;
+    one untimed warm-up pass, then the median of ``reps`` passes."""
     from oracle import features as OF
     from oracle import model as OM
     from oracle import weights as OW
@@ -264,16 +318,21 @@ def cpu_baseline(model, cfg, L):
     ocfg = dict(enc=ecfg, lm=lcfg, projector_type="mlp", k=4, audio_token_id=cfg.audio_token_id)
     ids, att, lab, counts = OW.synthetic_tokens(1, 125, lm.vocab_size, cfg.audio_token_id, cfg.pad_token_id,
                                                 cfg.eos_token_id, L=L)
-    t0 = time.perf_counter()
-    wav, lens = OF.pad_batch([OW.synthetic_wave(0)])
-    feats, _ = OF.log_mel(wav, lens)
-    batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
-    out = OM.asr_forward(batch, W, ocfg, training=True)
-    OM.asr_backward(out, W, ocfg)
-    dt = time.perf_counter() - t0
+    times, loss = [], 0.0
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        wav, lens = OF.pad_batch([OW.synthetic_wave(0)])
+        feats, _ = OF.log_mel(wav, lens)
+        batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
+        out = OM.asr_forward(batch, W, ocfg, training=True)
+        OM.asr_backward(out, W, ocfg)
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+        loss = float(out["loss"])
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(10.0 / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "1 clip x 1 full-depth training step (log-mel + fwd + bwd, fp32 numpy/OpenBLAS oracle), "
-                      f"{dt:.1f} s of CPU work, loss {float(out['loss']):.4f}"}
+            "sample": "1 clip x 1 full-depth training step (log-mel + fwd + bwd, fp32 numpy/OpenBLAS oracle): median of "
+                      f"{reps} passes after 1 warm-up, {dt:.1f} s each ({min(times):.1f}-{max(times):.1f}), loss {loss:.4f}"}
 
 
 if __name__ == "__main__":

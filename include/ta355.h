@@ -399,7 +399,7 @@ int ta_audio_index(const long* ids, const long* counts, int* src_row, int B, int
 int ta_embed_scatter(const long* ids, const int* src_row, const float* emb, const float* audio, float* x0,
                      void* x0_bf16, int n_rows, int D, long vocab, hipStream_t st);
 int ta_audio_grad_gather(const int* src_row, const float* dx0, float* d_audio, int n_rows, int D, hipStream_t st);
-/* input-lookup share of the embedding gradient: dembed[ids[m], :] += dx0[m, :] for every text row (src_row[m] < 0 or src_row NULL) */
+/* input-lookup share of the embedding gradient: dembed[ids[m], :] += dx0[m, :] for every text row (src_row[m] == -1 or src_row NULL) */
 int ta_embed_grad_scatter(const long* ids, const int* src_row, const float* dx0, float* dembed, int n_rows, int D, long vocab,
                           hipStream_t st);
 int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st);

@@ -294,6 +294,39 @@ def gen_asr():
          **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters()})
 
 
+def gen_train_moe():
+    """3 optimizer steps of the MoE projector with HF-Trainer loss semantics (TF:trainer.py compute_loss /
+    training_step with num_items_in_batch): the model returns sum(nll) / num_items_in_batch + aux -- the auxiliary loss
+    keeps its full weight (tiny_audio/asr_modeling.py:528-531) -- then clip_grad_norm_(1.0) + AdamW(lr 1e-3).
+    num_items_in_batch is the label-token count of the batch (one micro-batch, one rank); the auxiliary coefficient is 5x
+    the default so that a step loop which folds aux into the token-normalised sum (aux / N) cannot reproduce these numbers.
+    Unused experts: with this tiny batch an expert can receive no token in a step.  A single-process torch optimizer then
+    SKIPS that expert (grad None: no moment update); under DDP -- the configuration the build targets -- unused parameters
+    arrive as ZERO gradients and Adam keeps moving them on their momentum.  zero_grad(set_to_none=False) gives the DDP
+    behaviour in one process (the flat all-reduced gradient buffer of the build is zero-filled for unused experts)."""
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    batch = asr_batch()
+    tb = {k: t(v) for k, v in batch.items()}
+    n_lab = int((batch["labels"][:, 1:] != -100).sum())
+    model = build_asr("moe", OW.init_moe_projector(E, D, H), router_jitter_noise=0.0, router_aux_loss_coef=0.05)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.projector.parameters()], lr=1e-3, weight_decay=0.0)
+    losses, auxes, gnorms = [], [], []
+    for p in model.projector.parameters():
+        p.grad = torch.zeros_like(p)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=False)
+        out = model(**tb, num_items_in_batch=float(n_lab))
+        out.loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.projector.parameters(), 1.0)
+        opt.step()
+        losses.append(float(out.loss)); gnorms.append(float(gn)); auxes.append(float(model.projector.get_aux_loss()))
+    keep = ("norm.weight", "router.weight", "shared_expert.fc1.bias", "experts.1.fc2.weight", "experts.3.fc1.weight")
+    save("train3_moe_small.npz", losses=np.array(losses, np.float32), aux=np.array(auxes, np.float32),
+         gnorms=np.array(gnorms, np.float32), num_items=np.float32(n_lab),
+         **{"w." + k: p.detach().numpy() for k, p in model.projector.named_parameters() if k in keep})
+
+
 # ----------------------------------------------------------------------------- 6b. full decoder fine-tuning (section 8(f) rank 4)
 def gen_fullft():
     """freeze_language_model=False (configs/experiments/embedded.yaml:23): gradients of every trainable tensor after one
@@ -472,7 +505,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "fullft", "generate", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "train_moe", "fullft", "generate", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "train_moe": gen_train_moe, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

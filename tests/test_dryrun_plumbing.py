@@ -184,9 +184,15 @@ def test_full_finetune_plumbing(dry, tmp_path):
         assert p.grad is not None and p.grad.shape == p.shape, n
     tr = ASRTrainer(m, TrainingArguments(learning_rate=1e-3, weight_decay=0.1), decoder_learning_rate=1e-4)
     assert lmod.accumulate_into_grad and tr.flat.n >= sum(p.numel() for p in train.values())
+    # a decoder_* override selects the reference's own grouping (scripts/train.py:397-405), where only nn.LayerNorm and
+    # biases are exempt: Qwen3's RMSNorm scales decay there; without overrides HF's name patterns exempt them
     dec = dict(zip(tr.flat.names, tr.flat.decay))
-    assert dec["language_model.ft_wqkv"] and dec["language_model.ft_embed"] and not dec["language_model.ft_ln_in_w"] \
-        and not dec["language_model.ft_qn_w"] and not dec["language_model.ft_norm_w"]
+    assert dec["language_model.ft_wqkv"] and dec["language_model.ft_embed"] and dec["language_model.ft_ln_in_w"] \
+        and dec["language_model.ft_qn_w"] and dec["language_model.ft_norm_w"]
+    from tiny_audio_amd.trainer import decay_flags
+    dec0 = dict(zip(tr.flat.names, decay_flags(tr.flat.names, tr.flat.params, overrides=False)))
+    assert dec0["language_model.ft_wqkv"] and dec0["language_model.ft_embed"] and not dec0["language_model.ft_ln_in_w"] \
+        and not dec0["language_model.ft_qn_w"] and not dec0["language_model.ft_norm_w"]
     assert tr.group_hparams("language_model.ft_wd", True) == (1e-4, 0.1) and tr.group_hparams("projector.linear_1.weight", True) == (1e-3, 0.1)
     tr.training_step(batch)                         # masters re-homed into the flat buffer -> pointers rebound, images rebuilt
     assert lmod._w.embed_f32 == lmod.ft_embed.data_ptr() and lmod.ft_embed.data_ptr() >= tr.flat.flat_p.data_ptr()
@@ -387,3 +393,23 @@ def test_primitive_wrappers_marshal(dry):
     ops.bernoulli_keep(10, 0.9, 1, "cpu")
     ops.adamw_step(torch.zeros(8), torch.zeros(8), torch.zeros(8), torch.zeros(8), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1,
                    sqnorm=torch.zeros(1), max_norm=1.0, denom=torch.ones(1))
+
+
+def test_hub_sized_embedding_is_cut_to_the_tokenizer_vocab(dry):
+    """Hub Qwen3 checkpoints carry 151 936 embedding rows; the reference shrinks them to len(tokenizer) after adding
+    <audio> (resize_token_embeddings keeps the first rows; tiny_audio/asr_modeling.py:160-171)."""
+    from tiny_audio_amd.asr_config import LMConfig
+    from tiny_audio_amd.language_model import Qwen3MI355X
+    lm = OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=1, heads=4, kv_heads=2)
+    w = OW.init_lm(lm, 1)
+    big = dict(w)
+    extra = np.random.RandomState(0).standard_normal((266, 256)).astype(np.float32)
+    big["model.embed_tokens.weight"] = np.concatenate([w["model.embed_tokens.weight"], extra], 0)
+    m = Qwen3MI355X(LMConfig(lm), device="cpu").load_state_dict_hf(big)
+    assert m._bufs["embed_f32"].shape == (1000, 256)
+    np.testing.assert_array_equal(m._bufs["embed_f32"].numpy(), w["model.embed_tokens.weight"])
+    assert m._bufs["embed_bf16"].shape[0] == m.vocab_pad and float(m._bufs["embed_bf16"][1000:].abs().sum()) == 0.0
+    small = dict(w)
+    small["model.embed_tokens.weight"] = w["model.embed_tokens.weight"][:900]
+    with pytest.raises(ValueError):
+        Qwen3MI355X(LMConfig(lm), device="cpu").load_state_dict_hf(small)

@@ -84,14 +84,6 @@ def test_config_and_length_formulas():
         ASRConfig(audio_config=dict(hidden=1280, heads=10))                      # head_dim 128 encoder: unsupported
 
 
-def test_gather_semantics_helper(golden):
-    from tiny_audio_amd.asr_modeling import _gather_audio_embeds
-    g = golden("known_answers.npz")
-    for k in ("a", "b"):
-        out = _gather_audio_embeds(torch.from_numpy(g["emb"]), torch.from_numpy(g["counts_" + k]))
-        np.testing.assert_array_equal(out.numpy(), g["gather_" + k])
-
-
 def test_feature_tables(golden):
     from tiny_audio_amd.asr_processing import dft_tables, slaney_mel_filters
     g = golden("logmel.npz")
@@ -126,8 +118,13 @@ def test_flat_trainable_views_and_decay_groups():
     assert ft.n == sum(ft.sizes) and ft.flat_g.numel() == ft.n + 2
     assert torch.equal(m.projector.linear_1.weight, w0)
     assert m.projector.linear_1.weight.data_ptr() == ft.flat_p[ft.offsets[0]:].data_ptr()
+    # what transformers' get_decay_parameter_names returns for the reference's MLPAudioProjector (checked against the
+    # import): ".norm." matches HF's no-decay name patterns, "norm_2" matches none of them and decays
     assert dict(zip(ft.names, ft.decay)) == {"projector.linear_1.weight": True, "projector.norm.weight": False,
-                                             "projector.linear_2.weight": True, "projector.norm_2.weight": False}
+                                             "projector.linear_2.weight": True, "projector.norm_2.weight": True}
+    from tiny_audio_amd.trainer import decay_flags
+    # scripts/train.py:397-405 (any decoder_* / projector_weight_decay override): only nn.LayerNorm and biases are exempt
+    assert decay_flags(ft.names, ft.params, overrides=True) == [True, True, True, True]
     (m.projector.linear_2.weight.sum() * 2).backward()                            # autograd accumulates into the flat views
     o = ft.offsets[2]
     assert torch.all(ft.flat_g[o:o + ft.sizes[2]] == 2.0) and float(ft.flat_g[:ft.offsets[2]].abs().sum()) == 0.0
@@ -320,7 +317,7 @@ def test_split_parameter_groups():
                     decoder_weight_decay=0.01, projector_weight_decay=0.05)
     hp = {n: tr.group_hparams(n, d) for n, d in zip(tr.flat.names, tr.flat.decay)}
     assert hp["projector.weight"] == (1e-3, 0.05) and hp["projector.bias"] == (1e-3, 0.0)
-    assert hp["projector.norm.weight"] == (1e-3, 0.0)
+    assert hp["projector.norm.weight"] == (1e-3, 0.0) and hp["projector.norm.bias"] == (1e-3, 0.0)     # an nn.LayerNorm
     assert hp["language_model.lora_la_qkv"] == (1e-4, 0.01)
     tr2 = ASRTrainer(M(), TrainingArguments(learning_rate=1e-3, weight_decay=0.1))
     assert tr2.group_hparams("language_model.lora_la_qkv", True) == (1e-3, 0.1) and tr2.group_hparams("projector.weight", True) == (1e-3, 0.1)
@@ -348,6 +345,19 @@ def _trainer_worker(rank, world, port, q, mode):
     batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
                  labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
     m.train()
+    if mode == "mlp-overlap":
+        # deferred update: the collective of step n is launched asynchronously, its clip + AdamW run inside step n+1 right
+        # after the frozen encoder's forward (or in flush()); the gradient buffer is cleared only after that update
+        tr = ASRTrainer(m, TrainingArguments(gradient_accumulation_steps=1), overlap_allreduce=True)
+        tr.training_step(batch)
+        s1, pend1 = tr.global_step, tr._pending is not None
+        tr.training_step(batch)              # applies step 1 (after the encoder), launches step 2's collective
+        s2, c2 = tr.global_step, float(tr._last[1])
+        tr.flush()
+        s3, c3, pend3 = tr.global_step, float(tr._last[1]), tr._pending is not None
+        q.put((rank, s1, int(pend1), s2, c2, s3, c3 + int(pend3)))
+        dist.destroy_process_group()
+        return
     tr.training_step(batch)                  # micro-step 1: no collective yet
     assert tr.global_step == 0
     before = float(tr.flat.count_slot)
@@ -378,3 +388,59 @@ def test_trainer_two_ranks_flat_allreduce(mode):
     assert c0 == 2 * 22 + 2 * 23                     # both micro-steps of both ranks: the global label-token count
     assert b0 == 22.0 and b1 == 23.0                 # ... which was still local before the collective
     assert g0a == g1a == g0b == g1b == 3.0           # SUM over ranks of the stand-in gradients (1 + 2), first and last element
+
+
+def test_trainer_two_ranks_deferred_update():
+    """overlap_allreduce: same collective, same update order, applied one encoder-forward later (hidden under the next
+    step's frozen-encoder pass on the GPU)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, "mlp-overlap")) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, s1, pend1, s2, c2, s3, c3 in res:
+        assert (s1, pend1) == (0, 1)         # nothing applied yet, one collective in flight
+        assert (s2, c2) == (1, 45.0)         # step 1 applied inside step 2 with the GLOBAL token count 22 + 23
+        assert (s3, c3) == (2, 45.0)         # flush() applied step 2; nothing pending
+
+
+def test_bench_gpus_flag_starts_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment re-launches itself under torch.distributed.run with N
+    ranks on 127.0.0.1 (the driver's own command line); with too few GPUs it refuses instead of printing an n_gpus: 1 line."""
+    import argparse
+    import subprocess
+    import bench
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.relaunch_if_needed(argparse.Namespace(gpus=8))
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.relaunch_if_needed(argparse.Namespace(gpus=8))
+    assert "only 1 GPU" in str(e.value.code)
+    monkeypatch.setenv("WORLD_SIZE", "8")                     # under the driver's launcher: nothing to do
+    assert bench.relaunch_if_needed(argparse.Namespace(gpus=8)) is None
+    assert bench.relaunch_if_needed(argparse.Namespace(gpus=1)) is None
+
+
+def test_synthetic_batch_contract():
+    """bench.py's batch: the collator's layout (scripts/train.py:324-348) -- prompt | <audio>*n | prompt | transcript |
+    <|im_end|> | pad; only transcript + <|im_end|> carry labels; the count is known on the host."""
+    from tiny_audio_amd.synthetic import token_batch
+    from oracle import weights as OW
+    ids, att, lab, counts, n = token_batch(3, 125, 151670, 151669, 151643, 151645, L=192)
+    o_ids, o_att, o_lab, o_counts = OW.synthetic_tokens(3, 125, 151670, 151669, 151643, 151645, L=192)
+    assert np.array_equal(ids, o_ids) and np.array_equal(att, o_att) and np.array_equal(lab, o_lab) and np.array_equal(counts, o_counts)
+    assert n == 3 * 36 and (ids == 151669).sum() == 3 * 125 and (lab[att == 0] == -100).all()
+    with pytest.raises(ValueError):
+        token_batch(1, 125, 151670, 151669, 151643, 151645, L=100)

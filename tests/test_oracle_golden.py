@@ -262,6 +262,26 @@ def test_train_three_steps(golden):
         assert d.mean() < 1e-7 and d.max() < 3e-4, (k, d.mean(), d.max())
 
 
+def test_train_three_steps_moe_aux_weight(golden):
+    """Row a13 with an auxiliary loss: HF Trainer back-propagates sum(nll) / num_items_in_batch + aux -- the MoE balance /
+    z loss is NOT token-normalised.  The fixture uses a 5x auxiliary coefficient so that a
+    mis-weighted auxiliary term is visible in losses, gradient norms and router weights."""
+    g3 = golden("train3_moe_small.npz")
+    _, W, cfg, batch = _asr_setup(golden, "moe")
+    cfg = dict(cfg, router_aux_loss_coef=0.05)
+    state = {}
+    losses, gnorms = [], []
+    for _ in range(3):
+        l, gn = OM.train_step(batch, W, cfg, state, lr=1e-3, max_grad_norm=1.0, weight_decay=0.0, num_items_in_batch=float(g3["num_items"]))
+        losses.append(l); gnorms.append(gn)
+    np.testing.assert_allclose(losses, g3["losses"], rtol=2e-4)
+    np.testing.assert_allclose(gnorms, g3["gnorms"], rtol=2e-3)
+    for k in g3.files:
+        if k.startswith("w."):
+            d = np.abs(W["projector"][k[2:]] - g3[k])
+            assert d.mean() < 2e-6 and d.max() < 3e-4, (k, d.mean(), d.max())
+
+
 # ----------------------------------------------------------------------------- full decoder fine-tuning (8(f) rank 4)
 def _fullft_setup(golden):
     g, W, cfg, batch = _asr_setup(golden, "mlp")

@@ -24,8 +24,9 @@ from .projectors import PROJECTOR_CLASSES
 
 
 class CausalLMOutput:
-    def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None):
+    def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None, loss_ce=None):
         self.loss, self.logits, self.nll, self.n_label_tokens, self.aux_loss = loss, logits, nll, n_label_tokens, aux_loss
+        self.loss_ce = loss_ce                  # the LM's cross-entropy alone (loss = loss_ce + aux_loss)
 
     def __getitem__(self, k):
         return getattr(self, k)
@@ -89,18 +90,6 @@ class _ThinkGate:
         out = "" if self.inside else self.buf
         self.buf = ""
         return out
-
-
-def _gather_audio_embeds(audio_embeds: torch.Tensor, token_counts: torch.Tensor) -> torch.Tensor:
-    """Reference semantics of tiny_audio/asr_modeling.py:27-44 in plain torch (utility / tests only; the
-    training path never materialises the packed tensor: ``ta_audio_index`` maps rows directly)."""
-    _, max_len, _ = audio_embeds.shape
-    needed = int(token_counts.max().item())
-    if needed > max_len:
-        audio_embeds = torch.nn.functional.pad(audio_embeds, (0, 0, 0, needed - max_len))
-        max_len = needed
-    mask = torch.arange(max_len, device=audio_embeds.device).unsqueeze(0) < token_counts.unsqueeze(1)
-    return audio_embeds[mask]
 
 
 class ASRModel(nn.Module):
@@ -186,18 +175,23 @@ class ASRModel(nn.Module):
         self._drop_seed += 1
         return ops.bernoulli_keep(B * S, 1.0 - p, self._drop_seed, self.device_)
 
-    def _encode_audio(self, audio_features, frame_keep=None):
-        """-> projector output [B, N, llm_dim] fp32 (packing into <audio> rows happens in the LM op)."""
+    def _encode_audio(self, audio_features, frame_keep=None, after_encoder=None):
+        """-> projector output [B, N, llm_dim] fp32 (packing into <audio> rows happens in the LM op).
+        ``after_encoder``: called between the frozen encoder and the projector -- the last point of a step that has not
+        read a trainable weight yet (ASRTrainer applies a deferred optimizer update there)."""
         B, _, T = audio_features.shape
         S = self.audio_tower.output_length(T)
         keep = self._frame_keep_mask(B, S, frame_keep)
         hidden = self.audio_tower(audio_features, frame_keep=keep).last_hidden_state      # no_grad inside
+        if after_encoder is not None:
+            after_encoder()
         return self.projector(hidden)
 
     def forward(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, audio_token_counts: Optional[torch.Tensor] = None,
-                num_items_in_batch=None, return_logits: bool = True, frame_keep=None, label_meta=None, **kwargs):
+                num_items_in_batch=None, return_logits: bool = True, frame_keep=None, label_meta=None, after_encoder=None,
+                **kwargs):
         """Training/eval forward (tiny_audio/asr_modeling.py:481-533).
 
         ``num_items_in_batch``: as in HF Trainer -- loss = sum(nll) / num_items_in_batch (default: the number of
@@ -211,8 +205,10 @@ class ASRModel(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         B, L = ids.shape
         audio, src_row = None, None
+        if input_features is None and after_encoder is not None:
+            after_encoder()
         if input_features is not None:
-            y = self._encode_audio(input_features.to(dev), frame_keep)                    # [B, N, D]
+            y = self._encode_audio(input_features.to(dev), frame_keep, after_encoder)     # [B, N, D]
             N = y.shape[1]
             if audio_token_counts is None:
                 audio_token_counts = (ids == self.audio_token_id).sum(dim=-1)
@@ -235,15 +231,15 @@ class ASRModel(nn.Module):
                                                *(self.language_model.lora_parameters() or self.language_model.ft_parameters()))
         V = self.config.text_config.vocab_size
         logits = logits.reshape(B, L, -1)[:, :, :V] if return_logits else None
-        aux = None
+        aux, loss_ce = None, loss
         if labels is None:
-            loss = None
+            loss = loss_ce = None
         elif hasattr(self.projector, "get_aux_loss"):
             aux = self.projector.get_aux_loss()
             if aux is not None and aux.numel() > 0:
                 loss = loss + aux.to(loss.device)                                          # asr_modeling.py:528-531
         return CausalLMOutput(loss=loss, logits=logits, nll=nll[:n_lab] if labels is not None else None,
-                              n_label_tokens=n_lab, aux_loss=aux)
+                              n_label_tokens=n_lab, aux_loss=aux, loss_ce=loss_ce)
 
     # ------------------------------------------------------------------ checkpoints
     def save_pretrained(self, save_directory, **kwargs):

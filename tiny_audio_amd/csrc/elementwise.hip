@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void embed_grad_scatter_kernel(const long* __r
                                                                  int n_rows, int D, long vocab) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n_rows) return;
-  if (src_row && src_row[row] >= 0) return;            // an <audio> position: its embedding row was overwritten
+  if (src_row && src_row[row] != -1) return;           // an <audio> position (projector row, or the -2 zero row of a count
+                                                       // beyond the projector's length): its embedding row was overwritten
   const long id = ids[row];
   if (id < 0 || id >= vocab) return;
   for (int c = lane * 4; c < D; c += 256) {

@@ -295,7 +295,14 @@ class Qwen3MI355X(torch.nn.Module):
     def _set_embedding(self, emb):
         c, dev = self.config, self.device_
         V, D = emb.shape
-        assert V == c.vocab_size and D == c.hidden_size
+        # Hub checkpoints carry padded embedding matrices (Qwen3-0.6B / 1.7B: 151 936 rows); the reference calls
+        # resize_token_embeddings(len(tokenizer)) after adding <audio> (tiny_audio/asr_modeling.py:160-171), which keeps
+        # the FIRST vocab_size rows -- row vocab_size-1 becomes the <audio> token.  Do the same here.
+        if D != c.hidden_size or V < c.vocab_size:
+            raise ValueError(f"embed_tokens is [{V}, {D}]; the config needs at least [{c.vocab_size}, {c.hidden_size}]")
+        if V > c.vocab_size:
+            emb = emb[: c.vocab_size]
+            V = c.vocab_size
         self._bufs["embed_f32"] = emb.to(device=dev, dtype=F32).contiguous()
         eb = torch.zeros((self.vocab_pad, D), device=dev, dtype=BF16)
         eb[:V] = self._bufs["embed_f32"].to(BF16)
@@ -600,6 +607,10 @@ class FrozenLMLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_nll, _g_logits):
+        # accumulate_into_grad (full decoder fine-tuning under ASRTrainer): the kernels add the LM's weight gradients
+        # straight into the trainer's flat buffer, so d(loss) cannot be applied to them afterwards.  ASRTrainer is the only
+        # caller that sets the flag and it always back-propagates the CE with d(loss) == 1 (the auxiliary term is added
+        # outside this node, the token normalisation happens in the optimizer kernel); any other use must leave it off.
         d_audio, _, lg = ctx.lm.backward_from_ctx(ctx.c, ctx.n_audio, want_d_audio=ctx.needs_input_grad[0])
         ctx.c = None
         lora = tuple(None if g is None else g * g_loss for g in lg)[: ctx.n_lora] if lg is not None else ()

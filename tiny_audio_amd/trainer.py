@@ -14,6 +14,7 @@ torch so the N>1 logic is covered by gloo world_size-2 tests on CPU; the optimiz
 from __future__ import annotations
 
 import math
+import re
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -58,6 +59,32 @@ def lr_multiplier(step: int, args: TrainingArguments) -> float:
     raise ValueError(f"unknown lr_scheduler_type {args.lr_scheduler_type}")
 
 
+_HF_NO_DECAY = [re.compile(p) for p in (r"bias", r"layernorm", r"rmsnorm", r"(?:^|\.)norm(?:$|\.)", r"_norm(?:$|\.)")]
+
+
+def decay_flags(names, params, overrides: bool, layernorm_ids=frozenset()):
+    """Which parameters take weight decay, as the reference's two optimizer paths decide it.
+
+    No per-group override (``Trainer.create_optimizer``): every parameter decays except those inside an ``nn.LayerNorm``
+    and those whose lower-cased name matches one of HF's patterns -- bias, layernorm, rmsnorm, ``.norm.``, ``_norm.``
+    (TF:trainer.py get_decay_parameter_names).  Note ``projector.norm_2.weight`` matches none of them and decays.
+    With ``decoder_learning_rate`` / ``decoder_weight_decay`` / ``projector_weight_decay`` set (scripts/train.py:397-405):
+    ``get_parameter_names(model, ALL_LAYERNORM_LAYERS)`` minus names containing "bias" -- only nn.LayerNorm is exempt
+    there, so RMSNorm scales (the projector's LlamaRMSNorm, Qwen3's norms) DO decay.
+
+    ``layernorm_ids``: id() of parameters that live in an nn.LayerNorm module; parameters whose name carries Blip2's
+    ``LayerNorm`` attribute are treated the same.  ``p._no_decay`` marks stacked LM masters that hold RMSNorm scales
+    (their flat names here do not carry the reference's ``*_layernorm`` / ``*_norm`` names)."""
+    out = []
+    for n, p in zip(names, params):
+        is_ln = id(p) in layernorm_ids or "LayerNorm" in n
+        if overrides:
+            out.append(not (is_ln or "bias" in n))
+        else:
+            out.append(not (is_ln or getattr(p, "_no_decay", False) or any(r.search(n.lower()) for r in _HF_NO_DECAY)))
+    return out
+
+
 class FlatTrainable:
     """All trainable parameters as views of ONE fp32 buffer; gradients likewise, plus two trailing slots:
     [ ... grads ..., label_token_count, loss_sum ].  (SURVEY.md section 2a, C1 + C2 folded together.)"""
@@ -81,9 +108,7 @@ class FlatTrainable:
                 self.flat_p[o:o + s].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + s].view_as(p)
                 p.grad = self.flat_g[o:o + s].view_as(p)
-        # decay on weight matrices only; norm scales and biases get 0 (scripts/train.py:397-432)
-        self.decay = [not (n.endswith("bias") or "norm" in n.split(".")[-2:][0] or p.ndim < 2 or getattr(p, "_no_decay", False))
-                      for n, p in zip(self.names, self.params)]
+        self.decay = decay_flags(self.names, self.params, overrides=False)
 
     @property
     def grads(self):
@@ -104,30 +129,85 @@ class FlatTrainable:
                 p.grad = self.flat_g[o:o + s].view_as(p)
 
 
-def allreduce_flat(flat: torch.Tensor, group=None) -> torch.Tensor:
-    """SUM all-reduce of the flat [grads | count | loss] buffer (RCCL on GPUs, gloo in the CPU tests)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    return flat
+def _distributed(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def allreduce_flat(flat: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of the flat [grads | count | loss] buffer (RCCL on GPUs, gloo in the CPU tests).
+    ``async_op``: returns the collective's Work handle (None on a single rank) instead of waiting for it."""
+    if _distributed(group):
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work if async_op else flat
+    return None if async_op else flat
+
+
+class _StreamTimer:
+    """Sum of event-bracketed spans on the current stream (no host sync until ``total_ms`` is read)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled, self.spans = enabled and torch.cuda.is_available(), []
+
+    def __enter__(self):
+        if self.enabled:
+            self._a = torch.cuda.Event(enable_timing=True)
+            self._a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.spans.append((self._a, b))
+        return False
+
+    def total_ms(self, reset: bool = True) -> float:
+        if not self.spans:
+            return 0.0
+        self.spans[-1][1].synchronize()
+        t = sum(a.elapsed_time(b) for a, b in self.spans)
+        if reset:
+            self.spans = []
+        return t
 
 
 class ASRTrainer:
     def __init__(self, model, args: Optional[TrainingArguments] = None, group=None, decoder_learning_rate: Optional[float] = None,
-                 decoder_weight_decay: Optional[float] = None, projector_weight_decay: Optional[float] = None):
+                 decoder_weight_decay: Optional[float] = None, projector_weight_decay: Optional[float] = None,
+                 overlap_allreduce: bool = False, time_allreduce: bool = False):
         """``decoder_*`` / ``projector_weight_decay``: the split parameter groups of scripts/train.py:384-437 -- parameters
         under ``language_model.`` (the LoRA adapters in stage 2) take the decoder LR / weight decay, everything else the
         base LR and the projector weight decay; each falls back to ``args.learning_rate`` / ``args.weight_decay``; norm
-        scales and biases never decay.  The schedule multiplies both LRs alike (one LambdaLR over all groups)."""
+        scales and biases never decay.  The schedule multiplies both LRs alike (one LambdaLR over all groups).
+
+        ``overlap_allreduce``: the flat-gradient all-reduce of step n is launched asynchronously (RCCL's own stream) and
+        its optimizer update is applied inside step n+1 right after the FROZEN encoder's forward -- the only part of a step
+        that does not read trainable weights -- so the collective runs under ~half a step of compute.  Same arithmetic,
+        same order of updates; ``flush()`` applies a still-pending update (end of training, before saving / evaluating).
+        ``time_allreduce``: bracket the time the compute stream spends on / waiting for the collective with events
+        (``allreduce_exposed_ms()``)."""
         self.model, self.args, self.group = model, args or TrainingArguments(), group
         self.decoder_learning_rate, self.decoder_weight_decay = decoder_learning_rate, decoder_weight_decay
         self.projector_weight_decay = projector_weight_decay
         self.flat = FlatTrainable(list(model.named_parameters()))
+        overrides = decoder_learning_rate is not None or decoder_weight_decay is not None or projector_weight_decay is not None
+        ln_ids = frozenset(id(p) for m in model.modules() if isinstance(m, torch.nn.LayerNorm) for p in m.parameters(recurse=False))
+        self.flat.decay = decay_flags(self.flat.names, self.flat.params, overrides, ln_ids)
         lm = getattr(model, "language_model", None)
         if lm is not None and getattr(lm, "train_base", False):
             lm.accumulate_into_grad = True      # d(loss) is 1 here: weight gradients go straight into the flat buffer
         self.sqnorm = torch.zeros(1, device=self.flat.flat_p.device, dtype=torch.float32)
         self.global_step = 0
         self._micro = 0
+        self.overlap_allreduce = bool(overlap_allreduce)
+        self._pending = None                    # (work handle or None,) of the optimizer step that has not been applied yet
+        self._need_zero = True
+        self._timer = _StreamTimer(time_allreduce)
+        self._last = torch.zeros(3, device=self.flat.flat_p.device, dtype=torch.float32)   # loss sum, token count, sqnorm
+        self._aux_sum = None                    # sum of the auxiliary losses of the current optimizer step (device scalar)
+        # DDP ranks must not draw identical dropout patterns (the reference's per-process torch RNG): fold the rank in
+        if _distributed(group) and hasattr(model, "_drop_seed"):
+            model._drop_seed += 1000003 * dist.get_rank(group)
 
     def _invalidate(self):
         proj = getattr(self.model, "projector", None)
@@ -137,25 +217,87 @@ class ASRTrainer:
         if lm is not None and getattr(lm, "train_base", False):
             lm._ft_versions = None              # bf16 W / W^T images are rebuilt before the next forward
 
-    def training_step(self, batch: dict):
+    def _global_label_tokens(self, batch, n_local):
+        """Label tokens of this optimizer step over all ranks, as a device scalar (HF Trainer gathers the same number
+        before the forward when average_tokens_across_devices is on: TF:trainer.py get_batch_samples)."""
+        dev = self.flat.flat_p.device
+        cnt = torch.full((1,), float(n_local), device=dev, dtype=torch.float32)
+        if _distributed(self.group):
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+        return cnt
+
+    def training_step(self, batch: dict, num_items_in_batch=None, return_logits: bool = False):
         """One micro-batch: forward + backward of SUM-CE; optimizer step every gradient_accumulation_steps.
-        Returns the (not yet normalised) loss sum tensor of this micro-batch."""
-        if self._micro == 0:
-            self.flat.zero_grad()
-        out = self.model(**batch, num_items_in_batch=1.0, return_logits=False)
-        out.loss.backward()
+        Returns the (not yet normalised) CE sum of this micro-batch.
+
+        Auxiliary losses (MoE balance + z loss): HF Trainer back-propagates ``sum(nll) / num_items_in_batch + aux`` per
+        micro-batch -- the auxiliary term is NOT token-normalised (tiny_audio/asr_modeling.py:528-531 adds it after the
+        LM's loss).  Here every rank back-propagates the CE SUM and the optimizer divides by the global token count, so
+        the auxiliary term is back-propagated as ``aux * num_items_in_batch`` to keep its full weight.
+        ``num_items_in_batch`` (label tokens of the whole optimizer step, all ranks) is needed only then; it defaults to
+        this micro-batch's count summed over the ranks, which is exact without gradient accumulation."""
+        after_encoder = self._apply_pending if self._pending is not None else None
+        if self._pending is None and self._micro == 0 and self._need_zero:
+            self._zero()
+        out = self.model(**batch, num_items_in_batch=1.0, return_logits=return_logits,
+                         **({"after_encoder": after_encoder} if after_encoder else {}))
+        self.last_logits = out.logits           # None unless return_logits (the reference's outputs.logits [B, L, V])
+        ce = getattr(out, "loss_ce", None)
+        aux = out.aux_loss if (ce is not None and out.aux_loss is not None and out.aux_loss.numel() > 0) else None
+        if aux is not None:
+            if num_items_in_batch is None:
+                if self.args.gradient_accumulation_steps > 1:
+                    raise ValueError("a projector with an auxiliary loss under gradient accumulation needs num_items_in_batch "
+                                     "(label tokens of the whole optimizer step over all ranks)")
+                num_items_in_batch = self._global_label_tokens(batch, out.n_label_tokens)
+            n = num_items_in_batch if torch.is_tensor(num_items_in_batch) else float(num_items_in_batch)
+            (ce + aux.to(ce.device) * n).backward()
+            with torch.no_grad():
+                self._aux_sum = aux.detach().clone() if self._aux_sum is None else self._aux_sum + aux.detach()
+        else:
+            ce = out.loss if ce is None else ce
+            ce.backward()
         with torch.no_grad():
             self.flat.count_slot.add_(float(out.n_label_tokens))
-            self.flat.loss_slot.add_(out.loss.detach().reshape(1))
+            self.flat.loss_slot.add_(ce.detach().reshape(1))
         self._micro += 1
         if self._micro == self.args.gradient_accumulation_steps:
             self.optimizer_step()
             self._micro = 0
-        return out.loss.detach()
+        return ce.detach()
+
+    def _zero(self):
+        self.flat.zero_grad()
+        self._aux_sum = None
+        self._need_zero = False
 
     def optimizer_step(self):
+        """All-reduce [grads | token count | loss sum] and apply clip + AdamW -- at once, or (overlap_allreduce) launch
+        the collective now and apply the update inside the next training_step / flush()."""
+        f = self.flat
+        if self.overlap_allreduce:
+            self._pending = (allreduce_flat(f.flat_g, self.group, async_op=True),)
+            return
+        with self._timer:
+            allreduce_flat(f.flat_g, self.group)                  # grads, token count and loss sum in one collective
+        self._apply_update()
+
+    def _apply_pending(self):
+        if self._pending is None:
+            return
+        (work,) = self._pending
+        self._pending = None
+        with self._timer:
+            if work is not None:
+                work.wait()                                       # the compute stream waits for the collective here
+        self._apply_update()
+
+    def flush(self):
+        """Apply an optimizer step whose all-reduce is still in flight (overlap_allreduce)."""
+        self._apply_pending()
+
+    def _apply_update(self):
         a, f = self.args, self.flat
-        allreduce_flat(f.flat_g, self.group)                      # grads, token count and loss sum in one collective
         self.global_step += 1
         self.sqnorm.zero_()
         ops.grad_sqnorm(f.grads, self.sqnorm)
@@ -165,7 +307,14 @@ class ASRTrainer:
             ops.adamw_step(f.flat_p[o:o + s], f.flat_g[o:o + s], f.flat_m[o:o + s], f.flat_v[o:o + s], lr_p * mult,
                            a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd_p, self.global_step,
                            sqnorm=self.sqnorm, max_norm=a.max_grad_norm, grad_scale=1.0, denom=f.count_slot)
+        with torch.no_grad():
+            self._last.copy_(torch.cat([f.loss_slot, f.count_slot, self.sqnorm]))
+        self._last_aux = self._aux_sum
         self._invalidate()
+        if self.overlap_allreduce:
+            self._zero()                        # the next backward accumulates into a clean buffer
+        else:
+            self._need_zero = True
 
     def group_hparams(self, name: str, decays: bool):
         """(base lr, weight decay) of one parameter: scripts/train.py:406-432."""
@@ -179,10 +328,19 @@ class ASRTrainer:
         return lr, (wd if decays else 0.0)
 
     def last_loss(self) -> float:
-        """Global mean loss of the last optimizer step (one host sync; for logging)."""
-        f = self.flat
-        return float((f.loss_slot / f.count_slot.clamp(min=1)).item())
+        """Global mean CE of the last APPLIED optimizer step (one host sync; for logging).  Auxiliary losses are not
+        included (``last_aux``)."""
+        return float((self._last[0] / self._last[1].clamp(min=1)).item())
+
+    def last_aux(self) -> float:
+        """Sum of the auxiliary losses over the micro-batches of the last applied optimizer step (this rank)."""
+        aux = getattr(self, "_last_aux", None)
+        return 0.0 if aux is None else float(aux.item())
 
     def last_grad_norm(self) -> float:
-        f = self.flat
-        return float((self.sqnorm.sqrt() / f.count_slot.clamp(min=1)).item())
+        return float((self._last[2].sqrt() / self._last[1].clamp(min=1)).item())
+
+    def allreduce_exposed_ms(self, reset: bool = True) -> float:
+        """Milliseconds the compute stream spent inside (synchronous mode) or waiting for (overlap mode) the gradient
+        all-reduce since the last call; needs ``time_allreduce=True``."""
+        return self._timer.total_ms(reset)
