@@ -138,6 +138,12 @@ int ta_moe_projector_backward(const ta_moe_weights* w, const void* x_bf16, int B
                               const float* noise, int training, const void* tape, float* d_norm_w, float* d_router_w,
                               float* const* dW1, float* const* db1, float* const* dW2, float* const* db2, void* ws,
                               long ws_bytes, hipStream_t st);
+/* The same with the upstream gradient of the auxiliary loss read from DEVICE memory (d_aux_dev: one f32): the autograd
+ * engine hands it over as a device scalar, and reading it on the host would stall the launch queue once per step. */
+int ta_moe_projector_backward_dev(const ta_moe_weights* w, const void* x_bf16, int B, int S, const float* dy,
+                                  const float* d_aux_dev, const float* noise, int training, const void* tape,
+                                  float* d_norm_w, float* d_router_w, float* const* dW1, float* const* db1,
+                                  float* const* dW2, float* const* db2, void* ws, long ws_bytes, hipStream_t st);
 
 /* ---- frozen Qwen3 LM + shifted CE: replaces model.language_model(inputs_embeds=, attention_mask=, labels=)
  *      together with the embed/masked_scatter glue of ASRModel.forward

@@ -89,7 +89,7 @@ def test_moe_plumbing(dry):
     out.loss.backward()
     for n, p in m.projector.named_parameters():
         assert p.grad is not None and p.grad.shape == p.shape, n
-    assert "ta_moe_projector_forward" in dry.calls and "ta_moe_projector_backward" in dry.calls
+    assert "ta_moe_projector_forward" in dry.calls and "ta_moe_projector_backward_dev" in dry.calls
 
 
 def test_lora_stage2_plumbing(dry):

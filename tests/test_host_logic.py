@@ -444,3 +444,39 @@ def test_synthetic_batch_contract():
     assert n == 3 * 36 and (ids == 151669).sum() == 3 * 125 and (lab[att == 0] == -100).all()
     with pytest.raises(ValueError):
         token_batch(1, 125, 151670, 151669, 151643, 151645, L=100)
+
+
+def test_torch_library_operators_are_registered():
+    """north_star: the composites are PyTorch custom ops -- torch.ops.ta355.* with schemas, fake (meta) kernels and autograd."""
+    from tiny_audio_amd import torch_ops
+    for name in torch_ops.OPERATORS:
+        op = getattr(torch.ops.ta355, name)
+        schema = str(op.default._schema)
+        assert schema.startswith(f"ta355::{name}("), schema
+    s = str(torch.ops.ta355.lm_forward_loss.default._schema)
+    assert "Tensor audio" in s and "Tensor[] trainable" in s and "SymInt handle" in s and "Tensor? src_row" in s
+    assert "-> (Tensor, Tensor, Tensor, Tensor, Tensor)" in s
+    s = str(torch.ops.ta355.mlp_projector.default._schema)
+    assert "Tensor x, Tensor w1, Tensor g1, Tensor w2, Tensor g2, SymInt handle" in s
+    # shapes without a GPU: the fake kernels
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from tiny_audio_amd.asr_config import ASRConfig as Cfg
+    from tiny_audio_amd.projectors import MLPAudioProjector
+    proj = MLPAudioProjector(Cfg())
+    h = torch_ops.register_module(proj)
+    assert torch_ops.register_module(proj) == h and torch_ops.module_of(h) is proj
+    with FakeTensorMode():
+        x = torch.empty(2, 500, 1280, dtype=torch.bfloat16)
+        y, xb, tape = torch.ops.ta355.mlp_projector(x, torch.empty(1024, 5120), torch.empty(1024), torch.empty(1024, 1024),
+                                                    torch.empty(1024), h)
+        assert y.shape == (2, 125, 1024) and y.dtype == torch.float32 and xb.shape == x.shape
+    with pytest.raises(Exception):
+        torch_ops.module_of(10 ** 9)
+
+
+def test_model_output_is_trainer_compatible():
+    from tiny_audio_amd.asr_modeling import CausalLMOutput
+    o = CausalLMOutput(loss=torch.tensor(1.5), logits=None, n_label_tokens=3)
+    assert isinstance(o, dict) and o["loss"] is o.loss is o[0] and o.n_label_tokens == 3 and o.logits is None
+    with pytest.raises(AttributeError):
+        o.nope

@@ -23,13 +23,27 @@ from .ops import F32
 from .projectors import PROJECTOR_CLASSES
 
 
-class CausalLMOutput:
+class CausalLMOutput(dict):
+    """What ``ASRModel.forward`` returns: attribute access (``out.loss``), key access (``out["loss"]``) and positional access
+    (``out[0]`` = the first field that is not None) like transformers' ``CausalLMOutputWithPast``, which HF
+    ``Trainer.compute_loss`` relies on (TF:trainer.py: ``outputs["loss"] if isinstance(outputs, dict) else outputs[0]``)."""
+
+    _order = ("loss", "logits", "nll", "n_label_tokens", "aux_loss", "loss_ce")
+
     def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None, loss_ce=None):
-        self.loss, self.logits, self.nll, self.n_label_tokens, self.aux_loss = loss, logits, nll, n_label_tokens, aux_loss
-        self.loss_ce = loss_ce                  # the LM's cross-entropy alone (loss = loss_ce + aux_loss)
+        # loss_ce: the LM's cross-entropy alone (loss = loss_ce + aux_loss)
+        super().__init__(loss=loss, logits=logits, nll=nll, n_label_tokens=n_label_tokens, aux_loss=aux_loss, loss_ce=loss_ce)
+
+    def __getattr__(self, k):
+        try:
+            return dict.__getitem__(self, k)
+        except KeyError:
+            raise AttributeError(k) from None
 
     def __getitem__(self, k):
-        return getattr(self, k)
+        if isinstance(k, int):
+            return [dict.__getitem__(self, n) for n in self._order if dict.__getitem__(self, n) is not None][k]
+        return dict.__getitem__(self, k)
 
 
 def _is_cjk(ch: str) -> bool:
@@ -118,6 +132,12 @@ class ASRModel(nn.Module):
             self.projector.requires_grad_(False)
         self._drop_seed = 0x5EED + seed
         self.tokenizer = kwargs.get("tokenizer")        # optional: only needed when generate() must build the prompt
+        if self.tokenizer is not None and hasattr(self.tokenizer, "convert_tokens_to_ids"):
+            # the reference reads the placeholder's id from the tokenizer (tiny_audio/asr_modeling.py:160-171), config.json
+            # does not carry it
+            tid = self.tokenizer.convert_tokens_to_ids("<audio>")
+            if tid is not None and int(tid) >= 0:
+                self.audio_token_id = config.audio_token_id = int(tid)
         self.system_prompt = getattr(config, "system_prompt", None)
 
     def _setup_lora(self, config, seed=0):

@@ -69,7 +69,12 @@ class LogMelFeatureExtractor:
         self._mel = torch.from_numpy(slaney_mel_filters(feature_size)).to(self.device)
 
     def extract(self, wav: torch.Tensor, lens: torch.Tensor):
-        """wav [B, Ls] f32 (zero padded, device), lens [B] int64 -> (features [B, n_mels, T], mask [B, T] int32)."""
+        """wav [B, Ls] f32 (zero padded, device), lens [B] int64 -> (features [B, n_mels, T], mask [B, T] int32);
+        torch.ops.ta355.logmel."""
+        from . import torch_ops
+        return torch.ops.ta355.logmel(wav, lens, torch_ops.register_module(self))
+
+    def _extract(self, wav: torch.Tensor, lens: torch.Tensor):
         B, Ls = wav.shape
         T = Ls // HOP
         feats = torch.empty((B, self.feature_size, T), device=self.device, dtype=F32)

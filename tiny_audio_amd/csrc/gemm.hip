@@ -56,6 +56,7 @@ struct GemmArgs {
   //   mode 2 (columns are tokens): v = acc * rstd[n] + (-mean rstd)[n] * c1[m]   (the V^T = Wv x^T product)
   // lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from ta_layernorm_stats; lnf_c1[j] = sum_k W'[j, k]
   const float* lnf_stats; const float* lnf_c1; int lnf_mode;
+  int dbg;             // experiments only (TA355_GEMM_DEBUG): bit 0 = no epilogue stores, bit 1 = contract over ONE K tile only
 };
 
 #define BM 128
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
   if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;
+  if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
   int Mact = p.M, rbase = 0;
   if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
 
@@ -511,6 +513,176 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   }
 }
 
+
+// ============================================================================ v3: ping-pong over a 4-slot ring of 32-deep half K-tiles
+// Same tile (256 x BN2), same wave layout, same two wave groups one barrier interval apart as the PP form of v2 -- but
+// the staging unit is a HALF K-tile (32 columns: exactly one MFMA k-step) in a ring of 4 slots, and the DMA waits are
+// counted: half-tile h+3 is issued during L(h) and only has to have landed by the end of L(h+2), i.e. every DMA has
+// 4-5 barrier intervals (~2 us) to arrive instead of 2.5 (the 2-slot v2 drains vmcnt to 0 once per K-tile).  The step's
+// K = 1024-1280 GEMMs run on operands that come from HBM / the infinity cache, where the DMA latency is what v2 waits on.
+//   barrier interval        2h           2h+1          2h+2          2h+3
+//   group 0 (waves 0-3)     L(h)         C(h)          L(h+1)        C(h+1)          L(h): ds_read slot h&3, issue DMA(h+3),
+//   group 1 (waves 4-7)     C(h-1)       L(h)          C(h)          L(h+1)                wait until DMA(h+1) has landed
+// LDS image of a slot: rows of 64 B.  One DMA wave instruction covers 16 rows (lane -> row lane>>2, chunk lane&3), one
+// fragment ds_read_b128 covers the same 16 rows (lane -> row l15, k-chunk g).  The 16-lane groups of ds_read_b128 are
+// {0-3, 12-15, 20-27}, ...: conflict-free needs chunk' = chunk ^ m(row>>2) with m = (0, 2, 3, 1) -- applied to the DMA's
+// SOURCE chunk and to the read address (the LDS destination of the DMA is lane-linear by construction).
+// Hazards.  RAW: each wave's share of DMA(h+1) is waited for (counted vmcnt) before the barrier that ends ITS L(h); the
+// first read of slot (h+1)&3 is group 0's L(h+1), two barriers (group 0's own share) resp. one barrier (group 1's share)
+// later.  WAR: DMA(h+3) overwrites the slot of half-tile h-1, whose last reads (group 1's L(h-1), interval 2h-1) retired
+// (lgkmcnt 0) before barrier 2h; the earliest issue is group 0's L(h), after that barrier.
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+template <int C1> __device__ __forceinline__ void wait_groups(int rem) {     // rem DMA groups of C1 instructions may stay in flight
+  if (rem >= 2) wait_vm_lgkm0<2 * C1>();
+  else if (rem == 1) wait_vm_lgkm0<C1>();
+  else wait_vm_lgkm0<0>();
+}
+
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool KEXT = false>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
+  constexpr int BM2 = 256;
+  constexpr int NT = BN2 / 64;
+  constexpr int A_BYTES = BM2 * 64, SLOT = (BM2 + BN2) * 64;   // one half-tile stage: (256 + BN2) rows x 32 bf16
+  constexpr int NWB = BN2 / 16;                                // 16-row DMA blocks of W per half-tile (A: 16)
+  constexpr int CW0 = NWB > 16 ? 3 : 2;                        // W blocks issued by a wave of group 0 (group 1: 2)
+  __shared__ __attribute__((aligned(16))) char smem[4 * SLOT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  int t = bid - z * tiles;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  const int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int m0 = pm * BM2, n0 = pn * BN2;
+
+  const int nkt = p.K / BK;
+  int kt_begin = (int)(((long)nkt * z) / p.splits);
+  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (KEXT) kt_end = nkt + p.K2 / BK;
+  if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
+  int Mact = p.M, rbase = 0;
+  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
+
+  // ---- DMA sources: wave w stages A blocks w, w+8 and W blocks w, w+8 (, w+16)
+  const int drow = lane >> 2;
+  const int dchk = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);      // m = (0, 2, 3, 1)
+  const char* a_src[2];
+  const char* w_src[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int gm = rbase + min(m0 + (wave + 8 * i) * 16 + drow, Mact - 1);
+    if (p.a_idx) gm = p.a_idx[gm];
+    const long aoff = p.a_plain ? (long)gm * p.lda : (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+    a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + dchk * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int gn = min(n0 + (wave + 8 * i) * 16 + drow, p.N - 1);
+    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + dchk * 8);
+  }
+  const int lag = __builtin_amdgcn_readfirstlane(wm);       // SGPR: group 1 runs one barrier interval behind
+  char* lds_w = smem + wave * 1024;
+
+  const int rd = l15 * 64 + ((g ^ ((0x78 >> (2 * ((l15 >> 2) & 3))) & 3)) << 4);
+  const int a_rd = (wm * 128) * 64 + rd;
+  const int b_rd = A_BYTES + (wn * (BN2 / 4)) * 64 + rd;
+
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nh = 2 * (kt_end - kt_begin);
+  const int ext_at = KEXT ? 2 * (nkt - kt_begin) : -1;      // first half-tile of the K extension
+  auto issue = [&](int hh) {
+    if (KEXT && hh == ext_at) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a_src[i] = (const char*)(p.A2 + (long)(rbase + min(m0 + (wave + 8 * i) * 16 + drow, Mact - 1)) * p.lda2 + dchk * 8);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        w_src[i] = (const char*)(p.W2 + (long)min(n0 + (wave + 8 * i) * 16 + drow, p.N - 1) * p.K2 + dchk * 8);
+    }
+    char* base = lds_w + (hh & 3) * SLOT;
+    glds16(a_src[0], base); a_src[0] += 64;
+    glds16(a_src[1], base + 8192); a_src[1] += 64;
+    glds16(w_src[0], base + A_BYTES); w_src[0] += 64;
+    glds16(w_src[1], base + A_BYTES + 8192); w_src[1] += 64;
+    if (CW0 == 3 && !lag) { glds16(w_src[2], base + A_BYTES + 16384); w_src[2] += 64; }
+  };
+
+  const int npro = min(nh, 3);
+  for (int hh = 0; hh < npro; ++hh) issue(hh);
+  if (lag) wait_groups<4>(npro - 1); else wait_groups<2 + CW0>(npro - 1);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (lag) __builtin_amdgcn_s_barrier();
+  for (int h = 0; h < nh; ++h) {
+    const char* S = smem + (h & 3) * SLOT;
+    bf16x8 af[8], bfr[NT];
+    // ---- L(h)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 1024);
+    if (h + 3 < nh) issue(h + 3);
+    const int rem = min(h + 3, nh - 1) - (h + 1);            // DMA groups issued after DMA(h+1)
+    if (lag) wait_groups<4>(rem); else wait_groups<2 + CW0>(rem);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C(h)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!lag) __builtin_amdgcn_s_barrier();
+
+  char* Cb = (char*)p.C;
+  if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+  if (p.dbg & 1) {                                            // experiment: main loop only
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 1234.5678f) *(float*)Cb = sacc;
+    return;
+  }
+  const bool wide = epilogue_wide_ok(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ml = m0 + wm * 128 + i * 16 + l15;
+    if (ml >= Mact) continue;
+    const int m = rbase + ml;
+    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m);
+  }
+}
+
 // out[i] = (add ? add[i] : 0) + sum_z slab[z][i]  (f32 and/or bf16 out; add may alias out); n4 = count / 4
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long slab_stride, const float* add,
                                      float* out, bf16_t* __restrict__ out_bf, long n4) {
@@ -545,7 +717,7 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 5) return forced;
+  if (forced >= 0 && forced <= 7) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -557,13 +729,18 @@ static int pick_variant(int M, int N, int splits) {
     const double t = rounds * (double)bm[v] * bn[v] / rate[v] * ((v == 0 || v == 5) ? 2.0 : 1.0);
     if (t < best_t) { best_t = t; best = v; }
   }
+  // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
+  static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
+  if (ring && (best == 3 || best == 4)) best += 3;
   return best;
 }
 
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int variant = pick_variant(a.M, a.N, a.splits);
-  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256), bn = variant == 4 ? 320 : ((variant == 1 || variant == 3) ? 256 : 128);
+  if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256);
+  const int bn = (variant == 4 || variant == 7) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
   a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   {
@@ -571,6 +748,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.group_m = gm && *gm ? atoi(gm) : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD
     const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
     a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
+    const char* d = getenv("TA355_GEMM_DEBUG");           // experiments: 1 = no epilogue stores, 2 = one K tile only
+    a.dbg = d && *d ? atoi(d) : 0;
   }
   ProfRec r;
   if (g_prof_on) {
@@ -585,6 +764,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
     } else {
       return TA_ERR_ARG;
@@ -595,6 +776,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
   else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   TA_CHECK_LAUNCH();
@@ -678,6 +861,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
   a.w_blocked = o.w_blocked ? 1 : 0;
   a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
+  a.dbg = 0;
   if (a.lnf_mode) {
     const bool row_ok = a.lnf_mode == 1 && act != 0;
     const bool col_ok = a.lnf_mode == 2 && act == 0 && out_bf16 && !residual && (N % 4) == 0;

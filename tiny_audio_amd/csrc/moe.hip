@@ -257,9 +257,10 @@ __global__ void moe_router_bwd_kernel(const float* __restrict__ dtopw, const flo
                                       const int* __restrict__ topi, const float* __restrict__ topraw,
                                       const float* __restrict__ lse, const float* __restrict__ noise,
                                       const float* __restrict__ psum, float* __restrict__ dlogits, int T, int E, float d_aux,
-                                      float coef, float zcoef, int training) {
+                                      const float* __restrict__ d_aux_dev, float coef, float zcoef, int training) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
+  if (d_aux_dev) d_aux = *d_aux_dev;               // upstream gradient of the auxiliary loss read on the device (no host sync)
   float p[MOE_MAX_E], dp[MOE_MAX_E];
   for (int e = 0; e < E; ++e) { p[e] = probs[(long)t * E + e]; dp[e] = 0.f; }
   const int i0 = topi[2 * t], i1 = topi[2 * t + 1];
@@ -449,10 +450,10 @@ extern "C" int ta_moe_projector_forward(const ta_moe_weights* w, const void* x, 
   return TA_OK;
 }
 
-extern "C" int ta_moe_projector_backward(const ta_moe_weights* w, const void* x, int B, int S, const float* dy, float d_aux,
-                                         const float* noise, int training, const void* tape, float* d_norm_w,
-                                         float* d_router_w, float* const* dW1, float* const* db1, float* const* dW2,
-                                         float* const* db2, void* ws, long ws_bytes, hipStream_t st) {
+static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int S, const float* dy, float d_aux,
+                             const float* d_aux_dev, const float* noise, int training, const void* tape, float* d_norm_w,
+                             float* d_router_w, float* const* dW1, float* const* db1, float* const* dW2,
+                             float* const* db2, void* ws, long ws_bytes, hipStream_t st) {
   const MoeDims d = moe_dims(w, B, S);
   if (B <= 0 || d.N <= 0) return TA_OK;
   MoeTape t = moe_tape(w, B, S, (void*)tape);
@@ -496,10 +497,26 @@ extern "C" int ta_moe_projector_backward(const ta_moe_weights* w, const void* x,
   }
   // ---- router and input norm
   TA_LAUNCH(moe_router_bwd_kernel, dim3(ta_cdiv(d.T, 256)), tb, 0, st, s.dtopw, t.probs, t.topi, t.topraw, t.lse,
-            training ? noise : nullptr, t.psum, s.dlogits, d.T, E, d_aux, w->aux_coef, w->z_coef, training);
+            training ? noise : nullptr, t.psum, s.dlogits, d.T, E, d_aux, d_aux_dev, w->aux_coef, w->z_coef, training);
   TA_LAUNCH(moe_router_dw_kernel, dim3(ta_cdiv(d.In, 256), 16), tb, 0, st, s.dlogits, t.xn, d_router_w, d.T, d.In, E, 16);
   TA_LAUNCH(moe_norm_bwd_kernel, dim3(ta_cdiv(d.In, 256), 32), tb, 0, st, s.dxn_sh, s.dxn_slot, t.slot_of, s.dlogits, w->router_w,
             (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In, t.rstd, d_norm_w, d.T, d.In, E, 32);
   TA_CHECK_LAUNCH();
   return TA_OK;
+}
+
+extern "C" int ta_moe_projector_backward(const ta_moe_weights* w, const void* x, int B, int S, const float* dy, float d_aux,
+                                         const float* noise, int training, const void* tape, float* d_norm_w,
+                                         float* d_router_w, float* const* dW1, float* const* db1, float* const* dW2,
+                                         float* const* db2, void* ws, long ws_bytes, hipStream_t st) {
+  return moe_backward_impl(w, x, B, S, dy, d_aux, nullptr, noise, training, tape, d_norm_w, d_router_w, dW1, db1, dW2, db2, ws,
+                           ws_bytes, st);
+}
+extern "C" int ta_moe_projector_backward_dev(const ta_moe_weights* w, const void* x, int B, int S, const float* dy,
+                                             const float* d_aux_dev, const float* noise, int training, const void* tape,
+                                             float* d_norm_w, float* d_router_w, float* const* dW1, float* const* db1,
+                                             float* const* dW2, float* const* db2, void* ws, long ws_bytes, hipStream_t st) {
+  if (!d_aux_dev) return TA_ERR_ARG;
+  return moe_backward_impl(w, x, B, S, dy, 0.f, d_aux_dev, noise, training, tape, d_norm_w, d_router_w, dW1, db1, dW2, db2, ws,
+                           ws_bytes, st);
 }

@@ -189,6 +189,14 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
 
     @torch.no_grad()
     def forward(self, input_features, frame_keep=None, return_f32=False, **_):
+        """model.audio_tower(input_features=...).last_hidden_state through torch.ops.ta355.encoder_forward."""
+        from . import torch_ops
+        x = input_features.to(device=self.device_, dtype=F32)
+        if frame_keep is not None:
+            frame_keep = frame_keep.to(device=self.device_, dtype=F32).contiguous()
+        return BaseModelOutput(torch.ops.ta355.encoder_forward(x, frame_keep, torch_ops.register_module(self), bool(return_f32)))
+
+    def _forward_impl(self, input_features, frame_keep=None, return_f32=False):
         if self._w is None:
             raise _lib.Ta355Error("encoder weights not loaded (load_state_dict_hf / random_init)")
         x = input_features.to(device=self.device_, dtype=F32).contiguous()
@@ -205,4 +213,4 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
             frame_keep = frame_keep.to(device=self.device_, dtype=F32).contiguous()
         _lib.check(_lib.lib().ta_encoder_forward(C.byref(self._w), ptr(x), B, T, ptr(frame_keep), ptr(out_b), ptr(out_f),
                                                  ptr(self._ws), self._ws.numel(), stream()), "ta_encoder_forward")
-        return BaseModelOutput(out_f if return_f32 else out_b)
+        return out_f if return_f32 else out_b

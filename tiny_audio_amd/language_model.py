@@ -588,31 +588,23 @@ class Qwen3MI355X(torch.nn.Module):
         yield out_seq[:, :n_new]
 
 
-class FrozenLMLoss(torch.autograd.Function):
-    """loss = CE(frozen_LM(embed(ids) with <audio> rows := audio_embeds)); grad flows to audio_embeds and, when
-    adapters are enabled, to the LoRA masters passed as trailing inputs (``*lm.lora_parameters()``)."""
+class FrozenLMLoss:
+    """loss = CE(frozen_LM(embed(ids) with <audio> rows := audio_embeds)) through ``torch.ops.ta355.lm_forward_loss``
+    (torch_ops.py); grad flows to audio_embeds and to the trainable LM tensors passed as trailing inputs -- the LoRA masters
+    (``*lm.lora_parameters()``) or, with a trainable base LM, its fp32 masters (``*lm.ft_parameters()``).
+
+    accumulate_into_grad (full decoder fine-tuning under ASRTrainer): the kernels add the LM's weight gradients straight
+    into the trainer's flat buffer, so d(loss) cannot be applied to them afterwards.  ASRTrainer is the only caller that
+    sets the flag and it always back-propagates the CE with d(loss) == 1 (the auxiliary term is added outside this node,
+    the token normalisation happens in the optimizer kernel); any other use must leave it off."""
 
     @staticmethod
-    def forward(ctx, audio_embeds, lm, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale,
-                want_logits, *lora_params):
-        a = audio_embeds.detach().to(F32).contiguous()
-        loss, nll, logits, c = lm.forward_loss(input_ids, src_row, a, kmask, label_rows, label_targets, n_label_rows,
-                                               loss_scale, want_logits)
-        ctx.lm, ctx.c, ctx.n_audio, ctx.n_lora = lm, c, a.shape[0], len(lora_params)
-        ctx.mark_non_differentiable(nll)
-        if logits is None:
-            logits = torch.empty(0, device=a.device)
-        ctx.mark_non_differentiable(logits)
-        return loss.reshape(()), nll, logits
-
-    @staticmethod
-    def backward(ctx, g_loss, _g_nll, _g_logits):
-        # accumulate_into_grad (full decoder fine-tuning under ASRTrainer): the kernels add the LM's weight gradients
-        # straight into the trainer's flat buffer, so d(loss) cannot be applied to them afterwards.  ASRTrainer is the only
-        # caller that sets the flag and it always back-propagates the CE with d(loss) == 1 (the auxiliary term is added
-        # outside this node, the token normalisation happens in the optimizer kernel); any other use must leave it off.
-        d_audio, _, lg = ctx.lm.backward_from_ctx(ctx.c, ctx.n_audio, want_d_audio=ctx.needs_input_grad[0])
-        ctx.c = None
-        lora = tuple(None if g is None else g * g_loss for g in lg)[: ctx.n_lora] if lg is not None else ()
-        lora = lora + (None,) * (ctx.n_lora - len(lora))
-        return (None if d_audio is None else d_audio * g_loss,) + (None,) * 9 + lora
+    def apply(audio_embeds, lm, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale,
+              want_logits, *trainable):
+        from . import torch_ops
+        loss, nll, logits, _tape, _ws = torch.ops.ta355.lm_forward_loss(
+            audio_embeds, list(trainable), torch_ops.register_module(lm), input_ids, src_row, kmask, label_rows, label_targets,
+            int(n_label_rows), float(loss_scale), bool(want_logits))
+        # a fresh tensor: the outputs of a multi-output custom op may not be modified in place, and HF Trainer does
+        # `loss *= ...` on what the model returns (TF:trainer.py compute_loss)
+        return loss.clone(), nll, logits

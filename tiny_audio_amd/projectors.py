@@ -14,7 +14,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, torch_ops
 from .ops import BF16, F32, cast_bf16, ptr, stream, transpose_to_bf16
 
 
@@ -25,44 +25,6 @@ class _RMSNormWeight(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(dim))
         self.variance_epsilon = eps
-
-
-class _MLPProjectorFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w1, g1, w2, g2, mod):
-        B, S, _ = x.shape
-        xb = x.detach()
-        if xb.dtype != BF16:
-            xb = xb.to(BF16)
-        xb = xb.contiguous()
-        wts = mod._packed_weights()
-        L_ = _lib.lib()
-        N = mod.get_output_length(S)
-        tape = torch.empty(L_.ta_mlp_tape_bytes(C.byref(wts), B, S), device=x.device, dtype=torch.uint8)
-        y = torch.empty((B, N, mod.llm_dim), device=x.device, dtype=F32)
-        _lib.check(L_.ta_mlp_projector_forward(C.byref(wts), ptr(xb), B, S, ptr(y), ptr(tape), stream()),
-                   "ta_mlp_projector_forward")
-        ctx.mod, ctx.xb, ctx.tape, ctx.dims = mod, xb, tape, (B, S)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        mod, (B, S) = ctx.mod, ctx.dims
-        wts = mod._packed_weights()
-        L_ = _lib.lib()
-        dev = dy.device
-        dy = dy.to(F32).contiguous()
-        dW1 = torch.empty_like(mod.linear_1.weight, dtype=F32)
-        dW2 = torch.empty_like(mod.linear_2.weight, dtype=F32)
-        dg1 = torch.empty_like(mod.norm.weight, dtype=F32)
-        dg2 = torch.empty_like(mod.norm_2.weight, dtype=F32)
-        ws = torch.empty(L_.ta_mlp_bwd_workspace_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
-        _lib.check(L_.ta_mlp_projector_backward(C.byref(wts), ptr(ctx.xb), B, S, ptr(dy), ptr(ctx.tape), ptr(dW1), ptr(dg1),
-                                                ptr(dW2), ptr(dg2), ptr(ws), ws.numel(), stream()),
-                   "ta_mlp_projector_backward")
-        ctx.tape = None
-        # the encoder is frozen: no gradient w.r.t. x is ever needed on the training path
-        return None, dW1, dg1, dW2, dg2, None
 
 
 class MLPAudioProjector(nn.Module):
@@ -103,12 +65,17 @@ class MLPAudioProjector(nn.Module):
             self._pack_versions = versions
         return self._pack[0]
 
+    def _packed_weights_meta(self):
+        """Dimensions only (null pointers): enough for the host-side ``*_bytes`` size queries of the C ABI."""
+        return _lib.MlpWeights(enc_dim=self.encoder_dim, k=self.k, hidden=self.hidden_dim, llm_dim=self.llm_dim, eps=1e-6)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B, S, encoder_dim] (bf16 encoder output) -> [B, (S-k)//k+1, llm_dim] fp32."""
         if not x.is_cuda and not _lib.DRY_RUN:
             raise _lib.Ta355Error("MLPAudioProjector runs on the MI355X HIP path only (no CPU fallback)")
-        return _MLPProjectorFn.apply(x, self.linear_1.weight, self.norm.weight, self.linear_2.weight, self.norm_2.weight,
-                                     self)
+        # torch.ops.ta355.mlp_projector (torch_ops.py): forward + registered autograd; outputs 1, 2 are its saved state
+        return torch.ops.ta355.mlp_projector(x, self.linear_1.weight, self.norm.weight, self.linear_2.weight, self.norm_2.weight,
+                                             torch_ops.register_module(self))[0]
 
 
 # =============================================================================
@@ -121,55 +88,6 @@ class SimpleAdapter(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(input_dim, hidden_dim)
         self.fc2 = nn.Linear(hidden_dim, output_dim)
-
-
-class _MoEProjectorFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, noise, mod, *params):
-        B, S, _ = x.shape
-        xb = x.detach()
-        xb = (xb if xb.dtype == BF16 else xb.to(BF16)).contiguous()
-        wts = mod._packed_weights()
-        L_ = _lib.lib()
-        dev = x.device
-        training = bool(mod.training)
-        N = mod.get_output_length(S)
-        tape = torch.empty(L_.ta_moe_tape_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
-        y = torch.empty((B, N, mod.llm_dim), device=dev, dtype=F32)
-        aux = torch.zeros((), device=dev, dtype=F32)
-        nz = None if noise is None else noise.to(device=dev, dtype=F32).contiguous()
-        _lib.check(L_.ta_moe_projector_forward(C.byref(wts), ptr(xb), B, S, ptr(nz), int(training), ptr(y), ptr(aux), ptr(tape),
-                                               stream()), "ta_moe_projector_forward")
-        ctx.mod, ctx.xb, ctx.tape, ctx.dims, ctx.noise, ctx.training = mod, xb, tape, (B, S), nz, training
-        return y, aux
-
-    @staticmethod
-    def backward(ctx, dy, d_aux):
-        mod, (B, S) = ctx.mod, ctx.dims
-        wts = mod._packed_weights()
-        L_ = _lib.lib()
-        dev = dy.device
-        dy = dy.to(F32).contiguous()
-        E = mod.num_experts
-        adapters = list(mod.experts) + [mod.shared_expert]
-        g_norm = torch.empty_like(mod.norm.weight, dtype=F32)
-        g_router = torch.empty_like(mod.router.weight, dtype=F32)
-        gW1 = [torch.empty_like(a.fc1.weight, dtype=F32) for a in adapters]
-        gb1 = [torch.empty_like(a.fc1.bias, dtype=F32) for a in adapters]
-        gW2 = [torch.empty_like(a.fc2.weight, dtype=F32) for a in adapters]
-        gb2 = [torch.empty_like(a.fc2.bias, dtype=F32) for a in adapters]
-        arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
-        ws = torch.empty(L_.ta_moe_bwd_workspace_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
-        # d_aux is the upstream gradient of the auxiliary loss (1.0 when loss = CE + aux); one host read of a scalar
-        da = float(d_aux) if d_aux is not None else 0.0
-        _lib.check(L_.ta_moe_projector_backward(C.byref(wts), ptr(ctx.xb), B, S, ptr(dy), da, ptr(ctx.noise), int(ctx.training),
-                                                ptr(ctx.tape), ptr(g_norm), ptr(g_router), arr(gW1), arr(gb1), arr(gW2),
-                                                arr(gb2), ptr(ws), ws.numel(), stream()), "ta_moe_projector_backward")
-        ctx.tape = None
-        grads = [g_norm, g_router]
-        for i in range(E + 1):
-            grads += [gW1[i], gb1[i], gW2[i], gb2[i]]
-        return (None, None, None, *grads)
 
 
 class MoEAudioProjector(nn.Module):
@@ -243,6 +161,12 @@ class MoEAudioProjector(nn.Module):
             self._pack_versions = versions
         return self._pack[0]
 
+    def _packed_weights_meta(self):
+        """Dimensions only (null pointers): enough for the host-side ``*_bytes`` size queries of the C ABI."""
+        return _lib.MoeWeights(enc_dim=self.encoder_dim, k=self.k, hidden=self.hidden_dim, llm_dim=self.llm_dim,
+                               num_experts=self.num_experts, eps=1e-6, aux_coef=float(self.aux_coef),
+                               z_coef=float(self.router_z_loss_coef))
+
     def forward(self, x: torch.Tensor, jitter_noise: torch.Tensor = None) -> torch.Tensor:
         """x [B, S, encoder_dim] -> [B, N, llm_dim] fp32.  ``jitter_noise`` [B*N, E] injects the multiplicative router
         noise (tests); in training it is otherwise drawn U(1-eps, 1+eps) as the reference does (projectors.py:294-300)."""
@@ -254,7 +178,10 @@ class MoEAudioProjector(nn.Module):
         if noise is None and self.training and self.router_jitter_noise > 0:
             noise = torch.empty((T, self.num_experts), device=x.device, dtype=F32).uniform_(
                 1.0 - self.router_jitter_noise, 1.0 + self.router_jitter_noise)
-        y, aux = _MoEProjectorFn.apply(x, noise, self, *self._param_list())
+        if noise is not None:
+            noise = noise.to(device=x.device, dtype=F32).contiguous()
+        y, aux, _xb, _tape = torch.ops.ta355.moe_projector(x, noise, self._param_list(), torch_ops.register_module(self),
+                                                           bool(self.training))
         self.last_aux_loss = aux
         return y
 
