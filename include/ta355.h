@@ -331,6 +331,18 @@ int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int
                         int out_bf16, int splits, float* splitk_ws, const int* a_idx, const int* seg,
                         const int* krange, const ta_gemm_opts* opts, hipStream_t st);
 long ta_gemm_splitk_ws_bytes(int M, int N, int splits);
+/* Grouped GEMMs: every expert of the MoE projector in ONE launch (tiny_audio/projectors.py:327-345 loops over the experts
+ * in Python).  n_groups <= 8; exactly one of seg / krange is given (DEVICE int arrays, read by the kernel):
+ *   rows form     seg = int[2 * n_groups] {row base, row count} over a common row space (the expert-sorted token slots).
+ *                 Group e: C[rows of e, :] = act(A[rows of e (through a_idx, if given), :] (W + e * w_stride)^T + bias[e * N ...]).
+ *                 M = upper bound of the TOTAL row count (grid sizing); the tile -> (expert, row tile) map is resolved on the
+ *                 device, so routing counts never visit the host.
+ *   K-slice form  krange = int[2 * n_groups] {first, end} 64-wide K tile.  Group e: (C + e * c_stride)[M, N] = A[:, slice e]
+ *                 W[:, slice e]^T, f32, no bias / activation (per-expert weight gradients: the contraction runs over the slot
+ *                 axis, which the counting-sort plan keeps contiguous and 64-aligned per expert). */
+int ta_gemm_bf16_nt_grouped(const void* A, const void* W, void* C, int M, int N, int K, const float* bias, int act, int out_bf16,
+                            const int* a_idx, const int* seg, const int* krange, int n_groups, long w_stride, long c_stride,
+                            hipStream_t st);
 /* "TN" product (contraction over the ROWS of both row-major operands): out f32 [Ny, Nx] (+)= Y[M, Ny]^T X[M, Nx] -- the
  * weight gradient dW = dY^T X of a linear layer (full decoder fine-tuning) without transposing dY and X first.
  * Ny, Nx multiples of 8; ws: ta_gemm_bf16_tn_ws_bytes(M, Ny, Nx) bytes of scratch (row-chunk partial sums). */

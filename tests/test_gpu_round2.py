@@ -446,3 +446,53 @@ def test_hf_trainer_drives_the_model_unchanged(tmp_path):
         b = collator([{"audio": {"array": rows[0]["audio"]["array"].copy(), "sampling_rate": 16000}, "text": rows[0]["text"]}])
         o = model(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()})
     assert np.isfinite(float(o.loss))
+
+
+# ============================================================================ grouped GEMM (MoE experts in one launch)
+@pytest.mark.parametrize("variant", ["", "0", "3", "4", "5", "7"])
+def test_grouped_gemm_rows_and_kslices(variant, monkeypatch):
+    """ta_gemm_bf16_nt_grouped against fp32 matmuls of the same bf16 operands: ragged segments incl. an EMPTY expert and
+    partial tiles, a gather list, bias + GELU; the K-slice form with an empty slice (its gradient must be exactly zero)."""
+    from tiny_audio_amd import ops
+    monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    torch.manual_seed(1)
+    E, N, K = 4, 320, 256
+    counts = [300, 0, 257, 70]
+    base, segs = 0, []
+    for c in counts:
+        segs += [base, c]; base += (c + 63) // 64 * 64
+    Smax = base + 64
+    T = 400
+    src = torch.randn(T, K, device=DEV).to(torch.bfloat16)
+    perm = torch.full((Smax,), -1, dtype=torch.int32)
+    rng = np.random.RandomState(0)
+    for e, c in enumerate(counts):
+        perm[segs[2 * e]: segs[2 * e] + c] = torch.from_numpy(rng.randint(0, T, c).astype(np.int32))
+    W = (torch.randn(E, N, K, device=DEV) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(E, N, device=DEV)
+    seg = torch.tensor(segs, dtype=torch.int32, device=DEV)
+    permd = perm.to(DEV)
+    for out_dtype, act in ((torch.bfloat16, 1), (torch.float32, 0)):
+        out = torch.full((Smax, N), 7.0, device=DEV, dtype=out_dtype)
+        ops.gemm_nt_grouped(src, W, out, sum(counts), N, K, seg=seg, n_groups=E, bias=bias, act=act, a_idx=permd, w_stride=N * K)
+        ref = torch.full((Smax, N), 7.0, device=DEV)
+        for e, c in enumerate(counts):
+            rows = permd[segs[2 * e]: segs[2 * e] + c].long()
+            y = src[rows].float() @ W[e].float().t() + bias[e]
+            ref[segs[2 * e]: segs[2 * e] + c] = torch.nn.functional.gelu(y) if act else y
+        tol = 3e-2 if out_dtype == torch.bfloat16 else 2e-3
+        assert float((out.float() - ref).abs().max()) < tol * float(ref.abs().max())     # rows outside every segment untouched (7.0)
+    # K-slice form: dW[e] = Y[:, slice e] X[:, slice e]^T over 64-aligned slices of the slot axis
+    Mo, No = 192, 320
+    Y = torch.randn(Mo, Smax, device=DEV).to(torch.bfloat16)
+    X = torch.randn(No, Smax, device=DEV).to(torch.bfloat16)
+    kr = []
+    for e, c in enumerate(counts):
+        kr += [segs[2 * e] // 64, (segs[2 * e] + (c + 63) // 64 * 64) // 64]
+    out = torch.full((E, Mo, No), 3.0, device=DEV)
+    ops.gemm_nt_grouped(Y, X, out, Mo, No, Smax, krange=torch.tensor(kr, dtype=torch.int32, device=DEV), n_groups=E, c_stride=Mo * No)
+    for e in range(E):
+        a, b = kr[2 * e] * 64, kr[2 * e + 1] * 64
+        ref = Y[:, a:b].float() @ X[:, a:b].float().t()
+        assert float((out[e] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + (0.0 if b > a else 0.0), e
+    assert float(out[1].abs().max()) == 0.0                                              # the empty expert

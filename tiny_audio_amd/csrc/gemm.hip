@@ -57,6 +57,12 @@ struct GemmArgs {
   // lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from ta_layernorm_stats; lnf_c1[j] = sum_k W'[j, k]
   const float* lnf_stats; const float* lnf_c1; int lnf_mode;
   int dbg;             // experiments only (TA355_GEMM_DEBUG): bit 0 = no epilogue stores, bit 1 = contract over ONE K tile only
+  // Grouped launch (MoE experts in ONE launch, ta_gemm_bf16_nt_grouped):
+  //   rows form    seg = int[2 * grp_n] {row base, row count}: M tile indices run over the concatenation of the groups' row
+  //                tiles; group e multiplies by W + e * grp_w_stride and adds bias + e * N
+  //   K-slice form krange = int[2 * grp_n] K-tile ranges, the launch's z index IS the group: (C + z * slab_stride) gets the
+  //                product contracted over slice z (per-expert weight gradients over the slot-sorted token axis)
+  int grp_n; long grp_w_stride;
 };
 
 #define BM 128
@@ -86,7 +92,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // (16 * (j + (g & 1)) + 8 * (g >> 1) ...) and one store covers 64 contiguous bytes per row.
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
-                                               int m) {
+                                               int m, const float* bias) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
@@ -112,8 +118,8 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         v[0] = v[0] * s0.x + s0.y * c; v[1] = v[1] * s0.z + s0.w * c;
         v[2] = v[2] * s1.x + s1.y * c; v[3] = v[3] * s1.z + s1.w * c;
       }
-      if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + n);
+      if (bias) {
+        const float4 b = *(const float4*)(bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
       if (BASE == 1) {
@@ -177,6 +183,30 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 }
 __device__ __forceinline__ bool epilogue_wide_ok(const GemmArgs& p) { return p.wide != 0; }
 
+
+// Group of a tile in a grouped launch (see GemmArgs.grp_n).  rows form: walks the <= 8 segments; returns false for the
+// surplus tiles of the (upper-bound) grid.
+template <int BMT_>
+__device__ __forceinline__ bool resolve_group(const GemmArgs& p, int& pm, int z, const int*& seg, const bf16_t*& W,
+                                              const float*& bias, const int*& krange) {
+  seg = p.seg; W = p.W; bias = p.bias; krange = p.krange;
+  if (p.grp_n <= 0) return true;
+  if (p.seg) {
+    int e = 0, rem = pm;
+    for (; e < p.grp_n; ++e) {
+      const int te = (p.seg[2 * e + 1] + BMT_ - 1) / BMT_;
+      if (rem < te) break;
+      rem -= te;
+    }
+    if (e == p.grp_n) return false;
+    pm = rem; seg = p.seg + 2 * e; W = p.W + (long)e * p.grp_w_stride;
+    if (bias) bias += (long)e * p.N;
+  } else if (p.krange) {
+    krange = p.krange + 2 * z;
+  }
+  return true;
+}
+
 // BMT = 128, or 96 rows per tile (waves 2x2 of 48x64): M = 6144 x N = 1024 is then 512 tiles = every resident slot of the
 // chip (two workgroups per CU) instead of 384.
 // KEXT: the K extension of ta_gemm_opts.a2/w2 (LoRA) is compiled in (its pointer switch sits in the main loop: 0.3 ms per
@@ -204,17 +234,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int group = t / width;
   const int first_m = group * GROUP_M;
   const int gsize = min(p.tiles_m - first_m, GROUP_M);
-  const int pm = first_m + (t % width) % gsize;
+  int pm = first_m + (t % width) % gsize;
   const int pn = (t % width) / gsize;
+  const int* segp; const bf16_t* Wp; const float* biasp; const int* krp;
+  if (!resolve_group<BMT>(p, pm, z, segp, Wp, biasp, krp)) return;            // block-uniform: before any barrier
   const int m0 = pm * BMT, n0 = pn * BN;
 
   const int nkt = p.K / BK;
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
-  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;              // K extension (host guarantees splits == 1, no krange)
   int Mact = p.M, rbase = 0;
-  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }   // block-uniform: before any barrier
+  if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
 
   // ---- per-thread DMA source pointers: 4 x 16 B chunks of A and of W per K-step
   const int lr = tid >> 3;
@@ -231,8 +263,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       a_src[i] = (const char*)(p.A + aoff + (long)kt_begin * BK + clog * 8);
     }
     const int gn = min(n0 + r, p.N - 1);
-    w_src[i] = p.w_blocked ? (const char*)(p.W + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
-                           : (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+    w_src[i] = p.w_blocked ? (const char*)(Wp + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
+                           : (const char*)(Wp + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
   }
   const int w_step = p.w_blocked ? 8192 : BK * 2;      // bytes to the next K tile of the same rows
   char* lds_w = smem + wave * 1024;   // + buf*2*TILE + (A:0 | W:TILE) + i*4096, lane*16 added by the DMA
@@ -308,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m);
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp);
   }
 }
 
@@ -355,18 +387,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int group = t / width;
   const int first_m = group * GROUP_M;
   const int gsize = min(p.tiles_m - first_m, GROUP_M);
-  const int pm = first_m + (t % width) % gsize;
+  int pm = first_m + (t % width) % gsize;
   const int pn = (t % width) / gsize;
+  const int* segp; const bf16_t* Wp; const float* biasp; const int* krp;
+  if (!resolve_group<BM2>(p, pm, z, segp, Wp, biasp, krp)) return;
   const int m0 = pm * BM2, n0 = pn * BN2;
 
   const int nkt = p.K / BK;
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
-  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;
   if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
   int Mact = p.M, rbase = 0;
-  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
+  if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
 
   const int lr = tid >> 3;                                    // 0..63
   const int clog = (tid & 7) ^ ((lr >> 1) & 7);
@@ -382,8 +416,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int gn = min(n0 + i * 64 + lr, p.N - 1);
-    w_src[i] = p.w_blocked ? (const char*)(p.W + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
-                           : (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
+    w_src[i] = p.w_blocked ? (const char*)(Wp + (((long)(gn >> 6) * nkt + kt_begin) << 12) + ((gn & 63) << 6) + clog * 8)
+                           : (const char*)(Wp + (long)gn * p.K + (long)kt_begin * BK + clog * 8);
   }
   const int w_step = p.w_blocked ? 8192 : BK * 2;
   char* lds_w = smem + wave * 1024;
@@ -509,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp);
   }
 }
 
@@ -564,18 +598,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
   const int group = t / width;
   const int first_m = group * GROUP_M;
   const int gsize = min(p.tiles_m - first_m, GROUP_M);
-  const int pm = first_m + (t % width) % gsize;
+  int pm = first_m + (t % width) % gsize;
   const int pn = (t % width) / gsize;
+  const int* segp; const bf16_t* Wp; const float* biasp; const int* krp;
+  if (!resolve_group<BM2>(p, pm, z, segp, Wp, biasp, krp)) return;
   const int m0 = pm * BM2, n0 = pn * BN2;
 
   const int nkt = p.K / BK;
   int kt_begin = (int)(((long)nkt * z) / p.splits);
   int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
-  if (p.krange) { kt_begin = p.krange[0]; kt_end = p.krange[1]; }
+  if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;
   if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
   int Mact = p.M, rbase = 0;
-  if (p.seg) { rbase = p.seg[0]; Mact = p.seg[1]; if (m0 >= Mact) return; }
+  if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
 
   // ---- DMA sources: wave w stages A blocks w, w+8 and W blocks w, w+8 (, w+16)
   const int drow = lane >> 2;
@@ -592,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int gn = min(n0 + (wave + 8 * i) * 16 + drow, p.N - 1);
-    w_src[i] = (const char*)(p.W + (long)gn * p.K + (long)kt_begin * BK + dchk * 8);
+    w_src[i] = (const char*)(Wp + (long)gn * p.K + (long)kt_begin * BK + dchk * 8);
   }
   const int lag = __builtin_amdgcn_readfirstlane(wm);       // SGPR: group 1 runs one barrier interval behind
   char* lds_w = smem + wave * 1024;
@@ -679,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp);
   }
 }
 
@@ -741,7 +777,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
   const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256);
   const int bn = (variant == 4 || variant == 7) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
-  a.tiles_m = ta_cdiv(a.M, bm); a.tiles_n = ta_cdiv(a.N, bn);
+  // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
+  a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   {
     const char* gm = getenv("TA355_GROUP_M");             // experiments: tile-order group height
@@ -861,7 +898,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
   a.w_blocked = o.w_blocked ? 1 : 0;
   a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
-  a.dbg = 0;
+  a.dbg = 0; a.grp_n = 0; a.grp_w_stride = 0;
   if (a.lnf_mode) {
     const bool row_ok = a.lnf_mode == 1 && act != 0;
     const bool col_ok = a.lnf_mode == 2 && act == 0 && out_bf16 && !residual && (N % 4) == 0;
@@ -906,6 +943,31 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     return a.lnf_mode == 1 ? launch_gemm<4, true, false>(a, st) : launch_gemm<2, true, false>(a, st);
   }
   return TA_ERR_ARG;
+}
+
+
+// ---- grouped launches (MoE experts): see GemmArgs.grp_n and include/ta355.h
+extern "C" int ta_gemm_bf16_nt_grouped(const void* A, const void* W, void* C, int M, int N, int K, const float* bias, int act,
+                                       int out_bf16, const int* a_idx, const int* seg, const int* krange, int n_groups,
+                                       long w_stride, long c_stride, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || n_groups <= 0) return TA_OK;
+  if (n_groups > 8 || (seg != nullptr) == (krange != nullptr) || (K % BK) || (N % 4) || (w_stride % 8) || (c_stride % 4)) return TA_ERR_ARG;
+  if (krange && (out_bf16 || bias || act || a_idx || w_stride)) return TA_ERR_ARG;      // K-slice form: plain f32 products
+  if (act != 0 && act != 1) return TA_ERR_ARG;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = C; a.bias = bias; a.res = nullptr;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = K; a.a_rpb = 0x7fffffff; a.a_bs = 0; a.ldc = N; a.c_rpb = 0x7fffffff; a.c_bs = 0; a.c_off = 0;
+  a.a_plain = 1; a.c_plain = 1;
+  a.a_idx = a_idx; a.seg = seg; a.krange = krange;
+  a.A2 = nullptr; a.W2 = nullptr; a.K2 = 0; a.lda2 = 0; a.sw_gu = nullptr; a.sw_dgu = nullptr; a.res_bf16 = 0;
+  a.rope_tab = nullptr; a.rope_rows = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
+  a.grp_n = n_groups; a.grp_w_stride = w_stride;
+  a.splits = krange ? n_groups : 1;           // K-slice form: z = group, slabs c_stride apart
+  a.slab_stride = krange ? c_stride : (long)M * N;
+  a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
+  if (act == 1) return out_bf16 ? launch_gemm<1, true, false>(a, st) : launch_gemm<1, false, false>(a, st);
+  return out_bf16 ? launch_gemm<0, true, false>(a, st) : launch_gemm<0, false, false>(a, st);
 }
 
 extern "C" long ta_gemm_splitk_ws_bytes(int M, int N, int splits) {

@@ -6,6 +6,7 @@
 // GEMM K tile, so per-expert weight gradients contract over an aligned slot range), expert GEMMs read their rows
 // through the gather list with device-side segment bounds (ta_gemm_bf16_nt_ex), and the combine is a deterministic
 // per-token gather (no atomics, bit-reproducible).
+#include <cstdlib>
 #include "common.h"
 
 #define MOE_MAX_E 8
@@ -412,6 +413,20 @@ inline int gemm_seg(const void* A, const void* W, void* C, int Mmax, int N, int 
                     const int* a_idx, const int* seg, const int* krange, hipStream_t st) {
   return ta_gemm_bf16_nt_ex(A, W, C, Mmax, N, K, K, 0, 0, N, 0, 0, 0, bias, nullptr, 0, out_bf16, 1, nullptr, a_idx, seg, krange, st);
 }
+// Element stride between consecutive routed experts' buffers when they are laid out at a constant distance (the Python
+// module packs them into one tensor); 0 = not uniformly strided (then the per-expert launches are used).
+template <typename T> long expert_stride(const void* const* ptrs, int E) {
+  if (E < 2) return 0;
+  const long s = (const T*)ptrs[1] - (const T*)ptrs[0];
+  if (s <= 0) return 0;
+  for (int e = 1; e + 1 < E; ++e)
+    if ((const T*)ptrs[e + 1] - (const T*)ptrs[e] != s) return 0;
+  return s;
+}
+inline bool grouped_enabled() {
+  static const bool on = [] { const char* e = getenv("TA355_MOE_GROUPED"); return !(e && *e == '0'); }();
+  return on;
+}
 }  // namespace
 
 extern "C" long ta_moe_tape_bytes(const ta_moe_weights* w, int B, int S) { return (long)moe_tape(w, B, S, nullptr).bytes; }
@@ -435,11 +450,18 @@ extern "C" int ta_moe_projector_forward(const ta_moe_weights* w, const void* x, 
   MRC(gemm_plain(t.xn, w->w1[E], t.h_s, d.T, d.H, d.In, w->b1[E], 1, 1, nullptr, st));
   TA_LAUNCH(gelu_bf16_kernel, dim3(ew((long)d.T * d.H / 4)), dim3(256), 0, st, t.h_s, t.act_s, (long)d.T * d.H / 4);
   MRC(gemm_plain(t.act_s, w->w2[E], y, d.T, d.D, d.H, w->b2[E], 0, 1, nullptr, st));
-  // routed experts over their slot segments (row counts stay on the device)
-  for (int e = 0; e < E; ++e)
+  // routed experts over their slot segments (row counts stay on the device): ONE grouped launch per matrix -- the
+  // tile -> (expert, row tile) map is resolved in the kernel from the plan's segment table -- when the experts' weights
+  // and biases sit at a constant stride (TA355_MOE_GROUPED=0: one launch per expert, 4x fewer workgroups each)
+  const long s_w1 = expert_stride<bf16_t>(w->w1, E), s_w2 = expert_stride<bf16_t>(w->w2, E);
+  const bool g1 = grouped_enabled() && s_w1 > 0 && expert_stride<float>((const void* const*)w->b1, E) == d.H;
+  const bool g2 = grouped_enabled() && s_w2 > 0 && expert_stride<float>((const void* const*)w->b2, E) == d.D;
+  if (g1) MRC(ta_gemm_bf16_nt_grouped(t.xn, w->w1[0], t.h_e, 2 * d.T, d.H, d.In, w->b1[0], 0, 1, t.perm, t.seg, nullptr, E, s_w1, 0, st));
+  else for (int e = 0; e < E; ++e)
     MRC(gemm_seg(t.xn, w->w1[e], t.h_e, d.T, d.H, d.In, w->b1[e], 1, t.perm, t.seg + 2 * e, nullptr, st));
   TA_LAUNCH(gelu_bf16_kernel, dim3(ew((long)d.Smax * d.H / 4)), dim3(256), 0, st, t.h_e, t.act_e, (long)d.Smax * d.H / 4);
-  for (int e = 0; e < E; ++e)
+  if (g2) MRC(ta_gemm_bf16_nt_grouped(t.act_e, w->w2[0], t.y_e, 2 * d.T, d.D, d.H, w->b2[0], 0, 0, nullptr, t.seg, nullptr, E, s_w2, 0, st));
+  else for (int e = 0; e < E; ++e)
     MRC(gemm_seg(t.act_e, w->w2[e], t.y_e, d.T, d.D, d.H, w->b2[e], 0, nullptr, t.seg + 2 * e, nullptr, st));
   TA_LAUNCH(moe_combine_kernel, dim3(ta_cdiv(d.T, 4)), dim3(256), 0, st, y, t.y_e, t.slot_of, t.topw, d.T, d.D);
   if (aux) {
@@ -482,19 +504,25 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   dim3 tb(256);
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.D, 64), d.Smax / 64), tb, 0, st, s.dy_slot, d.D, t.perm, 0, s.dyT, d.Smax);
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.H, 64), d.Smax / 64), tb, 0, st, t.act_e, d.H, t.perm, 0, s.acteT, d.Smax);
-  for (int e = 0; e < E; ++e) {
+  const long s_w2t = expert_stride<bf16_t>(w->w2_t, E), s_w1t = expert_stride<bf16_t>(w->w1_t, E);
+  const long s_dw2 = expert_stride<float>((const void* const*)dW2, E), s_dw1 = expert_stride<float>((const void* const*)dW1, E);
+  const bool grp = grouped_enabled();
+  for (int e = 0; e < E; ++e)
     TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.D, 256), 16), tb, 0, st, s.dy_slot, d.D, t.seg + 2 * e, 0, db2[e], 16);
-    MRC(gemm_seg(s.dyT, s.acteT, dW2[e], d.D, d.H, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
-    MRC(gemm_seg(s.dy_slot, w->w2_t[e], s.dact_e, d.T, d.H, d.D, nullptr, 1, nullptr, t.seg + 2 * e, nullptr, st));
-  }
+  // dW2[e] = dy_e^T act_e: the contraction runs over expert e's (64-aligned) slot range -> the K-slice grouped form
+  if (grp && s_dw2 > 0) MRC(ta_gemm_bf16_nt_grouped(s.dyT, s.acteT, dW2[0], d.D, d.H, d.Smax, nullptr, 0, 0, nullptr, nullptr, t.kr, E, 0, s_dw2, st));
+  else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dyT, s.acteT, dW2[e], d.D, d.H, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
+  if (grp && s_w2t > 0) MRC(ta_gemm_bf16_nt_grouped(s.dy_slot, w->w2_t[0], s.dact_e, 2 * d.T, d.H, d.D, nullptr, 0, 1, nullptr, t.seg, nullptr, E, s_w2t, 0, st));
+  else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dy_slot, w->w2_t[e], s.dact_e, d.T, d.H, d.D, nullptr, 1, nullptr, t.seg + 2 * e, nullptr, st));
   TA_LAUNCH(gelu_bwd_bf16_kernel, dim3(ew((long)d.Smax * d.H / 4)), tb, 0, st, s.dact_e, t.h_e, s.dh_e, (long)d.Smax * d.H / 4);
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.H, 64), d.Smax / 64), tb, 0, st, s.dh_e, d.H, t.perm, 0, s.dheT, d.Smax);
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.In, 64), d.Smax / 64), tb, 0, st, t.xn, d.In, t.perm, 1, s.xngT, d.Smax);
-  for (int e = 0; e < E; ++e) {
+  for (int e = 0; e < E; ++e)
     TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.H, 256), 16), tb, 0, st, s.dh_e, d.H, t.seg + 2 * e, 0, db1[e], 16);
-    MRC(gemm_seg(s.dheT, s.xngT, dW1[e], d.H, d.In, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
-    MRC(gemm_seg(s.dh_e, w->w1_t[e], s.dxn_slot, d.T, d.In, d.H, nullptr, 0, nullptr, t.seg + 2 * e, nullptr, st));
-  }
+  if (grp && s_dw1 > 0) MRC(ta_gemm_bf16_nt_grouped(s.dheT, s.xngT, dW1[0], d.H, d.In, d.Smax, nullptr, 0, 0, nullptr, nullptr, t.kr, E, 0, s_dw1, st));
+  else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dheT, s.xngT, dW1[e], d.H, d.In, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
+  if (grp && s_w1t > 0) MRC(ta_gemm_bf16_nt_grouped(s.dh_e, w->w1_t[0], s.dxn_slot, 2 * d.T, d.In, d.H, nullptr, 0, 0, nullptr, t.seg, nullptr, E, s_w1t, 0, st));
+  else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dh_e, w->w1_t[e], s.dxn_slot, d.T, d.In, d.H, nullptr, 0, nullptr, t.seg + 2 * e, nullptr, st));
   // ---- router and input norm
   TA_LAUNCH(moe_router_bwd_kernel, dim3(ta_cdiv(d.T, 256)), tb, 0, st, s.dtopw, t.probs, t.topi, t.topraw, t.lse,
             training ? noise : nullptr, t.psum, s.dlogits, d.T, E, d_aux, d_aux_dev, w->aux_coef, w->z_coef, training);

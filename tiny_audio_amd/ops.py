@@ -89,6 +89,16 @@ def gemm_tn(Y, X, out=None, accumulate=False):
     return out
 
 
+def gemm_nt_grouped(A, W, out, M, N, K, *, seg=None, krange=None, n_groups=1, bias=None, act=0, a_idx=None, w_stride=0, c_stride=0):
+    """ta_gemm_bf16_nt_grouped: every group (MoE expert) in ONE launch.  rows form: ``seg`` int32 [2 * n] {row base, count},
+    W [n, N, K] (w_stride = N * K), bias [n, N]; K-slice form: ``krange`` int32 [2 * n] 64-wide K-tile ranges, out f32
+    [n, M, N] (c_stride = M * N)."""
+    _req(A, BF16); _req(W, BF16)
+    check(lib().ta_gemm_bf16_nt_grouped(ptr(A), ptr(W), ptr(out), M, N, K, ptr(bias), act, int(out.dtype == BF16), ptr(a_idx),
+                                        ptr(seg), ptr(krange), n_groups, w_stride, c_stride, stream()), "ta_gemm_bf16_nt_grouped")
+    return out
+
+
 def layernorm(x, w, b, eps=1e-5, rowscale=None, out_bf16=True, out_f32=False):
     if x.dtype == BF16:
         M, H = x.shape
@@ -249,21 +259,22 @@ def swiglu_bwd(dact, gu, F):
     return dgu
 
 
-def cast_bf16(x):
+def cast_bf16(x, out=None):
     _req(x, F32)
-    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    y = torch.empty(x.shape, device=x.device, dtype=BF16) if out is None else out
     check(lib().ta_cast_f32_bf16(ptr(x), ptr(y), x.numel(), stream()), "ta_cast_f32_bf16")
     return y
 
 
-def transpose_to_bf16(x, ld_out=None, in_map=None, rows=None, cols=None):
+def transpose_to_bf16(x, ld_out=None, in_map=None, rows=None, cols=None, out=None):
     """x [R, C] (f32 or bf16) -> bf16 [C, ld_out] (zero padded columns).  With ``in_map`` = (ld_in, batch_stride,
     rows_per_batch) the logical [rows, cols] matrix is an affine view of ``x`` (e.g. the im2col view of a padded
     time-major buffer: overlapping rows)."""
     R, Cc = (rows, cols) if rows is not None else x.shape
     ld_out = ld_out or R
     ld_in, in_bs, in_rpb = in_map or (Cc, 0, 0)
-    out = torch.empty((Cc, ld_out), device=x.device, dtype=BF16)
+    if out is None:
+        out = torch.empty((Cc, ld_out), device=x.device, dtype=BF16)
     check(lib().ta_transpose_to_bf16(ptr(x), int(x.dtype == F32), ld_in, in_bs, in_rpb, ptr(out), ld_out, R, Cc,
                                      stream()), "ta_transpose_to_bf16")
     return out

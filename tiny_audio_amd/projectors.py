@@ -143,12 +143,19 @@ class MoEAudioProjector(nn.Module):
             keep = []
             f32 = lambda p: p.detach().to(F32).contiguous()
             norm_w, router_w = f32(self.norm.weight), f32(self.router.weight)
+            # every kind of image is ONE tensor over the E + 1 adapters: the routed experts then sit at a constant stride,
+            # which lets libta355 run all of them in one grouped GEMM launch (ta_gemm_bf16_nt_grouped)
+            dev, H, In, D = norm_w.device, self.hidden_dim, self.encoder_dim * self.k, self.llm_dim
+            W1a, W1ta = torch.empty((E + 1, H, In), device=dev, dtype=BF16), torch.empty((E + 1, In, H), device=dev, dtype=BF16)
+            W2a, W2ta = torch.empty((E + 1, D, H), device=dev, dtype=BF16), torch.empty((E + 1, H, D), device=dev, dtype=BF16)
+            B1a, B2a = torch.empty((E + 1, H), device=dev, dtype=F32), torch.empty((E + 1, D), device=dev, dtype=F32)
             w1, w1t, b1, w2, w2t, b2 = [], [], [], [], [], []
-            for a in list(self.experts) + [self.shared_expert]:
+            for i, a in enumerate(list(self.experts) + [self.shared_expert]):
                 W1, W2 = f32(a.fc1.weight), f32(a.fc2.weight)
-                w1.append(cast_bf16(W1)); w1t.append(transpose_to_bf16(W1))
-                w2.append(cast_bf16(W2)); w2t.append(transpose_to_bf16(W2))
-                b1.append(f32(a.fc1.bias)); b2.append(f32(a.fc2.bias))
+                w1.append(cast_bf16(W1, out=W1a[i])); w1t.append(transpose_to_bf16(W1, out=W1ta[i]))
+                w2.append(cast_bf16(W2, out=W2a[i])); w2t.append(transpose_to_bf16(W2, out=W2ta[i]))
+                B1a[i].copy_(a.fc1.bias.detach()); B2a[i].copy_(a.fc2.bias.detach())
+                b1.append(B1a[i]); b2.append(B2a[i])
             arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
             arrays = [arr(w1), arr(w1t), arr(b1), arr(w2), arr(w2t), arr(b2)]
             wts = _lib.MoeWeights(enc_dim=self.encoder_dim, k=self.k, hidden=self.hidden_dim, llm_dim=self.llm_dim,

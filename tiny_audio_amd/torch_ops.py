@@ -192,7 +192,10 @@ def _(x, noise, params, handle, training):
 @torch.library.custom_op("ta355::moe_projector_backward", mutates_args=())
 def moe_projector_backward(dy: Tensor, d_aux: Tensor, xb: Tensor, noise: Optional[Tensor], tape: Tensor, handle: int,
                            training: bool) -> List[Tensor]:
-    """Gradients of sum(dy * y) + d_aux * aux for every tensor of ``params`` (same order); d_aux is a DEVICE scalar."""
+    """Gradients of sum(dy * y) + d_aux * aux (d_aux: a DEVICE scalar) -> [d norm.weight, d router.weight, then one STACKED
+    tensor per kind over the E routed experts + the shared expert: d fc1.weight [E+1, H, In], d fc1.bias [E+1, H],
+    d fc2.weight [E+1, D, H], d fc2.bias [E+1, D]].  (Operator outputs may not alias one another, and the constant stride
+    between the experts' buffers is what lets the library write them from one grouped launch.)"""
     mod = module_of(handle)
     B, S, _ = xb.shape
     wts = mod._packed_weights()
@@ -203,25 +206,29 @@ def moe_projector_backward(dy: Tensor, d_aux: Tensor, xb: Tensor, noise: Optiona
     adapters = list(mod.experts) + [mod.shared_expert]
     f = lambda p: torch.empty(p.shape, device=dev, dtype=F32)
     g_norm, g_router = f(mod.norm.weight), f(mod.router.weight)
-    gW1 = [f(a.fc1.weight) for a in adapters]
-    gb1 = [f(a.fc1.bias) for a in adapters]
-    gW2 = [f(a.fc2.weight) for a in adapters]
-    gb2 = [f(a.fc2.bias) for a in adapters]
+    # the adapters' gradients of one kind are slices of ONE tensor: a constant stride between the experts' buffers is what
+    # lets the library write all per-expert weight gradients from one grouped launch
+    stack = lambda ps: torch.empty((len(ps),) + tuple(ps[0].shape), device=dev, dtype=F32)
+    GW1, Gb1 = stack([a.fc1.weight for a in adapters]), stack([a.fc1.bias for a in adapters])
+    GW2, Gb2 = stack([a.fc2.weight for a in adapters]), stack([a.fc2.bias for a in adapters])
+    gW1, gb1, gW2, gb2 = (list(t.unbind(0)) for t in (GW1, Gb1, GW2, Gb2))
     arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
     ws = torch.empty(L_.ta_moe_bwd_workspace_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
     da = d_aux.to(device=dev, dtype=F32).reshape(1).contiguous()
     _lib.check(L_.ta_moe_projector_backward_dev(C.byref(wts), ptr(xb), B, S, ptr(dy), ptr(da), ptr(noise), int(training),
                                                 ptr(tape), ptr(g_norm), ptr(g_router), arr(gW1), arr(gb1), arr(gW2), arr(gb2),
                                                 ptr(ws), ws.numel(), stream()), "ta_moe_projector_backward_dev")
-    grads = [g_norm, g_router]
-    for i in range(E + 1):
-        grads += [gW1[i], gb1[i], gW2[i], gb2[i]]
-    return grads
+    return [g_norm, g_router, GW1, Gb1, GW2, Gb2]
 
 
 @moe_projector_backward.register_fake
 def _(dy, d_aux, xb, noise, tape, handle, training):
-    return [dy.new_empty(p.shape, dtype=F32) for p in module_of(handle)._param_list()]
+    mod = module_of(handle)
+    n = mod.num_experts + 1
+    a = mod.shared_expert
+    f = lambda *s: dy.new_empty(s, dtype=F32)
+    return [f(*mod.norm.weight.shape), f(*mod.router.weight.shape), f(n, *a.fc1.weight.shape), f(n, *a.fc1.bias.shape),
+            f(n, *a.fc2.weight.shape), f(n, *a.fc2.bias.shape)]
 
 
 def _moe_setup(ctx, inputs, output):
@@ -238,8 +245,12 @@ def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
     if dy is None:
         dy = torch.zeros((xb.shape[0], module_of(ctx.handle).get_output_length(xb.shape[1]), module_of(ctx.handle).llm_dim),
                          device=xb.device, dtype=F32)
-    grads = torch.ops.ta355.moe_projector_backward(dy, d_aux, xb, noise, tape, ctx.handle, ctx.training)
-    return None, None, list(grads), None, None
+    g_norm, g_router, GW1, Gb1, GW2, Gb2 = torch.ops.ta355.moe_projector_backward(dy, d_aux, xb, noise, tape, ctx.handle,
+                                                                                   ctx.training)
+    grads = [g_norm, g_router]                                # the order of MoEAudioProjector._param_list()
+    for i in range(GW1.shape[0]):
+        grads += [GW1[i], Gb1[i], GW2[i], Gb2[i]]
+    return None, None, grads, None, None
 
 
 moe_projector.register_autograd(_moe_bwd, setup_context=_moe_setup)
