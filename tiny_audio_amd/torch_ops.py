@@ -144,10 +144,13 @@ def _(dy, xb, tape, handle):
 
 def _mlp_setup(ctx, inputs, output):
     ctx.handle = inputs[5]
+    ctx.set_materialize_grads(False)         # or autograd zero-fills a gradient for the saved-state outputs (xb, tape) every step
     ctx.save_for_backward(output[1], output[2])
 
 
 def _mlp_bwd(ctx, dy, _dxb, _dtape):
+    if dy is None:
+        return (None,) * 6
     xb, tape = ctx.saved_tensors
     dW1, dg1, dW2, dg2 = torch.ops.ta355.mlp_projector_backward(dy, xb, tape, ctx.handle)
     return None, dW1, dg1, dW2, dg2, None
@@ -234,10 +237,13 @@ def _(dy, d_aux, xb, noise, tape, handle, training):
 def _moe_setup(ctx, inputs, output):
     x, noise, params, handle, training = inputs
     ctx.handle, ctx.training, ctx.has_noise, ctx.n_params = handle, training, noise is not None, len(params)
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(output[2], output[3], *([noise] if noise is not None else []))
 
 
 def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
+    if dy is None and d_aux is None:
+        return None, None, [None] * ctx.n_params, None, None
     xb, tape, *rest = ctx.saved_tensors
     noise = rest[0] if ctx.has_noise else None
     if d_aux is None:
@@ -311,11 +317,16 @@ def _lm_setup(ctx, inputs, output):
     (audio, trainable, handle, input_ids, src_row, kmask, label_rows, _targets, n_label_rows, _scale, _want) = inputs
     ctx.handle, ctx.n_label_rows, ctx.n_audio, ctx.n_train = handle, n_label_rows, audio.shape[0], len(trainable)
     ctx.want_d_audio = audio.requires_grad
+    # without this autograd materialises ZERO gradients for the unused outputs on every backward -- the tape alone is
+    # 8.9 GB at B = 32 (a 1.35 ms fill per step, measured), the workspace 1.2 GB
+    ctx.set_materialize_grads(False)
     ctx.present = [t is not None for t in (src_row, kmask, label_rows)]
     ctx.save_for_backward(output[3], output[4], input_ids, *[t for t in (src_row, kmask, label_rows) if t is not None])
 
 
 def _lm_bwd(ctx, g_loss, _g_nll, _g_logits, _g_tape, _g_ws):
+    if g_loss is None:                                        # the loss was not used
+        return (None, [None] * ctx.n_train) + (None,) * 9
     tape, ws, ids, *rest = ctx.saved_tensors
     it = iter(rest)
     src_row, kmask, label_rows = (next(it) if p else None for p in ctx.present)
