@@ -27,3 +27,16 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _poison_free_gpu_memory(request):
+    """-m gpu tests: fill the allocator's free pool with NaN bit patterns before every test, so that a kernel reading memory
+    nobody wrote (workspace padding rows, an unwritten gradient slice ...) fails loudly instead of depending on what ran before."""
+    if "gpu" in request.keywords:
+        import torch
+        if torch.cuda.is_available():
+            blocks = [torch.full((64 * 1024 * 1024,), float("nan"), device="cuda") for _ in range(4)]    # 4 x 256 MB
+            small = [torch.full((n,), float("nan"), device="cuda") for n in (256, 4096, 65536, 1 << 20) for _ in range(8)]
+            del blocks, small
+    yield

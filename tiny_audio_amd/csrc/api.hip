@@ -54,6 +54,10 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   const int M = B * S;
   EncWs e = enc_carve(w, B, T, ws);
   if ((long)e.bytes > ws_bytes) return TA_ERR_ARG;
+  // The strided attention reads Lp = pad64(S) key columns per clip from the V^T image [H, M]: past a clip's S columns come
+  // the next clip's (finite, masked), and past the LAST row of the image the 128-element slack behind it -- masked as well,
+  // but P = 0 times a NaN bit pattern is NaN, so the slack must hold finite values: zero it (the GEMMs never write it)
+  if (hipMemsetAsync(e.qkv + (size_t)M * 3 * H, 0, 128 * sizeof(bf16_t), st) != hipSuccess) return TA_ERR_LAUNCH;
   // conv front end as two row-mapped GEMMs over zero-padded time-major buffers
   RC(ta_feats_to_time_major(feats, e.x0, B, NM, T, st));
   RC(ta_zero_pad_rows(e.x1, B, T, H, st));

@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 // Hazards: every wave drains its own DMA (vmcnt 0) at the end of L(t,1), i.e. before barrier 4t+3 (group 0) /
 // 4t+4 (group 1), and the first read of tile t+1 is after barrier 4t+4; the last reads of tile t-1 (group 1's
 // L(t-1,1)) retire (lgkmcnt 0) before barrier 4t, and the first DMA into that buffer is issued after it.
-template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool PP, bool KEXT = false>
+// TIMING (experiments, variant 8): s_memtime stamps around the L / barrier / C / barrier phases of every interval; instead
+// of the epilogue every wave writes its five cycle sums {L, wait for barrier 1, C, wait for barrier 2, whole loop} to C.
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool PP, bool KEXT = false, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   constexpr int BM2 = 256;
   constexpr int NT = BN2 / 64;                 // n-fragments per wave
@@ -458,6 +460,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   if constexpr (PP) {
     const int lag = __builtin_amdgcn_readfirstlane(wm);     // SGPR: scalar branches around the extra barriers
     if (lag) __builtin_amdgcn_s_barrier();
+    unsigned long long tL = 0, tB1 = 0, tC = 0, tB2 = 0, tAll = 0;
+    if (TIMING) tAll = __builtin_amdgcn_s_memtime();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int cur = (kt - kt_begin) & 1;
       const bool more = kt + 1 < kt_end;
@@ -467,6 +471,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ko = kk ? koff1 : koff0;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (TIMING) s0 = __builtin_amdgcn_s_memtime();
         // ---- L(t, kk)
 #pragma unroll
         for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
@@ -484,9 +490,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
+        if (TIMING) { s1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (TIMING) { s2 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         // ---- C(t, kk)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -496,9 +504,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (TIMING) { s3 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (TIMING) {
+          const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          tL += s1 - s0; tB1 += s2 - s1; tC += s3 - s2; tB2 += s4 - s3;
+        }
       }
+    }
+    if (TIMING) {
+      tAll = __builtin_amdgcn_s_memtime() - tAll;
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (lane == 0) {
+        unsigned long long* o = (unsigned long long*)p.C + ((long)blockIdx.x * 8 + wave) * 8;
+        o[0] = tL; o[1] = tB1; o[2] = tC; o[3] = tB2; o[4] = tAll; o[5] = (unsigned long long)(kt_end - kt_begin);
+        o[6] = sacc == 1234.5678f;
+      }
+      return;
     }
     if (!lag) __builtin_amdgcn_s_barrier();
   } else {
@@ -753,7 +781,7 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 7) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
+  if (forced >= 0 && forced <= 8) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -776,7 +804,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int variant = pick_variant(a.M, a.N, a.splits);
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
   const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256);
-  const int bn = (variant == 4 || variant == 7) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
+  if (variant == 8 && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
+  const int bn = (variant == 4 || variant == 7 || variant == 8) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
@@ -813,6 +842,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 8) {
+    if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) TA_LAUNCH((gemm_nt_kernel_v2<320, 0, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+  }
   else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
   else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
