@@ -480,3 +480,35 @@ def test_model_output_is_trainer_compatible():
     assert isinstance(o, dict) and o["loss"] is o.loss is o[0] and o.n_label_tokens == 3 and o.logits is None
     with pytest.raises(AttributeError):
         o.nope
+
+
+def test_hub_snapshot_loaders(tmp_path):
+    """The frozen models' weights from local hub snapshots: sharded safetensors, the audio_tower sub-tree of the GLM-ASR
+    checkpoint (tiny_audio/asr_modeling.py:221-231), Qwen3 with its tied lm_head dropped and an oversized embedding."""
+    import json
+    from safetensors.torch import save_file
+    from oracle import weights as OW
+    from tiny_audio_amd import hub_weights
+    enc = OW.enc_config(hidden=128, ffn=256, layers=1, heads=2)
+    w = {k: torch.from_numpy(v) for k, v in OW.init_encoder(enc, 0).items()}
+    d = tmp_path / "glm"; d.mkdir()
+    names = sorted(w)
+    a = {"audio_tower." + k: w[k] for k in names[: len(names) // 2]}
+    b = {"audio_tower." + k: w[k] for k in names[len(names) // 2:]}
+    b["language_model.model.embed_tokens.weight"] = torch.zeros(4, 4)            # the GLM decoder: must be ignored
+    b["multi_modal_projector.linear_1.weight"] = torch.zeros(4, 4)
+    save_file(a, str(d / "model-00001-of-00002.safetensors")); save_file(b, str(d / "model-00002-of-00002.safetensors"))
+    json.dump({"weight_map": {**{k: "model-00001-of-00002.safetensors" for k in a}, **{k: "model-00002-of-00002.safetensors" for k in b}}},
+              open(d / "model.safetensors.index.json", "w"))
+    sd = hub_weights.encoder_state_dict(str(d))
+    assert set(sd) == set(w) and all(torch.equal(sd[k], w[k]) for k in w)
+    lm = OW.lm_config(vocab=300, hidden=64, ffn=128, layers=1, heads=2, kv_heads=1)
+    wl = {k: torch.from_numpy(v) for k, v in OW.init_lm(lm, 1).items()}
+    wl["model.embed_tokens.weight"] = torch.cat([wl["model.embed_tokens.weight"], torch.ones(20, 64)], 0)      # hub padding rows
+    wl["lm_head.weight"] = wl["model.embed_tokens.weight"].clone()
+    q = tmp_path / "qwen"; q.mkdir()
+    save_file(wl, str(q / "model.safetensors"))
+    sl = hub_weights.lm_state_dict(str(q))
+    assert "lm_head.weight" not in sl and sl["model.embed_tokens.weight"].shape == (320, 64)
+    with pytest.raises(KeyError):
+        hub_weights.encoder_state_dict(str(q))
