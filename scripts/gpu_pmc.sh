@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC counter passes (separate runs, --kernel-trace only: no sys/hip trace) on a command; CSVs -> gpurun_out/pmc_<tag>/
+# Rows of kernels the summary does not use (torch's init kernels, ...) are dropped on the box: the merge back is capped at 64 MiB.
 TAG=${1:-r1}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
@@ -13,5 +14,17 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_C
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT -o pass$i -- $CMD > $OUT/pass$i.log 2>&1
   echo "pass $i ($set) rc=$?"
+  rm -f $OUT/pass${i}_kernel_trace.csv
+  python - "$OUT/pass${i}_counter_collection.csv" <<'PY'
+import csv, sys
+p = sys.argv[1]
+keep = ("gemm_nt", "attn_", "lora_", "linear_small")
+with open(p) as f:
+    r = csv.reader(f); hdr = next(r); k = hdr.index("Kernel_Name")
+    rows = [row for row in r if any(s in row[k] for s in keep)]
+with open(p, "w", newline="") as f:
+    w = csv.writer(f, quoting=csv.QUOTE_ALL); w.writerow(hdr); w.writerows(rows)
+print(p, len(rows), "rows kept")
+PY
 done
-ls $OUT | head -30
+du -sh $OUT

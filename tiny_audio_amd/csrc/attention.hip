@@ -485,13 +485,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT,
-                                                          const bf16_t* __restrict__ dO, long dO_stride,
-                                                          const float* __restrict__ LSE, const float* __restrict__ Delta,
-                                                          const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
-                                                          int B, int Hq, int Hkv, int L, int Lp, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                 const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT,
+                                                 const bf16_t* __restrict__ dO, long dO_stride,
+                                                 const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                 const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
+                                                 int B, int Hq, int Hkv, int L, int Lp, float scale) {
   char* Ks = smem;
   char* Vs = Ks + RowTile<HD>::BYTES;
   char* KTs = Vs + RowTile<HD>::BYTES;
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int nq = (L + 63) / 64, grp = Hq / Hkv;
   int group, member;
-  if (!decode_group(blockIdx.x, grp * nq, B * Hkv, group, member)) return;
+  if (!decode_group(block_id, grp * nq, B * Hkv, group, member)) return;
   const int b = group / Hkv, hk = group % Hkv;
   const int h = hk * grp + member / nq, qt = member % nq;
   const int qrow = qt * 64 + wave * 16 + l15;
@@ -582,15 +581,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // grid (key tiles, Hkv, B); loops over the Hq/Hkv query heads of the group and over query tiles.
 //   dV^T[d,key] += dO^T[d,q] P[q,key]      dK^T[d,key] += Q^T[d,q] dS[q,key]
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
-                                                           const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-                                                           const bf16_t* __restrict__ dO, long dO_stride,
-                                                           const bf16_t* __restrict__ dOT,
-                                                           const float* __restrict__ LSE, const float* __restrict__ Delta,
-                                                           const int* __restrict__ kmask, bf16_t* __restrict__ dK,
-                                                           bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
-                                                           float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
+                                                  const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                  const bf16_t* __restrict__ dO, long dO_stride,
+                                                  const bf16_t* __restrict__ dOT,
+                                                  const float* __restrict__ LSE, const float* __restrict__ Delta,
+                                                  const int* __restrict__ kmask, bf16_t* __restrict__ dK,
+                                                  bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
+                                                  float scale) {
   char* Qs = smem;
   char* dOs = Qs + RowTile<HD>::BYTES;
   char* QTs = dOs + RowTile<HD>::BYTES;
@@ -600,7 +598,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int grp = Hq / Hkv;
   int group, kt_idx;
-  if (!decode_group(blockIdx.x, (L + 63) / 64, B * Hkv, group, kt_idx)) return;
+  if (!decode_group(block_id, (L + 63) / 64, B * Hkv, group, kt_idx)) return;
   const int b = group / Hkv, hk = group % Hkv;
   const int krow = kt_idx * 64 + wave * 16 + l15;
   const int kr = krow < L ? krow : L - 1;
@@ -696,6 +694,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   }
 }
 
+// One launch for both halves of the backward: blocks [0, n_dkv) run the dK / dV body, the rest the dQ body.  The two
+// are independent (both only read Q, K, V, dO), so a single grid lets the dQ workgroups fill the CUs while the longer
+// dK / dV ones drain, without a second stream or a kernel boundary in between.  The heavier dK / dV blocks go first.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
+                                                       const bf16_t* __restrict__ K, const bf16_t* __restrict__ KT,
+                                                       const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, long dO_stride,
+                                                       const bf16_t* __restrict__ dOT, const float* __restrict__ LSE,
+                                                       const float* __restrict__ Delta, const int* __restrict__ kmask,
+                                                       bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
+                                                       int B, int Hq, int Hkv, int L, int Lp, float scale, int n_dkv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < n_dkv)
+    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale);
+  else
+    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale);
+}
+
 // ----------------------------------------------------------------------------- C-ABI
 template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + (HD + 16) * CT_STRIDE + 64 * 4; }
 
@@ -760,26 +776,35 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
   const size_t lds_kv = 2 * RowTile<HD>::BYTES + 2 * ColTile<HD>::BYTES + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     attr_done = true;
   }
-  dim3 gq(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv)), gk(grouped_grid(ta_cdiv(L, 64), B * Hkv)), blk(256);
-  if (causal) {
-    TA_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
-                       (bf16_t*)dQ, B, Hq, Hkv, L, Lp, scale);
-    TA_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
-                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
-                       kmask, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale);
-  } else {
-    TA_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, blk, lds_q, st, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)V, (const bf16_t*)KT, (const bf16_t*)dO, dO_stride, LSE, Delta, kmask,
-                       (bf16_t*)dQ, B, Hq, Hkv, L, Lp, scale);
-    TA_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT,
-                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta,
-                       kmask, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale);
-  }
+  const int n_dq = grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv), n_dkv = grouped_grid(ta_cdiv(L, 64), B * Hkv);
+  (void)lds_q;
+  dim3 grid(n_dq + n_dkv), blk(256);
+  static const bool split = [] { const char* e = getenv("TA355_ATTN_BWD_MERGED"); return e && *e == '0'; }();   // experiment: two launches
+  if (split) {
+    // the same bodies as two launches: n_dkv = grid (all dK / dV) resp. n_dkv = 0 (all dQ)
+    if (causal) {
+      TA_LAUNCH((attn_bwd_kernel<HD, true>), dim3(n_dq), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, 0);
+      TA_LAUNCH((attn_bwd_kernel<HD, true>), dim3(n_dkv), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
+    } else {
+      TA_LAUNCH((attn_bwd_kernel<HD, false>), dim3(n_dq), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, 0);
+      TA_LAUNCH((attn_bwd_kernel<HD, false>), dim3(n_dkv), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
+    }
+  } else if (causal)
+    TA_LAUNCH((attn_bwd_kernel<HD, true>), grid, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+              (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK,
+              (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
+  else
+    TA_LAUNCH((attn_bwd_kernel<HD, false>), grid, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
+              (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK,
+              (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

@@ -5,6 +5,7 @@
 //   rmsnorm_fwd_kernel   Qwen3RMSNorm / LlamaRMSNorm            (TF:models/qwen3/modeling_qwen3.py:50-64;
 //                        tiny_audio/projectors.py:43,50), optionally fused with the projector's erf-GELU
 //   rmsnorm_bwd_kernel   its backward (dx, optional dw, optional GELU' prologue, optional residual add)
+#include <cstdlib>
 #include "common.h"
 
 #define MAXV_LIMIT 20   // float4 per lane -> rows up to 64*4*20 = 5120 columns
@@ -65,6 +66,55 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         ((uint2*)(yb + (long)row * H))[c] = p;
       }
     }
+  }
+}
+
+
+// bf16 -> bf16 LayerNorm with 16-byte accesses: HALF a wave per row (32 lanes x NCH chunks of 8 columns, H = 256 * NCH),
+// two rows per wave, eight per workgroup.  The encoder's two LayerNorms per layer read and write the bf16 residual stream
+// (82 MB per call at B = 32): halving the number of memory instructions per byte is what this variant is for.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                               const float* __restrict__ rowscale, int M, float eps) {
+  constexpr int H = NCH * 256;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const int l = threadIdx.x & 31;
+  const uint4* xr = (const uint4*)(x + (long)row * H);
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const uint4 u = xr[l + i * 32];
+    const uint32_t q[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[i][2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[i][2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); s += v[i][2 * j] + v[i][2 * j + 1]; }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);          // lanes 0-31 / 32-63 reduce separately
+  const float mean = s / (float)H;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q2 += d * d; }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+  const float rstd = rsqrtf(q2 / (float)H + eps);
+  const float rs = rowscale ? rowscale[row] : 1.0f;
+  uint4* yr = (uint4*)(y + (long)row * H);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (l + i * 32) * 8;
+    const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + c + 4);
+    const float4 b0 = *(const float4*)(b + c), b1 = *(const float4*)(b + c + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ((v[i][j] - mean) * rstd * ww[j] + bb[j]) * rs;
+    yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
   }
 }
 
@@ -201,6 +251,18 @@ extern "C" int ta_layernorm_bf16(const void* x_bf16, const float* w, const float
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT || (!y_bf16 && !y_f32)) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
   const float* x = (const float*)x_bf16;
+  // bf16 -> bf16 only, H a multiple of 256 up to 2048: the 16-byte half-wave-per-row variant (TA355_LN_WIDE=0: the generic one)
+  static const bool ln_wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
+  if (ln_wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
+    dim3 g8(ta_cdiv(M, 8));
+    switch (H / 256) {
+#define LNW(N) case N: TA_LAUNCH((layernorm_bf16x8_kernel<N>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); break;
+      LNW(1) LNW(2) LNW(3) LNW(4) LNW(5) LNW(6) LNW(7) LNW(8)
+#undef LNW
+    }
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
 #define LNB_CALL(V)                                                                                              \
   if (y_bf16 && y_f32)                                                                                           \
     TA_LAUNCH((layernorm_kernel<V, true, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
