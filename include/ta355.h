@@ -35,7 +35,7 @@ int ta_version(void); /* ABI version, currently 1 */
  *      (TF:models/whisper/feature_extraction_whisper.py:135-168,330-339).
  * wav [B, Ls] f32 zero-padded to the longest clip, lens [B] true sample counts.
  * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once.
- * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.  clip_max_ws: int[B]. */
+ * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.  clip_max_ws: int[B + 2 * n_mels] scratch. */
 int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
                   const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st);
 

@@ -79,7 +79,7 @@ class LogMelFeatureExtractor:
         T = Ls // HOP
         feats = torch.empty((B, self.feature_size, T), device=self.device, dtype=F32)
         mask = torch.empty((B, T), device=self.device, dtype=torch.int32)
-        cm = torch.empty(B, device=self.device, dtype=torch.int32)
+        cm = torch.empty(B + 2 * self.feature_size, device=self.device, dtype=torch.int32)     # clip maxima + mel bin ranges
         _lib.check(_lib.lib().ta_logmel_f32(ptr(wav), ptr(lens), B, Ls, ptr(self._dft), ptr(self._win), ptr(self._mel),
                                             self.feature_size, ptr(feats), ptr(mask), ptr(cm), stream()), "ta_logmel_f32")
         return feats, mask

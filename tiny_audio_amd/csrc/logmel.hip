@@ -8,6 +8,7 @@
 // an FFT (see logmel_power_kernel).  The clip maximum is an atomicMax on an
 // order-preserving integer image of the float; a second tiny kernel applies floor/scale (the only
 // second pass over the 512 KB/clip output).
+#include <cstdlib>
 #include "common.h"
 
 #define NFFT 400
@@ -142,9 +143,237 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(const float* __restri
   if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
 }
 
-__global__ void logmel_init_kernel(int* clip_max, int B) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) clip_max[i] = f2ord(-INFINITY);
+
+// ============================================================================ FFT form (default)
+// The 400-point transform as a mixed-radix FFT, 400 = 16 x 25 = (4 x 4) x (5 x 5), in f32 on the VALU: 17 MFLOP per clip
+// instead of the 322 MFLOP of the DFT-as-GEMM above, which makes the stage what the north star asks of it -- bound by its
+// 1.15 MB of HBM traffic per clip, not by arithmetic.  (f32 FFT error ~1e-7 of the largest bin, below the O(N) error of a
+// direct f32 summation; same 5e-4 tolerance against the reference's torch.stft as before.)
+//   X[k1 + 16 k2] = sum_{n2} W25^{n2 k2} * ( W400^{n2 k1} * sum_{n1} W16^{n1 k1} z[25 n1 + n2] )
+// Two REAL frames ride in one complex transform, z = w * (x_a + i x_b):  X_a[k] = (Z[k] + conj Z[400-k]) / 2,
+// X_b[k] = (Z[k] - conj Z[400-k]) / 2i.  One workgroup = 64 frames of one clip (the waveform span of those frames is staged
+// once: 10 480 samples instead of 64 x 400 windowed copies); each wave transforms 4 frame pairs at a time:
+//   stage A  lane = (pair, n2): 16 samples of both frames from the span, windowed; 16-point FFT in registers (two radix-4
+//            passes); twiddle; Y[pair][k1][n2] to the wave's LDS scratch
+//   stage B  lane = (pair, k1): 25-point FFT in registers (two radix-5 passes); Z[pair][k] back to the same scratch
+//   combine  lane = (pair, k <= 200): the two frames' powers -> pw[frame][k]
+// then, as before, the mel bank (each filter over its own bin range only), log10, clip maximum, coalesced write-out.
+#include "logmel_twiddles.h"
+struct cpx { float re, im; };
+__device__ __forceinline__ cpx cmul(cpx a, float wr, float wi) { return {a.re * wr - a.im * wi, a.re * wi + a.im * wr}; }
+__device__ __forceinline__ void dft4(const cpx a0, const cpx a1, const cpx a2, const cpx a3, cpx& o0, cpx& o1, cpx& o2, cpx& o3) {
+  const cpx s02 = {a0.re + a2.re, a0.im + a2.im}, d02 = {a0.re - a2.re, a0.im - a2.im};
+  const cpx s13 = {a1.re + a3.re, a1.im + a3.im}, d13 = {a1.re - a3.re, a1.im - a3.im};
+  o0 = {s02.re + s13.re, s02.im + s13.im};
+  o2 = {s02.re - s13.re, s02.im - s13.im};
+  o1 = {d02.re + d13.im, d02.im - d13.re};          // d02 - i d13
+  o3 = {d02.re - d13.im, d02.im + d13.re};          // d02 + i d13
+}
+__device__ __forceinline__ void dft5(const cpx x0, const cpx x1, const cpx x2, const cpx x3, const cpx x4, cpx& o0, cpx& o1, cpx& o2,
+                                     cpx& o3, cpx& o4) {
+  const cpx t1 = {x1.re + x4.re, x1.im + x4.im}, t2 = {x2.re + x3.re, x2.im + x3.im};
+  const cpx t3 = {x1.re - x4.re, x1.im - x4.im}, t4 = {x2.re - x3.re, x2.im - x3.im};
+  o0 = {x0.re + t1.re + t2.re, x0.im + t1.im + t2.im};
+  const cpx m1 = {x0.re + R5_C1 * t1.re + R5_C2 * t2.re, x0.im + R5_C1 * t1.im + R5_C2 * t2.im};
+  const cpx m2 = {x0.re + R5_C2 * t1.re + R5_C1 * t2.re, x0.im + R5_C2 * t1.im + R5_C1 * t2.im};
+  const cpx n1 = {R5_S1 * t3.re + R5_S2 * t4.re, R5_S1 * t3.im + R5_S2 * t4.im};
+  const cpx n2 = {R5_S2 * t3.re - R5_S1 * t4.re, R5_S2 * t3.im - R5_S1 * t4.im};
+  o1 = {m1.re + n1.im, m1.im - n1.re};              // m1 - i n1
+  o4 = {m1.re - n1.im, m1.im + n1.re};              // m1 + i n1
+  o2 = {m2.re + n2.im, m2.im - n2.re};
+  o3 = {m2.re - n2.im, m2.im + n2.re};
+}
+// in-register 16-point FFT: n1 = 4p + q, k1 = r + 4s
+__device__ __forceinline__ void fft16(cpx* a) {
+  cpx u[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dft4(a[q], a[4 + q], a[8 + q], a[12 + q], u[q][0], u[q][1], u[q][2], u[q][3]);
+#pragma unroll
+    for (int r = 1; r < 4; ++r)
+      if (q > 0) u[q][r] = cmul(u[q][r], W16Q_RE[q][r], W16Q_IM[q][r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dft4(u[0][r], u[1][r], u[2][r], u[3][r], a[r], a[r + 4], a[r + 8], a[r + 12]);
+}
+// in-register 25-point FFT: n2 = 5p + q, k2 = r + 5s
+__device__ __forceinline__ void fft25(cpx* y) {
+  cpx u[5][5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    dft5(y[q], y[5 + q], y[10 + q], y[15 + q], y[20 + q], u[q][0], u[q][1], u[q][2], u[q][3], u[q][4]);
+#pragma unroll
+    for (int r = 1; r < 5; ++r)
+      if (q > 0) u[q][r] = cmul(u[q][r], W25Q_RE[q][r], W25Q_IM[q][r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 5; ++r) dft5(u[0][r], u[1][r], u[2][r], u[3][r], u[4][r], y[r], y[r + 5], y[r + 10], y[r + 15], y[r + 20]);
+}
+
+#define LF_PWS 201                          // power row stride (odd: the mel stage's reads spread over the banks)
+// LFT frames per workgroup (4 waves), LF_G frame pairs per wave at once.  <64, 4> fills every lane of stage B but needs
+// 150 KB of LDS (one workgroup, i.e. one wave per SIMD, per CU); <32, 2> needs 78 KB: two workgroups per CU.
+template <int LFT, int LF_G>
+__global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict__ wav, int Ls, const float* __restrict__ dft,
+                                                         const float* __restrict__ window, const float* __restrict__ melfb,
+                                                         int n_mels, float* __restrict__ out, int* __restrict__ clip_max, int T, int dbg,
+                                                         const int* __restrict__ mrange_g) {
+  constexpr int LF_SPAN = (LFT - 1) * HOP + NFFT, LF_SCR = LF_G * NFFT * 2, LF_MELS = LFT + 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* span = lds;                              // [LF_SPAN]            (later: melbuf [n_mels][LF_MELS])
+  float* scr = span + LF_SPAN;                    // [4 waves][LF_SCR]
+  float* pw = scr + 4 * LF_SCR;                   // [FT][LF_PWS]
+  float* win = pw + LFT * LF_PWS;                  // [NFFT]
+  float* tw = win + NFFT;                         // [NFFT][2] = W400^j
+  int* mrange = (int*)(tw + 2 * NFFT);            // [n_mels][2] first / end bin of every mel filter
+  const int b = blockIdx.y, t0 = blockIdx.x * LFT, tid = threadIdx.x;
+  const float* w = wav + (long)b * Ls;
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+  if (dbg & 4) ts[0] = __builtin_amdgcn_s_memtime();
+  // the span in batches of 8 independent loads per thread (a load -> LDS store loop serialises on the HBM latency)
+  for (int j0 = tid; j0 < LF_SPAN; j0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * 256;
+      int sidx = t0 * HOP + j - NFFT / 2;         // index into the (virtually) reflect-padded signal
+      if (sidx < 0) sidx = -sidx;
+      if (sidx >= Ls) sidx = 2 * (Ls - 1) - sidx;
+      v[u] = (j < LF_SPAN && sidx >= 0 && sidx < Ls) ? w[sidx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256; if (j < LF_SPAN) span[j] = v[u]; }
+  }
+  if (dbg & 4) { __syncthreads(); ts[1] = __builtin_amdgcn_s_memtime(); }
+  for (int j = tid; j < NFFT; j += 256) {
+    win[j] = window[j];
+    // W400^j = cos(2 pi j / 400) - i sin(2 pi j / 400) from row n = 1 of the host's table (columns k <= 200; mirrored above)
+    const int jj = j <= 200 ? j : NFFT - j;
+    const float c = dft[2 * NBIN + jj], sn = dft[2 * NBIN + NBIN + jj];
+    tw[2 * j] = c; tw[2 * j + 1] = j <= 200 ? -sn : sn;
+  }
+  for (int i = tid; i < 2 * n_mels; i += 256) mrange[i] = mrange_g[i];     // per-filter bin ranges (logmel_init_kernel)
+  __syncthreads();
+  if (dbg & 4) ts[2] = __builtin_amdgcn_s_memtime();
+  const int wave = tid >> 6, lane = tid & 63;
+  float* my = scr + wave * LF_SCR;
+  for (int it = 0; it < ((dbg & 1) ? 0 : LFT / 2 / 4 / LF_G); ++it) {            // LFT / 2 pairs per workgroup, a quarter per wave, LF_G at a time
+    const int pair0 = wave * (LFT / 8) + it * LF_G;
+    // ---- stage A
+#pragma unroll 1
+    for (int pass = 0; pass < (LF_G * 25 + 63) / 64; ++pass) {
+      const int id = lane + 64 * pass;
+      if (id < LF_G * 25) {
+        const int g = id / 25, n2 = id - g * 25;
+        const int fa = 2 * (pair0 + g);
+        const bool va = t0 + fa < T, vb = t0 + fa + 1 < T;
+        const float* xa = span + fa * HOP + n2;
+        cpx a[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+          const float wv = win[25 * n1 + n2];
+          a[n1].re = va ? xa[25 * n1] * wv : 0.f;
+          a[n1].im = vb ? xa[HOP + 25 * n1] * wv : 0.f;
+        }
+        fft16(a);
+        float* dst = my + ((g * 16) * 25 + n2) * 2;
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+          cpx v = a[k1];
+          if (k1 > 0) {
+            const int j = n2 * k1;                                // < 400
+            v = cmul(v, tw[2 * j], tw[2 * j + 1]);
+          }
+          *(float2*)(dst + k1 * 50) = make_float2(v.re, v.im);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage B: lane = (pair g, k1)
+    if (lane < LF_G * 16) {
+      const int g = lane >> 4, k1 = lane & 15;
+      const float* src = my + ((g * 16 + k1) * 25) * 2;
+      cpx y[25];
+#pragma unroll
+      for (int n2 = 0; n2 < 25; ++n2) { const float2 v = *(const float2*)(src + 2 * n2); y[n2] = {v.x, v.y}; }
+      fft25(y);                                                   // (every active lane holds its inputs: in-order LDS per wave)
+      float* dst = my + (g * NFFT + k1) * 2;
+#pragma unroll
+      for (int k2 = 0; k2 < 25; ++k2) *(float2*)(dst + 32 * k2) = make_float2(y[k2].re, y[k2].im);     // k = k1 + 16 k2
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- combine: powers of the two real frames of every pair
+    for (int id = lane; id < LF_G * NBIN; id += 64) {
+      const int g = id / NBIN, k = id - g * NBIN;
+      const float2 z = *(const float2*)(my + (g * NFFT + k) * 2);
+      const float2 c = *(const float2*)(my + (g * NFFT + (k == 0 ? 0 : NFFT - k)) * 2);
+      const float ar = 0.5f * (z.x + c.x), ai = 0.5f * (z.y - c.y);
+      const float br = 0.5f * (z.y + c.y), bi = 0.5f * (c.x - z.x);
+      const int fa = 2 * (pair0 + g);
+      pw[fa * LF_PWS + k] = ar * ar + ai * ai;
+      pw[(fa + 1) * LF_PWS + k] = br * br + bi * bi;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                              // the next iteration overwrites the scratch
+  }
+  __syncthreads();
+  if (dbg & 4) ts[3] = __builtin_amdgcn_s_memtime();
+  // ---- mel + log10: thread = (mel bin m, group of frames), every filter over its own bins only
+  float* melbuf = span;                                           // [n_mels][LF_MELS]
+  float lmax = -INFINITY;
+  const int fgroups = 256 / n_mels;
+  const int m = tid % n_mels, fg = tid / n_mels, nf = LFT / fgroups;
+  const int klo = mrange[2 * m], khi = mrange[2 * m + 1];
+  for (int fb = 0; fb < nf; fb += 16) {
+    float am[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) am[q] = 0.f;
+    const int f0 = fg * nf + fb;
+    for (int kk = klo; kk < ((dbg & 2) ? klo : khi); ++kk) {
+      const float wgt = melfb[kk * n_mels + m];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) am[q] = fmaf(wgt, pw[(f0 + q) * LF_PWS + kk], am[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float v = log10f(fmaxf(am[q], 1e-10f));
+      melbuf[m * LF_MELS + f0 + q] = v;
+      if (t0 + f0 + q < T) lmax = fmaxf(lmax, v);
+    }
+  }
+  lmax = wave_max(lmax);
+  if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
+  __syncthreads();
+  if (dbg & 4) ts[4] = __builtin_amdgcn_s_memtime();
+  for (int i = tid; i < n_mels * LFT; i += 256) {                 // one mel row = LFT consecutive frames per store
+    const int r = i / LFT, f = i - r * LFT;
+    if (t0 + f < T) out[((long)b * n_mels + r) * T + t0 + f] = melbuf[r * LF_MELS + f];
+  }
+  if (dbg & 4) {                                                  // experiment: phase stamps of workgroup (5, 3) into the output
+    __syncthreads();
+    ts[5] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 3)
+      for (int i = 0; i < 6; ++i) out[i] = (float)(ts[i] - ts[0]);
+  }
+}
+
+// block n_mels: clip maxima := -inf.  block m < n_mels: {first, end} bin of mel filter m (its non-zero taps) -> mrange[2m..]:
+// the FFT kernel applies every filter over its own ~4 (low) to ~13 (high) bins instead of all 201.
+__global__ __launch_bounds__(256) void logmel_init_kernel(int* clip_max, int B, const float* __restrict__ melfb, int n_mels,
+                                                          int* __restrict__ mrange) {
+  if ((int)blockIdx.x == n_mels) {
+    for (int i = threadIdx.x; i < B; i += blockDim.x) clip_max[i] = f2ord(-INFINITY);
+    return;
+  }
+  __shared__ int lo_s, hi_s;
+  if (threadIdx.x == 0) { lo_s = NBIN; hi_s = 0; }
+  __syncthreads();
+  const int k = threadIdx.x, m = blockIdx.x;
+  if (k < NBIN && melfb[k * n_mels + m] != 0.f) { atomicMin(&lo_s, k); atomicMax(&hi_s, k + 1); }
+  __syncthreads();
+  if (threadIdx.x == 0) { mrange[2 * m] = lo_s; mrange[2 * m + 1] = hi_s; }
 }
 
 // x = (max(x, clipmax - 8) + 4) / 4 in place; also the frame mask [B, T]: 1 iff t*160 < len[b]
@@ -161,15 +390,35 @@ __global__ void logmel_finalize_kernel(float* __restrict__ out, const int* __res
 }
 
 // wav f32 [B, Ls] (zero-padded to the longest clip), lens int64 [B] -> feats f32 [B, n_mels, T], mask i32 [B, T],
-// T = Ls / 160.  clip_max_ws: int[B] workspace.
+// T = Ls / 160.  clip_max_ws: int[B + 2 * n_mels] workspace (clip maxima, then the bin range of every mel filter).
 extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
                              const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st) {
   if (B <= 0) return TA_OK;
   const int T = Ls / HOP;
   if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256)) return TA_ERR_ARG;
-  TA_LAUNCH(logmel_init_kernel, dim3(ta_cdiv(B, 256)), dim3(256), 0, st, clip_max_ws, B);
-  TA_LAUNCH(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
-                     feats, clip_max_ws, T);
+  int* mrange_ws = clip_max_ws + B;                 // [2 * n_mels] behind the clip maxima
+  TA_LAUNCH(logmel_init_kernel, dim3(n_mels + 1), dim3(256), 0, st, clip_max_ws, B, melfb, n_mels, mrange_ws);
+  // TA355_LOGMEL_DFT=1: the exact-f32 DFT-as-GEMM form (bit-for-bit a scalar fmaf chain) instead of the mixed-radix FFT
+  static const bool use_dft = [] { const char* e = getenv("TA355_LOGMEL_DFT"); return e && *e == '1'; }();
+  if (use_dft) {
+    TA_LAUNCH(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
+              feats, clip_max_ws, T);
+  } else {
+    static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
+    static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
+    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4; };
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
+      (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
+      attr = true;
+    }
+    // the mel stage works on groups of 16 frames per thread: LFT / (256 / n_mels) >= 16 holds for <32, 2> only at n_mels = 128
+    if (big || n_mels != 128)
+      TA_LAUNCH((logmel_fft_kernel<64, 4>), dim3(ta_cdiv(T, 64), B), dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_max_ws, T, dbg, mrange_ws);
+    else
+      TA_LAUNCH((logmel_fft_kernel<32, 2>), dim3(ta_cdiv(T, 32), B), dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_max_ws, T, dbg, mrange_ws);
+  }
   int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
   TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_max_ws, lens, mask, n_mels, T);
   TA_CHECK_LAUNCH();

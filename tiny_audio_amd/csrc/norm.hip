@@ -118,6 +118,47 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __r
   }
 }
 
+
+// bf16 -> bf16 RMSNorm (the LM's residual stream) with 16-byte accesses, half a wave per row: same layout idea as
+// layernorm_bf16x8_kernel.  H = 256 * NCH.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                 bf16_t* __restrict__ y, float* __restrict__ rstd_out, int M,
+                                                                 float eps) {
+  constexpr int H = NCH * 256;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const int l = threadIdx.x & 31;
+  const uint4* xr = (const uint4*)(x + (long)row * H);
+  float v[NCH][8];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const uint4 u = xr[l + i * 32];
+    const uint32_t t[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[i][2 * j] = bf2f((bf16_t)(t[j] & 0xffff)); v[i][2 * j + 1] = bf2f((bf16_t)(t[j] >> 16));
+      q += v[i][2 * j] * v[i][2 * j] + v[i][2 * j + 1] * v[i][2 * j + 1];
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)H + eps);
+  if (rstd_out && l == 0) rstd_out[row] = rstd;
+  uint4* yr = (uint4*)(y + (long)row * H);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (l + i * 32) * 8;
+    const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + c + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * ww[j];
+    yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
 // y = w * (x * rstd)   [ACT==1: y = gelu(y)];  x f32 [M,H]
 template <int MAXV, int ACT, bool IN_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -314,6 +355,17 @@ extern "C" int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_b
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
   const float* x = (const float*)x_bf16;
+  static const bool wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
+  if (wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
+    dim3 g8(ta_cdiv(M, 8));
+    switch (H / 256) {
+#define RFW(N) case N: TA_LAUNCH((rmsnorm_fwd_bf16x8_kernel<N>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, (bf16_t*)y_bf16, rstd, M, eps); break;
+      RFW(1) RFW(2) RFW(3) RFW(4) RFW(5) RFW(6) RFW(7) RFW(8)
+#undef RFW
+    }
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
 #define RFB_CALL(V) TA_LAUNCH((rmsnorm_fwd_kernel<V, 0, true>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps);
   DISPATCH_MAXV(H, RFB_CALL);
   TA_CHECK_LAUNCH();
