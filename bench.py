@@ -298,7 +298,7 @@ def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
     out = {"layernorm_kernel (encoder, bf16 residual stream in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 4),
            "rmsnorm_fwd_kernel (LM, bf16 residual stream in -> bf16 out: the variant the step runs)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 4 + Ml * 4),
            "swiglu_fwd_kernel (LM, bf16 gate|up -> bf16)": rate(lambda: ops.swiglu_fwd(gu, F), Ml * F * 6),
-           "logmel (f32 wav -> f32 [128, 1000]; exact-f32 DFT on v_mfma_f32_16x16x4_f32: matrix-core-bound, not HBM-bound)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000), reps=5)}
+           "logmel (f32 wav -> f32 [128, 1000]; mixed-radix 16x25 FFT, two frames per transform; LDS-latency-bound)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000), reps=5)}
     return out
 
 

@@ -34,7 +34,8 @@ int ta_version(void); /* ABI version, currently 1 */
  *      scripts/train.py:327-333 and tiny_audio/asr_processing.py:74-80
  *      (TF:models/whisper/feature_extraction_whisper.py:135-168,330-339).
  * wav [B, Ls] f32 zero-padded to the longest clip, lens [B] true sample counts.
- * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once.
+ * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once (dft is read only by the
+ *      exact-DFT variant, TA355_LOGMEL_DFT=1; the default is a 16 x 25 mixed-radix FFT with compiled-in twiddles).
  * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.  clip_max_ws: int[B + 2 * n_mels] scratch. */
 int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
                   const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st);

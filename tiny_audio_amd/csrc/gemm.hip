@@ -79,6 +79,17 @@ struct GemmArgs {
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
 
+// the same DMA in its scalar-base form: address = 64-bit uniform base (SGPR pair) + 32-bit per-lane byte offset; `lds` is the
+// wave-uniform LDS byte address (the hardware adds lane * 16).  Inline assembly: the builtin keeps 64-bit per-lane pointers.
+// The compiler does not count these loads: every wait for them is an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16_s(const char* base, unsigned off, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {   // pins a wave-uniform pointer into an SGPR pair
+  const unsigned long v = (unsigned long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long)hi << 32) | lo);
+}
 __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -241,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int m0 = pm * BMT, n0 = pn * BN;
 
   const int nkt = p.K / BK;
-  int kt_begin = (int)(((long)nkt * z) / p.splits);
-  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  int kt_begin = 0, kt_end = nkt;                  // 32-bit, and only when split: two 64-bit quotients cost ~2 k cycles per workgroup
+  if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
   if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;              // K extension (host guarantees splits == 1, no krange)
   int Mact = p.M, rbase = 0;
@@ -374,6 +385,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int g = lane >> 4, l15 = lane & 15;
+  const bool life = TIMING && (p.dbg & 4);      // experiment: stamps of the workgroup's life (entry, first tile landed, loop end, stores issued / acknowledged)
+  unsigned long long lf[5] = {0, 0, 0, 0, 0};
+  if (life) lf[0] = __builtin_amdgcn_s_memtime();
 
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
@@ -396,13 +410,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int m0 = pm * BM2, n0 = pn * BN2;
 
   const int nkt = p.K / BK;
-  int kt_begin = (int)(((long)nkt * z) / p.splits);
-  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  int kt_begin = 0, kt_end = nkt;                  // 32-bit, and only when split: two 64-bit quotients cost ~2 k cycles per workgroup
+  if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
   if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;
   if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
   int Mact = p.M, rbase = 0;
   if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
+  if ((p.dbg >> 8) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {   // experiment: first-round workgroups of every other CU start late,
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();        // so that epilogues (HBM bursts) and main loops (MFMA) of the rounds interleave
+    const unsigned long long wait = (unsigned long long)(p.dbg >> 8) << 8;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
 
   const int lr = tid >> 3;                                    // 0..63
   const int clog = (tid & 7) ^ ((lr >> 1) & 7);
@@ -457,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     for (int i = 0; i < NB; ++i) dma_w(lds_w, i);
   }
   __syncthreads();
+  if (life) lf[1] = __builtin_amdgcn_s_memtime();
   if constexpr (PP) {
     const int lag = __builtin_amdgcn_readfirstlane(wm);     // SGPR: scalar branches around the extra barriers
     if (lag) __builtin_amdgcn_s_barrier();
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
       for (int kk = 0; kk < 2; ++kk) {
         const int ko = kk ? koff1 : koff0;
         unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        if (TIMING) s0 = __builtin_amdgcn_s_memtime();
+        if (TIMING && !life) s0 = __builtin_amdgcn_s_memtime();
         // ---- L(t, kk)
 #pragma unroll
         for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
@@ -490,11 +510,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-        if (TIMING) { s1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        if (TIMING && !life) { s1 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (TIMING) { s2 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        if (TIMING && !life) { s2 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         // ---- C(t, kk)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -504,17 +524,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (TIMING) { s3 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        if (TIMING && !life) { s3 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (TIMING) {
+        if (TIMING && !life) {
           const unsigned long long s4 = __builtin_amdgcn_s_memtime();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           tL += s1 - s0; tB1 += s2 - s1; tC += s3 - s2; tB2 += s4 - s3;
         }
       }
     }
-    if (TIMING) {
+    if (TIMING && !life) {
       tAll = __builtin_amdgcn_s_memtime() - tAll;
       float sacc = 0.f;
 #pragma unroll
@@ -529,6 +549,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
       return;
     }
     if (!lag) __builtin_amdgcn_s_barrier();
+    if (life) lf[2] = __builtin_amdgcn_s_memtime();
   } else {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
@@ -572,6 +593,252 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
     epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp);
+  }
+  if (life) {                                   // behind the C matrix: [workgroup][wave group] x {5 stamps, HW_ID, XCC_ID, tile}
+    lf[3] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lf[4] = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (wave & 3) == 0) {
+      unsigned long long* o = (unsigned long long*)((char*)p.C + (long)p.M * p.ldc * 2) + ((long)blockIdx.x * 2 + wm) * 8;
+      for (int i = 0; i < 5; ++i) o[i] = lf[i];
+      o[5] = __builtin_amdgcn_s_getreg(63492);  // HW_REG_HW_ID
+      o[6] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+      o[7] = (unsigned long long)bid;
+    }
+  }
+}
+
+
+// ============================================================================ v4: the ping-pong tile as a PERSISTENT workgroup
+// Measured on v2 (scripts/gemm_wg_life.py, profiles/r02_gemm_wg_life.txt): of the ~90 k cycles a CU spends per 256x320 tile of a
+// K = 1280 GEMM, 70 k are the main loop; 9.4 k go to issuing the epilogue's stores (16 rows x 64 B per instruction: the
+// store path takes row segments, not bytes), 4.7 k to the prologue (address set-up + the first K tile's DMA latency) and
+// 5.0 k pass between one workgroup's last store and the next workgroup's first instruction on that CU.  v4 keeps v2's
+// main loop (same accumulation order: bit-identical results) and changes what surrounds it:
+//   * grid = min(tiles, CUs); workgroup b walks tiles b, b + grid, ... (the same tile -> XCD map as the plain launch order),
+//     so a CU never waits for a workgroup hand-over between rounds;
+//   * after the main loop BOTH stage buffers are free: the next tile's first K tile is DMA'd into stage 0 BEFORE the
+//     epilogue, whose latency it hides behind the stores;
+//   * the DMA sources are a uniform base pointer (SGPR pair, stepped along K by scalar adds) + one 32-bit byte offset per
+//     16-B chunk: 9 registers instead of 18 and no vector adds in the main loop (which is what makes room for the loop-carried
+//     state of a persistent workgroup next to 160 accumulator registers);
+//   * the epilogue is v2's (direct stores in the accumulator layout).  Staging the bf16 tile through LDS to store whole
+//     640-B rows was built and measured: a CU issues contiguous 1-KB stores at 46 B/clk against 22 B/clk for the 16 rows x
+//     64 B of the direct form (scripts/probe/store_rate.hip), but pack + ds_write + barrier + ds_read per 64-row pass cost
+//     more than the stores saved (10.3 k cycles per tile against 8.5 k), so it was removed.
+// Per tile of a K = 1280 GEMM: 0.7 k wait + 60.5 k main loop + 2.2 k next-tile set-up + ~8.5 k epilogue, against 90 k for v2.
+struct TileCtx { int ok, m0, n0, kb, ke, Mact, rbase, z; const bf16_t* Wp; const float* biasp; };
+template <int BM2, int BN2, bool KEXT>
+__device__ __forceinline__ TileCtx tile_ctx(const GemmArgs& p, int h, int total) {
+  TileCtx c; c.ok = 0;
+  int bid = h;
+  {
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  const int t = bid - z * tiles;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int* segp; const int* krp;
+  if (!resolve_group<BM2>(p, pm, z, segp, c.Wp, c.biasp, krp)) return c;
+  c.m0 = pm * BM2; c.n0 = pn * BN2; c.z = z;
+  const int nkt = p.K / BK;
+  c.kb = 0; c.ke = nkt;
+  if (p.splits > 1) { c.kb = (nkt * z) / p.splits; c.ke = (nkt * (z + 1)) / p.splits; }   // 32-bit: the 64-bit quotients of v2 cost ~2 k cycles per tile
+  if (krp) { c.kb = krp[0]; c.ke = krp[1]; }
+  if (KEXT) c.ke = nkt + p.K2 / BK;
+  if (p.dbg & 2) c.ke = min(c.ke, c.kb + 1);
+  c.Mact = p.M; c.rbase = 0;
+  if (segp) { c.rbase = segp[0]; c.Mact = segp[1]; if (c.m0 >= c.Mact) return c; }
+  c.ok = 1;
+  return c;
+}
+
+// LIFE (experiments, variant 9): s_memtime stamps of every tile {loop top, first K tile landed, loop end, next tile's DMA issued,
+// stores issued} + HW_ID / XCC_ID behind the C matrix (scripts/gemm_wg_life.py)
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool KEXT = false, bool LIFE = false>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
+  constexpr int BM2 = 256;
+  constexpr int NT = BN2 / 64;
+  constexpr int NA = BM2 / 64, NB = BN2 / 64;
+  constexpr int A_BYTES = BM2 * 128, STAGE = (BM2 + BN2) * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int total = p.tiles_m * p.tiles_n * p.splits;
+  const int nkt = p.K / BK;
+
+  const int lr = tid >> 3;
+  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
+  // DMA sources: a uniform base pointer that walks along K (scalar adds) + one 32-bit byte offset per 16-B chunk
+  // (operands < 4 GB, checked by the host): half the registers of per-chunk pointers and no vector adds in the main loop
+  const char* a_base; const char* w_base;
+  unsigned a_off[NA], w_off[NB];
+  const int w_step = p.w_blocked ? 8192 : BK * 2;
+  // wave-uniform LDS byte address of this wave's 1-KB DMA window in stage 0
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+  const int swz = l15 >> 1;
+  const int a_rd = (wm * 128 + l15) * 128;
+  const int b_rd = A_BYTES + (wn * (BN2 / 4) + l15) * 128;
+  const int koff0 = ((0 + g) ^ swz) << 4;
+  const int koff1 = ((4 + g) ^ swz) << 4;
+  const int lag = __builtin_amdgcn_readfirstlane(wm);
+
+  auto dma_tile = [&](unsigned base) {                          // one K tile of both operands; the bases step to the next one
+    const char* ab = uniform_ptr(a_base);
+    const char* wb = uniform_ptr(w_base);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) glds16_s(ab, a_off[i], base + i * 8192);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) glds16_s(wb, w_off[i], base + A_BYTES + i * 8192);
+    a_base += BK * 2; w_base += w_step;
+  };
+  auto ext_switch = [&](const TileCtx& c, int tile) {            // call before staging K-tile `tile` of tile context c
+    if (KEXT && tile == nkt) {
+      a_base = (const char*)p.A2; w_base = (const char*)p.W2;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        a_off[i] = (unsigned)(((long)(c.rbase + min(c.m0 + i * 64 + lr, c.Mact - 1)) * p.lda2 + clog * 8) * 2);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        w_off[i] = (unsigned)(((long)min(c.n0 + i * 64 + lr, p.N - 1) * p.K2 + clog * 8) * 2);
+    }
+  };
+  auto first_dma = [&](const TileCtx& c) {                      // sources of tile c + its first K tile into stage 0
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int gm = c.rbase + min(c.m0 + i * 64 + lr, c.Mact - 1);
+      if (p.a_idx) gm = p.a_idx[gm];
+      const long aoff = p.a_plain ? (long)gm * p.lda : (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
+      a_off[i] = (unsigned)((aoff + clog * 8) * 2);
+    }
+    a_base = (const char*)p.A + (long)c.kb * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int gn = min(c.n0 + i * 64 + lr, p.N - 1);
+      w_off[i] = p.w_blocked ? (unsigned)(((((long)(gn >> 6) * nkt) << 12) + ((gn & 63) << 6) + clog * 8) * 2)
+                             : (unsigned)(((long)gn * p.K + clog * 8) * 2);
+    }
+    w_base = (const char*)c.Wp + (p.w_blocked ? (long)c.kb * 8192 : (long)c.kb * (BK * 2));
+    if (c.kb < c.ke) {
+      ext_switch(c, c.kb);
+      dma_tile(lds_w);
+    }
+  };
+
+  int h = blockIdx.x;
+  TileCtx cur = tile_ctx<BM2, BN2, KEXT>(p, h, total);
+  while (!cur.ok) {                                              // surplus tiles of a grouped launch
+    h += gridDim.x;
+    if (h >= total) return;
+    cur = tile_ctx<BM2, BN2, KEXT>(p, h, total);
+  }
+  first_dma(cur);
+
+  for (;;) {
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    unsigned long long lf[5] = {0, 0, 0, 0, 0};
+    if (LIFE) lf[0] = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share of the first K tile (and its last stores)
+    __syncthreads();
+    if (LIFE) lf[1] = __builtin_amdgcn_s_memtime();                                             // first K tile landed; every wave is past the previous epilogue's LDS reads
+    if (lag) __builtin_amdgcn_s_barrier();
+    for (int kt = cur.kb; kt < cur.ke; ++kt) {
+      const int cs = (kt - cur.kb) & 1;
+      const bool more = kt + 1 < cur.ke;
+      const char* S = smem + cs * STAGE;
+      const unsigned nxt = lds_w + (cs ^ 1) * STAGE;
+      bf16x8 af[8], bfr[NT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ko = kk ? koff1 : koff0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
+        if (kk == 0) {
+          if (more) {
+            ext_switch(cur, kt + 1);
+            dma_tile(nxt);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!lag) __builtin_amdgcn_s_barrier();                      // both groups are past their last LDS read: both stages are free
+
+    if (LIFE) lf[2] = __builtin_amdgcn_s_memtime();
+    // ---- the next tile of this workgroup: its first K tile travels while the epilogue runs
+    int hn = h + gridDim.x;
+    TileCtx nx; nx.ok = 0;
+    while (hn < total) {
+      nx = tile_ctx<BM2, BN2, KEXT>(p, hn, total);
+      if (nx.ok) break;
+      hn += gridDim.x;
+    }
+    if (nx.ok) first_dma(nx);
+    if (LIFE) lf[3] = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue of `cur`.  Its index arithmetic starts from an opaque copy of the thread index: otherwise the compiler
+    // hoists those loop-invariant values out of the tile loop and carries them, spilled, across the main loop.
+    if (!(p.dbg & 1)) {
+      int te = tid;
+      asm volatile("" : "+v"(te));
+      const int e_l15 = te & 15, e_g = (te >> 4) & 3, e_wn = (te >> 6) & 3, e_wm = te >> 8;
+      char* Cb = (char*)p.C;
+      if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
+      const bool wide = epilogue_wide_ok(p);
+      {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ml = cur.m0 + e_wm * 128 + i * 16 + e_l15;
+          if (ml >= cur.Mact) continue;
+          const int m = cur.rbase + ml;
+          const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+          epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, cur.n0 + e_wn * (BN2 / 4), e_g, wide, m, cur.biasp);
+        }
+      }
+    }
+    if (LIFE) {
+      lf[4] = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && (wave & 3) == 0) {
+        unsigned long long* o = (unsigned long long*)((char*)p.C + (long)p.M * p.ldc * 2) + ((long)h * 2 + wm) * 8;
+        for (int q = 0; q < 5; ++q) o[q] = lf[q];
+        o[5] = __builtin_amdgcn_s_getreg(63492);
+        o[6] = __builtin_amdgcn_s_getreg(63508);
+        o[7] = (unsigned long long)blockIdx.x;
+      }
+    }
+    if (!nx.ok) return;
+    cur = nx; h = hn;
   }
 }
 
@@ -633,8 +900,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
   const int m0 = pm * BM2, n0 = pn * BN2;
 
   const int nkt = p.K / BK;
-  int kt_begin = (int)(((long)nkt * z) / p.splits);
-  int kt_end = (int)(((long)nkt * (z + 1)) / p.splits);
+  int kt_begin = 0, kt_end = nkt;                  // 32-bit, and only when split: two 64-bit quotients cost ~2 k cycles per workgroup
+  if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
   if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
   if (KEXT) kt_end = nkt + p.K2 / BK;
   if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
@@ -781,7 +1048,7 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 8) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
+  if (forced >= 0 && forced <= 9) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -804,8 +1071,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   const int variant = pick_variant(a.M, a.N, a.splits);
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
   const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256);
-  if (variant == 8 && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
-  const int bn = (variant == 4 || variant == 7 || variant == 8) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
+  if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
+  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
@@ -817,6 +1084,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     const char* d = getenv("TA355_GEMM_DEBUG");           // experiments: 1 = no epilogue stores, 2 = one K tile only
     a.dbg = d && *d ? atoi(d) : 0;
   }
+  // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
+  bool persist = variant == 3 || variant == 4;
+  { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; }
+  static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const int pgrid = grid < ncu ? grid : ncu;
   ProfRec r;
   if (g_prof_on) {
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return TA_ERR_LAUNCH;
@@ -828,6 +1100,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 128, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 3 && persist) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
+      else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
@@ -840,8 +1114,13 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 3 && persist) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
+  else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 9) {
+    if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) TA_LAUNCH((gemm_nt_kernel_v4<320, 0, true, false, false, true>), dim3(pgrid), dim3(512), 0, st, a);
+  }
   else if (variant == 8) {
     if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) TA_LAUNCH((gemm_nt_kernel_v2<320, 0, true, false, true, false, true>), dim3(grid), dim3(512), 0, st, a);
   }
