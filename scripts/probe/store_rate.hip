@@ -12,6 +12,10 @@
 // MODE 2: 8 B per lane, 16 rows x 32 B per instruction                   -- the raw MFMA accumulator layout in bf16
 // MODE 3: 4 B per lane, fully contiguous (256 B per instruction)
 // MODE 4: 16 B per lane, fully contiguous, nontemporal
+// MODE 5: 16 B per lane, 8 rows x 128 B per instruction, line-aligned       -- what an in-register (DPP) row merge could reach
+// MODE 6: as 5 but every segment starts 32 B into a line (the 80-column wave spans of the 320-wide tile)
+// MODE 7: 16 B per lane, 4 rows x 256 B per instruction
+// MODE 8: 16 B per lane, rows of 160 B (10 lanes per row, 6.4 rows per instruction) -- wave-local staging of an 80-column span
 template <int MODE>
 __global__ __launch_bounds__(512) void k(char* out, long ld_bytes, unsigned long long* stamps, int reps) {
   extern __shared__ char lds[];
@@ -41,6 +45,27 @@ __global__ __launch_bounds__(512) void k(char* out, long ld_bytes, unsigned long
       for (int it = 0; it < 40; ++it) {
         const int rg = it / 20, cg = it % 20;
         *(uint2*)(tile + (wave * 32 + rg * 16 + (lane & 15)) * ld_bytes + cg * 32 + (lane >> 4) * 8) = make_uint2(v.x, v.y);
+      }
+    } else if (MODE == 5 || MODE == 6) {                             // wave: 32 rows x 640 B as 4 row groups of 8 x 5 column groups of 128 B
+#pragma unroll
+      for (int it = 0; it < 20; ++it) {
+        const int rg = it / 5, cg = it % 5;
+        *(uint4*)(tile + (wave * 32 + rg * 8 + (lane >> 3)) * ld_bytes + cg * 128 + (lane & 7) * 16 + (MODE == 6 ? 32 : 0)) = v;
+      }
+    } else if (MODE == 7) {                                          // 4 rows x 256 B; columns 0..511 + a 128-B remainder handled as 8 x 128
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int rg = it / 2, cg = it % 2;
+        *(uint4*)(tile + (wave * 32 + rg * 4 + (lane >> 4)) * ld_bytes + cg * 256 + (lane & 15) * 16) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        *(uint4*)(tile + (wave * 32 + it * 8 + (lane >> 3)) * ld_bytes + 512 + (lane & 7) * 16) = v;
+    } else if (MODE == 8) {                                          // wave w: 128 rows x 160 B at column byte 160 * (w & 3), rows (w >> 2) * 128 ..
+#pragma unroll
+      for (int it = 0; it < 20; ++it) {
+        const int item = it * 64 + lane, row = item / 10, ch = item - row * 10;
+        *(uint4*)(tile + ((wave >> 2) * 128 + row) * ld_bytes + (wave & 3) * 160 + ch * 16) = v;
       }
     } else if (MODE == 3) {
 #pragma unroll
@@ -75,12 +100,16 @@ int main() {
   const long ld = 5120 * 2;                                // row stride of a [M, 5120] bf16 matrix
   char* out; hipMalloc(&out, 256L * 256 * ld);
   unsigned long long* st; hipMalloc(&st, 256 * 16 * 8);
-  for (int grid : {1, 8, 64, 256}) {
+  for (int grid : {1, 256}) {
     run<0>("16 B/lane, contiguous 1 KB per instr", grid, out, ld, st, 1);
     run<1>("16 B/lane, 16 rows x 64 B per instr", grid, out, ld, st, 1);
     run<2>("8 B/lane, 16 rows x 32 B per instr", grid, out, ld, st, 1);
     run<3>("4 B/lane, contiguous 256 B per instr", grid, out, ld, st, 1);
     run<4>("16 B/lane, contiguous, nontemporal", grid, out, ld, st, 1);
+    run<5>("16 B/lane, 8 rows x 128 B aligned", grid, out, ld, st, 1);
+    run<6>("16 B/lane, 8 rows x 128 B, +32 B misaligned", grid, out, ld, st, 1);
+    run<7>("16 B/lane, 4 rows x 256 B (+ 128-B remainder)", grid, out, ld, st, 1);
+    run<8>("16 B/lane, rows of 160 B (wave-local spans)", grid, out, ld, st, 1);
   }
   run<0>("16 B/lane contiguous, 4 tiles back to back", 256, out, ld, st, 4);
   return 0;
