@@ -701,33 +701,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     for (int i = 0; i < NB; ++i) glds16_s(wb, w_off[i], base + A_BYTES + i * 8192);
     a_base += BK * 2; w_base += w_step;
   };
+  // Offsets are relative to the tile's first row of each operand (the base carries the rest), so they stay far below 4 GB
+  // whatever the operand's size; only A under a non-identity row map is addressed from the start of A (host: < 4 GB, no gather).
   auto ext_switch = [&](const TileCtx& c, int tile) {            // call before staging K-tile `tile` of tile context c
     if (KEXT && tile == nkt) {
-      a_base = (const char*)p.A2; w_base = (const char*)p.W2;
+      a_base = (const char*)(p.A2 + (long)(c.rbase + c.m0) * p.lda2);
+      w_base = (const char*)(p.W2 + (long)c.n0 * p.K2);
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        a_off[i] = (unsigned)(((long)(c.rbase + min(c.m0 + i * 64 + lr, c.Mact - 1)) * p.lda2 + clog * 8) * 2);
+        a_off[i] = (unsigned)(((long)(min(c.m0 + i * 64 + lr, c.Mact - 1) - c.m0) * p.lda2 + clog * 8) * 2);
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        w_off[i] = (unsigned)(((long)min(c.n0 + i * 64 + lr, p.N - 1) * p.K2 + clog * 8) * 2);
+        w_off[i] = (unsigned)(((long)(min(c.n0 + i * 64 + lr, p.N - 1) - c.n0) * p.K2 + clog * 8) * 2);
     }
   };
   auto first_dma = [&](const TileCtx& c) {                      // sources of tile c + its first K tile into stage 0
+    if (p.a_plain) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int gm = c.rbase + min(c.m0 + i * 64 + lr, c.Mact - 1);
-      if (p.a_idx) gm = p.a_idx[gm];
-      const long aoff = p.a_plain ? (long)gm * p.lda : (long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda;
-      a_off[i] = (unsigned)((aoff + clog * 8) * 2);
+      for (int i = 0; i < NA; ++i)
+        a_off[i] = (unsigned)(((long)(min(c.m0 + i * 64 + lr, c.Mact - 1) - c.m0) * p.lda + clog * 8) * 2);
+      a_base = (const char*)(p.A + (long)(c.rbase + c.m0) * p.lda) + (long)c.kb * (BK * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int gm = c.rbase + min(c.m0 + i * 64 + lr, c.Mact - 1);
+        a_off[i] = (unsigned)(((long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda + clog * 8) * 2);
+      }
+      a_base = (const char*)p.A + (long)c.kb * (BK * 2);
     }
-    a_base = (const char*)p.A + (long)c.kb * (BK * 2);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int gn = min(c.n0 + i * 64 + lr, p.N - 1);
-      w_off[i] = p.w_blocked ? (unsigned)(((((long)(gn >> 6) * nkt) << 12) + ((gn & 63) << 6) + clog * 8) * 2)
-                             : (unsigned)(((long)gn * p.K + clog * 8) * 2);
+      w_off[i] = p.w_blocked ? (unsigned)(((((long)((gn >> 6) - (c.n0 >> 6)) * nkt) << 12) + ((gn & 63) << 6) + clog * 8) * 2)
+                             : (unsigned)(((long)(gn - c.n0) * p.K + clog * 8) * 2);
     }
-    w_base = (const char*)c.Wp + (p.w_blocked ? (long)c.kb * 8192 : (long)c.kb * (BK * 2));
+    w_base = (const char*)c.Wp + (p.w_blocked ? (((long)(c.n0 >> 6) * nkt) << 13) + (long)c.kb * 8192 : ((long)c.n0 * p.K + (long)c.kb * BK) * 2);
     if (c.kb < c.ke) {
       ext_switch(c, c.kb);
       dma_tile(lds_w);
@@ -1085,9 +1093,10 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.dbg = d && *d ? atoi(d) : 0;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
-  bool persist = variant == 3 || variant == 4;
-  { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; }
+  bool persist = (variant == 3 || variant == 4) && !a.a_idx;    // gathered A rows stay on v2 (their offsets are not bounded by the tile)
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
+  if (!a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32)) persist = false;   // row-mapped A is addressed from its start with 32-bit offsets
   const int pgrid = grid < ncu ? grid : ncu;
   ProfRec r;
   if (g_prof_on) {
