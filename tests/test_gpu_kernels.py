@@ -56,7 +56,7 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 64, 256), (1000, 1024, 1024), (6144, 4096, 1024), (4100, 1024, 3072)])
-@pytest.mark.parametrize("variant", [None, "0", "1", "3", "4"])
+@pytest.mark.parametrize("variant", [None, "0", "1", "3", "4", "10"])
 def test_gemm_k_extension(M, N, K, variant, monkeypatch):
     """C = A W^T + A2 W2^T in one launch (one extra 64-wide K tile: the fused LoRA update), every tile variant."""
     if variant is not None:
@@ -473,7 +473,7 @@ def test_relu_and_mix():
     assert relerr(dob, ot.grad) < 1e-2 and relerr(dlg, lt.grad) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10"])
 def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     """dX GEMM of down_proj with the SwiGLU backward in its epilogue == GEMM followed by ta_swiglu_bwd."""
     if variant is not None:
@@ -491,7 +491,7 @@ def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     assert relerr(ops.gemm_nt(dx, W, out_dtype=F32), dact) < 2e-3             # one-shot
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10"])
 def test_gemm_bf16_residual_in_place(variant, monkeypatch):
     """x += A W^T + b with a bf16 residual stream aliased to the output (the encoder's residual GEMMs)."""
     if variant is not None:
@@ -541,7 +541,7 @@ def il_perm():
     return torch.where(p < 32, (p >> 1) + 16 * (p & 1), p)
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10"])
 def test_gemm_rope_epilogue(variant, monkeypatch):
     """act = 2: q|k = rope(A W^T + b) with W's rows in the interleaved pair order == HF rotate-half rope on the plain
     projection, column-permuted (TF:models/glmasr/modeling_glmasr.py:153-168)."""
@@ -629,7 +629,7 @@ def test_attention_fwd_is_deterministic():
         assert torch.equal(o2, r2)
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10"])
 def test_gemm_w_blocked(variant, monkeypatch):
     """W handed over as [N/64][K/64][64][64] blocks (8 KB contiguous per K tile of 64 rows) == the row-major call."""
     if variant is not None:

@@ -20,6 +20,7 @@
 //     (tiny_audio/projectors.py:79-87).
 #include "common.h"
 #include "../../include/ta355.h"
+#include <type_traits>
 
 struct GemmArgs {
   const bf16_t* A;
@@ -75,6 +76,7 @@ struct GemmArgs {
 #define TA355_RATE_256x128 0.5      /* measured slower than 128x128 on every shape */
 #define TA355_RATE_256x256_PP 1.40  /* per unit tile area vs the 128x128 kernel, fitted on profiles/r01_f_gemm_variants.txt (lm_qkv 56 vs 62 us, sq8192 1330 vs 1050 TF/s) */
 #define TA355_RATE_96x128 0.93      /* 3x4 instead of 4x4 MFMAs per fragment set; estimate, to be refitted */
+#define TA355_RATE_192x128 1.0      /* v5 (one 192x128 tile per CU), cold operands, profiles/r02_gemm_v5_ab_cold.txt: 1.05-1.15 in one round (lm o / down / dX: 43.5 / 58.5 / 61.7 / 97.2 us vs 49.4 / 68.4 / 74.3 / 120.2 for 96x128), 0.9-1.03 over several rounds; 0 = never chosen */
 #define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
@@ -1039,6 +1041,181 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
   }
 }
 
+// ============================================================================ v5: 192 x 128 tile, ONE 4-wave workgroup per CU, 3-slot ring
+// For outputs that are ONE round of small tiles (the LM's M = 6144 x N = 1024 products: 512 tiles of 96x128, two per CU, or
+// 256 tiles of 192x128).  One 192 x 128 tile per CU stages (192 + 128) rows per K step instead of 2 x (96 + 128), and as 4 waves
+// of 96 x 64 (6 A + 4 W fragments per 24 MFMAs) it reads 10 KB of LDS per 24 MFMAs instead of 7 KB per 12.  With a single wave
+// per SIMD nothing else hides latency or issue slots, so:
+//   * a ring of 3 K-tile slots (120 KB): group t+2 is DMA'd while tile t is computed; the wait for group t+1 is counted
+//     (s_waitcnt vmcnt(10): one group of 10 instructions may stay in flight), i.e. every DMA has two K tiles to land;
+//   * fragments are double-buffered in registers: the ds_reads of half-step h+1 and the DMA issues of group t+2 sit BETWEEN the
+//     24 MFMAs of half-step h, one per MFMA (all of them in front of the MFMA group: 660 cycles per half-step for 384 of MFMA);
+//   * DMA sources are a uniform base + 32-bit tile-relative offsets (as in v4); rows are 128 B (whole lines: a first version
+//     with 64-B half K-tile slots needed one address-path cycle per 64-B row segment, 320 per half-step -- measured 700 cycles
+//     per half-step against 400 with the DMA removed);
+//   * one barrier per K TILE: it publishes slot t+1 (every wave waited for its own share) and retires slot t-1.
+// Slot image: v2's ([rows][128 B], 16-B chunk index XOR (row >> 1 & 7), applied on the source side of the DMA).
+// EXP (experiments, wrong results): 1 no W fragment reads, 2 no A fragment reads, 3 neither, 4 no DMA after the prologue.
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0_n() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+template <int ACT, bool OUT_BF16, bool HAS_RES, int EXP = 0>
+__global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
+  constexpr int BM5 = 192, BN5 = 128, NS = 3;
+  constexpr int A_BYTES = BM5 * 128, SLOT = (BM5 + BN5) * 128;
+  __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  const int t = bid - z * tiles;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int* segp; const bf16_t* Wp; const float* biasp; const int* krp;
+  if (!resolve_group<BM5>(p, pm, z, segp, Wp, biasp, krp)) return;
+  const int m0 = pm * BM5, n0 = pn * BN5;
+  const int nkt = p.K / BK;
+  int kt_begin = 0, kt_end = nkt;
+  if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
+  if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
+  if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
+  int Mact = p.M, rbase = 0;
+  if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
+
+  // ---- DMA sources: pass q stages rows [32 q, 32 q + 32) of A (q < 6) / of W (q - 6 < 4); a thread owns one 16-B chunk per pass
+  const int lr = tid >> 3;
+  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
+  unsigned a_off[6], w_off[4];
+  const char* a_base; const char* w_base;
+  if (p.a_plain) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      a_off[q] = (unsigned)(((long)(min(m0 + q * 32 + lr, Mact - 1) - m0) * p.lda + clog * 8) * 2);
+    a_base = (const char*)(p.A + (long)(rbase + m0) * p.lda) + (long)kt_begin * (BK * 2);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int gm = rbase + min(m0 + q * 32 + lr, Mact - 1);
+      a_off[q] = (unsigned)(((long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda + clog * 8) * 2);
+    }
+    a_base = (const char*)p.A + (long)kt_begin * (BK * 2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    w_off[q] = (unsigned)(((long)(min(n0 + q * 32 + lr, p.N - 1) - n0) * p.K + clog * 8) * 2);
+  w_base = (const char*)(Wp + (long)n0 * p.K) + (long)kt_begin * (BK * 2);
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+
+  const int swz = l15 >> 1;
+  const int a_rd = (wm * 96 + l15) * 128;
+  const int b_rd = A_BYTES + (wn * 64 + l15) * 128;
+  const int koff0 = ((0 + g) ^ swz) << 4;
+  const int koff1 = ((4 + g) ^ swz) << 4;
+
+  f32x4 acc[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = kt_end - kt_begin;
+  if (nt > 0) {
+    // DMA group k (k = 0, 1, ...) loads K tile min(k, nt - 1) into slot k % 3: the groups past the end re-load the last tile into
+    // a retired slot, so that every K tile issues exactly one group and every wait is the same count.
+    int islot = 0, kgrp = 0;
+    auto advance = [&]() {
+      ++kgrp;
+      if (kgrp < nt) { a_base += BK * 2; w_base += BK * 2; }
+      islot = islot == NS - 1 ? 0 : islot + 1;
+    };
+    for (int hh = 0; hh < 2; ++hh) {
+      const char* ab = uniform_ptr(a_base);
+      const char* wb = uniform_ptr(w_base);
+      const unsigned base = lds_w + islot * SLOT;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) glds16_s(ab, a_off[q], base + q * 4096);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16_s(wb, w_off[q], base + A_BYTES + q * 4096);
+      advance();
+    }
+    bf16x8 af0[6], bf0[4], af1[6], bf1[4];
+    wait_vm_lgkm0_n<10>();                                     // group 0 landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf0[j] = *(const bf16x8*)(smem + b_rd + j * 2048 + koff0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) af0[i] = *(const bf16x8*)(smem + a_rd + i * 2048 + koff0);
+    int rslot = 0;                                             // slot of the K tile being computed
+    // One half-step.  FIRST (k columns 0..31 of tile t): MFMAs on (ca, cb), reads of the second half of the same slot into
+    // (na, nb), DMA of group t + 2 into the slot tile t - 1 left.  SECOND: waits for group t + 1 (group t + 2 may stay in flight),
+    // barrier, MFMAs, reads of the first half of slot t + 1.  In the last half-step the reads fetch a slot nobody uses.
+    auto step = [&](auto first_tag, bf16x8* ca, bf16x8* cb, bf16x8* na, bf16x8* nb) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
+      if (FIRST || EXP == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else wait_vm_lgkm0_n<10>();
+      // pass the fragments through an empty asm: the compiler's own wait for them lands HERE, not behind the reads issued below
+#pragma unroll
+      for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(ca[i]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(cb[j]));
+      __builtin_amdgcn_sched_barrier(0);
+      if (!FIRST) {
+        __builtin_amdgcn_s_barrier();                          // slot t + 1 is complete; slot t may be overwritten (by group t + 3, next tile)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const char* S = smem + (FIRST ? rslot : nslot) * SLOT + (FIRST ? koff1 : koff0);
+      const char* ab = uniform_ptr(a_base);
+      const char* wb = uniform_ptr(w_base);
+      const unsigned base = lds_w + islot * SLOT;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 24; ++q) {
+        const int i = q >> 2, j = q & 3;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+        if (q < 4) { if (!(EXP & 1) || EXP == 4) nb[q] = *(const bf16x8*)(S + b_rd + q * 2048); }
+        else if (q < 10) { if (!(EXP & 2) || EXP == 4) na[q - 4] = *(const bf16x8*)(S + a_rd + (q - 4) * 2048); }
+        else if (FIRST && EXP != 4) {
+          if (q < 16) glds16_s(ab, a_off[q - 10], base + (q - 10) * 4096);
+          else if (q < 20) glds16_s(wb, w_off[q - 16], base + A_BYTES + (q - 16) * 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (FIRST) advance(); else rslot = nslot;
+    };
+    for (int kt = 0; kt < nt; ++kt) {
+      step(std::true_type{}, af0, bf0, af1, bf1);
+      step(std::false_type{}, af1, bf1, af0, bf0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the surplus groups: no DMA may be in flight into LDS at the end
+  }
+
+  char* Cb = (char*)p.C;
+  if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+  if (p.dbg & 1) return;
+  const bool wide = epilogue_wide_ok(p);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int ml = m0 + wm * 96 + i * 16 + l15;
+    if (ml >= Mact) continue;
+    const int m = rbase + ml;
+    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp);
+  }
+}
+
 // ---- optional in-situ timing of every GEMM launch (bench.py's roofline leg): HIP events recorded on the
 //      launch stream around the kernel, summed after the fact.  Off by default (zero overhead).
 #include <vector>
@@ -1053,10 +1230,10 @@ std::vector<ProfRec> g_prof;
 // Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
 // come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0..3 forces one (experiments, tests).
 #include <cstdlib>
-static int pick_variant(int M, int N, int splits) {
+static int pick_variant(int M, int N, int K, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 9) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
+  if (forced >= 0 && forced <= 10) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -1068,6 +1245,13 @@ static int pick_variant(int M, int N, int splits) {
     const double t = rounds * (double)bm[v] * bn[v] / rate[v] * ((v == 0 || v == 5) ? 2.0 : 1.0);
     if (t < best_t) { best_t = t; best = v; }
   }
+  {                                                  // 10 = 192x128, one 4-wave workgroup per CU (v5)
+    static const double r10 = [] { const char* v = getenv("TA355_RATE_192x128"); return v && *v ? atof(v) : TA355_RATE_192x128; }();
+    const long tiles = (long)ta_cdiv(M, 192) * ta_cdiv(N, 128) * splits;
+    const double t = (double)((tiles + 255) / 256) * 192.0 * 128.0 / r10;
+    // only long contractions: with one workgroup per CU nothing overlaps its prologue and epilogue (K = 1280: 33 vs 28 us for 96x128)
+    if (r10 > 0.0 && K / splits >= 2048 && t < best_t) { best_t = t; best = 10; }
+  }
   // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
   static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
   if (ring && (best == 3 || best == 4)) best += 3;
@@ -1076,9 +1260,11 @@ static int pick_variant(int M, int N, int splits) {
 
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
-  const int variant = pick_variant(a.M, a.N, a.splits);
+  int variant = pick_variant(a.M, a.N, a.K, a.splits);
+  const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
+  if (variant == 10 && (a.A2 || a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 has no K extension, no gather, plain W only
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
-  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : 256);
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : (variant == 10 ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
   const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
@@ -1096,7 +1282,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   bool persist = (variant == 3 || variant == 4) && !a.a_idx;    // gathered A rows stay on v2 (their offsets are not bounded by the tile)
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
-  if (!a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32)) persist = false;   // row-mapped A is addressed from its start with 32-bit offsets
+  if (a_far) persist = false;
   const int pgrid = grid < ncu ? grid : ncu;
   ProfRec r;
   if (g_prof_on) {
@@ -1127,6 +1313,18 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 10) {
+    const int ex = a.dbg >> 4;                                  // TA355_GEMM_DEBUG = 16 * EXP (plain bf16 GEMMs only)
+    if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) {
+      if (ex == 1) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 1>), dim3(grid), dim3(256), 0, st, a);
+      else if (ex == 2) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 2>), dim3(grid), dim3(256), 0, st, a);
+      else if (ex == 3) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 3>), dim3(grid), dim3(256), 0, st, a);
+      else if (ex == 4) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 4>), dim3(grid), dim3(256), 0, st, a);
+      else TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+      TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+    }
+  }
   else if (variant == 9) {
     if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) TA_LAUNCH((gemm_nt_kernel_v4<320, 0, true, false, false, true>), dim3(pgrid), dim3(512), 0, st, a);
   }
