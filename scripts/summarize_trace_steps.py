@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-STEP kernel table from a rocprofv3 --kernel-trace CSV of bench.py: model construction and warm-up are cut off (a step
-starts at its logmel_power_kernel launch), so the table holds exactly what one training step launches.
+starts at its logmel_init_kernel / logmel_power_kernel launch), so the table holds exactly what one training step launches.
 
 usage: summarize_trace_steps.py <kernel_trace.csv> <out.md> [--skip N] [--note "..."]"""
 import csv
@@ -27,7 +27,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "logmel_power_kernel" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "logmel_init_kernel" in r[2] or "logmel_power_kernel" in r[2]]
     if len(starts) <= skip + 1:
         raise SystemExit(f"only {len(starts)} steps in the trace")
     lo, hi = starts[skip], starts[-1]                      # whole steps only: from step `skip` to the start of the last one

@@ -1057,7 +1057,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 // Slot image: v2's ([rows][128 B], 16-B chunk index XOR (row >> 1 & 7), applied on the source side of the DMA).
 // EXP (experiments, wrong results): 1 no W fragment reads, 2 no A fragment reads, 3 neither, 4 no DMA after the prologue.
 template <int N> __device__ __forceinline__ void wait_vm_lgkm0_n() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-template <int ACT, bool OUT_BF16, bool HAS_RES, int EXP = 0>
+// KEXT: the K extension of ta_gemm_opts.a2 / w2 (LoRA): after the K tiles of A / W the groups continue over A2 / W2.
+template <int ACT, bool OUT_BF16, bool HAS_RES, int EXP = 0, bool KEXT = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   constexpr int BM5 = 192, BN5 = 128, NS = 3;
   constexpr int A_BYTES = BM5 * 128, SLOT = (BM5 + BN5) * 128;
@@ -1089,6 +1090,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   int kt_begin = 0, kt_end = nkt;
   if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
   if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
+  if (KEXT) kt_end = nkt + p.K2 / BK;              // host guarantees splits == 1, no krange
   if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
   int Mact = p.M, rbase = 0;
   if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
@@ -1136,7 +1138,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
     int islot = 0, kgrp = 0;
     auto advance = [&]() {
       ++kgrp;
-      if (kgrp < nt) { a_base += BK * 2; w_base += BK * 2; }
+      if (kgrp < nt) {
+        if (KEXT && kt_begin + kgrp == nkt) {                   // the next group is the first K tile of the extension
+          a_base = (const char*)(p.A2 + (long)(rbase + m0) * p.lda2);
+          w_base = (const char*)(p.W2 + (long)n0 * p.K2);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) a_off[q] = (unsigned)(((long)(min(m0 + q * 32 + lr, Mact - 1) - m0) * p.lda2 + clog * 8) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w_off[q] = (unsigned)(((long)(min(n0 + q * 32 + lr, p.N - 1) - n0) * p.K2 + clog * 8) * 2);
+        } else {
+          a_base += BK * 2; w_base += BK * 2;
+        }
+      }
       islot = islot == NS - 1 ? 0 : islot + 1;
     };
     for (int hh = 0; hh < 2; ++hh) {
@@ -1250,7 +1263,8 @@ static int pick_variant(int M, int N, int K, int splits) {
     const long tiles = (long)ta_cdiv(M, 192) * ta_cdiv(N, 128) * splits;
     const double t = (double)((tiles + 255) / 256) * 192.0 * 128.0 / r10;
     // only long contractions: with one workgroup per CU nothing overlaps its prologue and epilogue (K = 1280: 33 vs 28 us for 96x128)
-    if (r10 > 0.0 && K / splits >= 2048 && t < best_t) { best_t = t; best = 10; }
+    static const int mink = [] { const char* v = getenv("TA355_V5_MINK"); return v && *v ? atoi(v) : 2048; }();
+    if (r10 > 0.0 && K / splits >= mink && t < best_t) { best_t = t; best = 10; }
   }
   // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
   static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
@@ -1262,7 +1276,7 @@ template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
   int variant = pick_variant(a.M, a.N, a.K, a.splits);
   const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
-  if (variant == 10 && (a.A2 || a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 has no K extension, no gather, plain W only
+  if (variant == 10 && (a.w_blocked || a.a_idx || a_far)) variant = 5;             // v5: no gather, plain W only
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
   const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : (variant == 10 ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
@@ -1279,7 +1293,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.dbg = d && *d ? atoi(d) : 0;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
-  bool persist = (variant == 3 || variant == 4) && !a.a_idx;    // gathered A rows stay on v2 (their offsets are not bounded by the tile)
+  // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
+  // the persistent form spills in the tile loop (LoRA step 54.5 ms against 53.6 with v2)
+  bool persist = (variant == 3 || variant == 4) && !a.a_idx && !a.A2;
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
   if (a_far) persist = false;
@@ -1295,10 +1311,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 128, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
-      else if (variant == 3 && persist) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
-      else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 10) TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES, 0, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
