@@ -34,7 +34,10 @@ def cos_sim(a, b):
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 1280, 1280), (77, 384, 3840), (2048, 1024, 4096), (333, 1284, 128), (515, 5128, 64)])
 @pytest.mark.parametrize("out_bf16", [True, False])
-def test_gemm_plain(M, N, K, out_bf16):
+@pytest.mark.parametrize("variant", [None, "3", "4", "10"])     # automatic choice; persistent ping-pong tiles (v4); one 192x128 tile per CU (v5)
+def test_gemm_plain(M, N, K, out_bf16, variant, monkeypatch):
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
     A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
     C = ops.gemm_nt(A, W, out_dtype=BF16 if out_bf16 else F32)
     ref = A.float() @ W.float().T                      # asymmetric operands: a transposed store would not pass
@@ -73,7 +76,10 @@ def test_gemm_k_extension(M, N, K, variant, monkeypatch):
 
 
 @pytest.mark.parametrize("splits", [2, 5, 16])
-def test_gemm_splitk(splits):
+@pytest.mark.parametrize("variant", [None, "4", "10"])
+def test_gemm_splitk(splits, variant, monkeypatch):
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
     M, N, K = 200, 256, 64 * 37
     A, W = rnd(M, K, seed=7, dtype=BF16), rnd(N, K, seed=8, scale=1 / math.sqrt(K), dtype=BF16)
     ref = A.float() @ W.float().T
@@ -82,8 +88,11 @@ def test_gemm_splitk(splits):
     assert relerr(ops.gemm_nt(A, W, out_dtype=F32, splits=splits, residual=add), ref + add) < 2e-3
 
 
-def test_gemm_conv_rowmap():
+@pytest.mark.parametrize("variant", [None, "4", "10"])
+def test_gemm_conv_rowmap(variant, monkeypatch):
     """Conv1d(k=3, pad=1, stride s) as a row-mapped GEMM over a zero-padded time-major buffer."""
+    if variant is not None:
+        monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
     B, T, Cin, Cout = 3, 37, 128, 256
     x = rnd(B, Cin, T, seed=10)
     w = rnd(Cout, Cin, 3, seed=11, scale=1 / math.sqrt(3 * Cin))
