@@ -40,7 +40,7 @@ shapes = [  # name, M, N, K, act, residual(bf16, in place)
     ("enc_fc1", 16000, 5120, 1280, 1, False), ("proj_fc1", 4000, 1024, 5120, 1, False), ("proj_fc2", 4000, 1024, 1024, 0, False),
     ("ragged", 5000, 1000, 1280, 1, True), ("lm17_o", 6144, 2048, 2048, 0, True), ("lm17_down", 6144, 2048, 6144, 0, True),
 ]
-variants = ["0", "5", "3", "4", "10"]
+variants = ["0", "5", "3", "4", "10", "11"]
 print(f"{'shape':11s} {'M':>6s} {'N':>6s} {'K':>5s} " + " ".join(f"{'v' + v:>8s}" for v in variants) + "   us per launch" + (" (cold operands)" if cold else ""))
 for name, M, N, K, act, hasres in shapes:
     torch.manual_seed(0)
@@ -58,8 +58,8 @@ for name, M, N, K, act, hasres in shapes:
             out.copy_(res0)
         ts.append(timeit(fn))
     ok = not bool(torch.isnan(outs[-1].float()).any())
-    same = torch.equal(outs[-1], outs[1])
+    same = torch.equal(outs[-2], outs[1])
     md = float((outs[-1].float() - outs[1].float()).abs().max())
     best = min(range(len(ts)), key=lambda i: ts[i])
-    print(f"{name:11s} {M:6d} {N:6d} {K:5d} " + " ".join(f"{t:8.1f}" for t in ts) + f"   best v{variants[best]}  v10 vs v5: identical={same} maxdiff={md:.3g} finite={ok}", flush=True)
+    print(f"{name:11s} {M:6d} {N:6d} {K:5d} " + " ".join(f"{t:8.1f}" for t in ts) + f"   best v{variants[best]}  v10 vs v5 identical={same}; v11 vs v5 maxdiff={md:.3g} finite={ok}", flush=True)
 os.environ["TA355_GEMM_VARIANT"] = ""

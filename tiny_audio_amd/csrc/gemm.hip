@@ -1130,6 +1130,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  f32x16 acc32[6];                                    // EXP == 5 (timing only): the same tile as 6 blocks of 32x32, 12 MFMAs per half-step
+  if (EXP == 5) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f;
+  }
 
   const int nt = kt_end - kt_begin;
   if (nt > 0) {
@@ -1196,6 +1204,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
 #pragma unroll
       for (int q = 0; q < 24; ++q) {
         const int i = q >> 2, j = q & 3;
+        if (EXP == 5) {                                         // every second slot: one 32x32x16 MFMA on arbitrary fragments (timing only)
+          if ((q & 1) == 0) acc32[q / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[j], ca[i], acc32[q / 4], 0, 0, 0);
+        } else
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
         if (q < 4) { if (!(EXP & 1) || EXP == 4) nb[q] = *(const bf16x8*)(S + b_rd + q * 2048); }
         else if (q < 10) { if (!(EXP & 2) || EXP == 4) na[q - 4] = *(const bf16x8*)(S + a_rd + (q - 4) * 2048); }
@@ -1218,6 +1229,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   char* Cb = (char*)p.C;
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   if (p.dbg & 1) return;
+  if (EXP == 5) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = (f32x4){acc32[i][4 * e], acc32[i][4 * e + 1], acc32[i][4 * e + 2], acc32[i][4 * e + 3]};
+  }
   const bool wide = epilogue_wide_ok(p);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -1228,6 +1245,235 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
     epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp);
   }
 }
+
+// ============================================================================ v6: v5 on v_mfma_f32_32x32x16_bf16
+// Same tile (192 x 128 per CU), same 4 waves of 96 x 64, same 3-slot K-tile ring and DMA as v5 -- but the wave's tile is 3 x 2
+// blocks of 32 x 32 and a k-step is 16 columns: 6 MFMAs of 32 cycles instead of 24 of 16 per half-step, for the same 10 fragment
+// reads.  With one wave per SIMD every ds_read / DMA placed between two MFMAs costs issue time; twice as long an MFMA hides it
+// (timing-only experiment on v5, profiles/r02_gemm_v5_exp.txt: 633 -> 495 cycles per half-step).  Plain linears only (ACT == 0:
+// bias, f32 / bf16 residual, f32 / bf16 output, K extension).  The accumulation order inside the instruction differs from
+// 16x16x32 in principle (measured: bit-identical on every test shape).  NOT the default: per launch on warm operands it is 10-14 %
+// faster than v5, on cold operands equal, and in the step -- where these GEMMs wait for HBM, not for issue slots -- 2-4.6 us per
+// launch SLOWER (the staged epilogue): 45.86 against 45.38 ms per step (profiles/r02_gemm_v6_*.txt).  TA355_GEMM_M32=1 / variant 11.
+// Lane l of a 32x32 block (operands swapped as everywhere: first = W rows, second = A rows): A row l % 32; columns
+// 8 q + 4 (l / 32) .. + 3 for q = 0..3.  The epilogue stages the f32 tile through LDS (the ring is free by then) and stores
+// whole rows: 16 B of bf16 (or 32 B of f32) per lane, 4 rows x 256 B per instruction; residuals are read the same way.
+template <bool OUT_BF16, bool HAS_RES, bool KEXT = false>
+__global__ __launch_bounds__(256) void gemm_nt_kernel_v6(GemmArgs p) {
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  constexpr int BM5 = 192, BN5 = 128, NS = 3;
+  constexpr int A_BYTES = BM5 * 128, SLOT = (BM5 + BN5) * 128;
+  constexpr int EP = BN5 * 4 + 16;                   // bytes per staged f32 row
+  static_assert(BM5 * EP <= NS * SLOT, "the staged tile must fit in the ring");
+  __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, within = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int z = bid / tiles;
+  const int t = bid - z * tiles;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = t / width;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(p.tiles_m - first_m, GROUP_M);
+  int pm = first_m + (t % width) % gsize;
+  const int pn = (t % width) / gsize;
+  const int* segp; const bf16_t* Wp; const float* biasp; const int* krp;
+  if (!resolve_group<BM5>(p, pm, z, segp, Wp, biasp, krp)) return;
+  const int m0 = pm * BM5, n0 = pn * BN5;
+  const int nkt = p.K / BK;
+  int kt_begin = 0, kt_end = nkt;
+  if (p.splits > 1) { kt_begin = (nkt * z) / p.splits; kt_end = (nkt * (z + 1)) / p.splits; }
+  if (krp) { kt_begin = krp[0]; kt_end = krp[1]; }
+  if (KEXT) kt_end = nkt + p.K2 / BK;
+  if (p.dbg & 2) kt_end = min(kt_end, kt_begin + 1);
+  int Mact = p.M, rbase = 0;
+  if (segp) { rbase = segp[0]; Mact = segp[1]; if (m0 >= Mact) return; }
+
+  // ---- DMA sources (as v5)
+  const int lr = tid >> 3;
+  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
+  unsigned a_off[6], w_off[4];
+  const char* a_base; const char* w_base;
+  if (p.a_plain) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+      a_off[q] = (unsigned)(((long)(min(m0 + q * 32 + lr, Mact - 1) - m0) * p.lda + clog * 8) * 2);
+    a_base = (const char*)(p.A + (long)(rbase + m0) * p.lda) + (long)kt_begin * (BK * 2);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int gm = rbase + min(m0 + q * 32 + lr, Mact - 1);
+      a_off[q] = (unsigned)(((long)(gm / p.a_rpb) * p.a_bs + (long)(gm % p.a_rpb) * p.lda + clog * 8) * 2);
+    }
+    a_base = (const char*)p.A + (long)kt_begin * (BK * 2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    w_off[q] = (unsigned)(((long)(min(n0 + q * 32 + lr, p.N - 1) - n0) * p.K + clog * 8) * 2);
+  w_base = (const char*)(Wp + (long)n0 * p.K) + (long)kt_begin * (BK * 2);
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+
+  // ---- fragment reads: block row l31, 16-B chunk 2 s + hi of k-step s, chunk index XOR (row >> 1 & 7) (wm * 96, wn * 64 and the
+  // block offsets of 32 rows leave that term alone)
+  const int swz = (l31 >> 1) & 7;
+  const int a_rd = (wm * 96 + l31) * 128;
+  const int b_rd = A_BYTES + (wn * 64 + l31) * 128;
+  int ko[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) ko[s4] = ((2 * s4 + hi) ^ swz) << 4;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nt = kt_end - kt_begin;
+  if (nt > 0) {
+    int islot = 0, kgrp = 0;
+    auto advance = [&]() {
+      ++kgrp;
+      if (kgrp < nt) {
+        if (KEXT && kt_begin + kgrp == nkt) {
+          a_base = (const char*)(p.A2 + (long)(rbase + m0) * p.lda2);
+          w_base = (const char*)(p.W2 + (long)n0 * p.K2);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) a_off[q] = (unsigned)(((long)(min(m0 + q * 32 + lr, Mact - 1) - m0) * p.lda2 + clog * 8) * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w_off[q] = (unsigned)(((long)(min(n0 + q * 32 + lr, p.N - 1) - n0) * p.K2 + clog * 8) * 2);
+        } else {
+          a_base += BK * 2; w_base += BK * 2;
+        }
+      }
+      islot = islot == NS - 1 ? 0 : islot + 1;
+    };
+    for (int hh = 0; hh < 2; ++hh) {
+      const char* ab = uniform_ptr(a_base);
+      const char* wb = uniform_ptr(w_base);
+      const unsigned base = lds_w + islot * SLOT;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) glds16_s(ab, a_off[q], base + q * 4096);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16_s(wb, w_off[q], base + A_BYTES + q * 4096);
+      advance();
+    }
+    bf16x8 af0[3], bf0[2], af1[3], bf1[2];
+    wait_vm_lgkm0_n<10>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf0[j] = *(const bf16x8*)(smem + b_rd + j * 4096 + ko[0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) af0[i] = *(const bf16x8*)(smem + a_rd + i * 4096 + ko[0]);
+    int rslot = 0;
+    // one k-step (16 columns): 6 MFMAs on (ca, cb); the 5 fragment reads of the next k-step go to (na, nb).  S4 = 0..2 read on in
+    // the same slot, S4 = 3 first waits for K tile t + 1 (group t + 2 may stay in flight), passes the barrier and reads its k-step 0.
+    // The 10 DMA issues of group t + 2 ride in k-steps 0..2 (4 + 3 + 3), after the barrier of tile t - 1 retired their slot.
+    auto step = [&](auto s_tag, bf16x8* ca, bf16x8* cb, bf16x8* na, bf16x8* nb) {
+      constexpr int S4 = decltype(s_tag)::value;
+      const int nslot = rslot == NS - 1 ? 0 : rslot + 1;
+      if (S4 == 3) wait_vm_lgkm0_n<10>(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(ca[i]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(cb[j]));
+      __builtin_amdgcn_sched_barrier(0);
+      if (S4 == 3) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const char* S = smem + (S4 == 3 ? nslot : rslot) * SLOT + ko[(S4 + 1) & 3];
+      const char* ab = uniform_ptr(a_base);
+      const char* wb = uniform_ptr(w_base);
+      const unsigned base = lds_w + islot * SLOT;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int i = q >> 1, j = q & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+        if (q < 2) nb[q] = *(const bf16x8*)(S + b_rd + q * 4096);
+        else if (q < 5) na[q - 2] = *(const bf16x8*)(S + a_rd + (q - 2) * 4096);
+        if (S4 == 0) {                                         // DMA instructions 0..3: A passes 0..3
+          if (q >= 2) glds16_s(ab, a_off[q - 2], base + (q - 2) * 4096);
+        } else if (S4 == 1) {                                  // 4..6: A passes 4, 5 and W pass 0
+          if (q == 3) glds16_s(ab, a_off[4], base + 4 * 4096);
+          if (q == 4) glds16_s(ab, a_off[5], base + 5 * 4096);
+          if (q == 5) glds16_s(wb, w_off[0], base + A_BYTES);
+        } else if (S4 == 2) {                                  // 7..9: W passes 1..3
+          if (q >= 3) glds16_s(wb, w_off[q - 2], base + A_BYTES + (q - 2) * 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (S4 == 2) advance();
+      if (S4 == 3) rslot = nslot;
+    };
+    for (int kt = 0; kt < nt; ++kt) {
+      step(std::integral_constant<int, 0>{}, af0, bf0, af1, bf1);
+      step(std::integral_constant<int, 1>{}, af1, bf1, af0, bf0);
+      step(std::integral_constant<int, 2>{}, af0, bf0, af1, bf1);
+      step(std::integral_constant<int, 3>{}, af1, bf1, af0, bf0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  if (p.dbg & 1) return;
+  __builtin_amdgcn_s_barrier();                                // every wave is done with the ring: it becomes the f32 staging image
+
+  // ---- epilogue: stage [192][128] f32, then whole rows
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x16 v = acc[i][j];
+        *(float4*)(smem + (wm * 96 + i * 32 + l31) * EP + (wn * 64 + j * 32 + 8 * q + 4 * hi) * 4) =
+            make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
+  __syncthreads();
+  char* Cb = (char*)p.C;
+  if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
+  const int ch = tid & 15, n = n0 + ch * 8;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (biasp && n < p.N) { const float4 b0 = *(const float4*)(biasp + n), b1 = *(const float4*)(biasp + n + 4); bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w; }
+#pragma unroll 4
+  for (int it = 0; it < 12; ++it) {
+    const int r = it * 16 + (tid >> 4), ml = m0 + r;
+    if (ml >= Mact || n >= p.N) continue;
+    const int m = rbase + ml;
+    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+    const float4 x0 = *(const float4*)(smem + r * EP + ch * 32), x1 = *(const float4*)(smem + r * EP + ch * 32 + 16);
+    float v[8] = {x0.x + bv[0], x0.y + bv[1], x0.z + bv[2], x0.w + bv[3], x1.x + bv[4], x1.y + bv[5], x1.z + bv[6], x1.w + bv[7]};
+    if (HAS_RES) {
+      if (p.res_bf16) {
+        const uint4 rr = *(const uint4*)((const bf16_t*)p.res + roff + n);
+        const unsigned u[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += bf2f((bf16_t)(u[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(u[e] >> 16)); }
+      } else {
+        const float4 r0 = *(const float4*)(p.res + roff + n), r1 = *(const float4*)(p.res + roff + n + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+    }
+    if (OUT_BF16) {
+      *(uint4*)(Cb + (roff + n) * 2) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    } else {
+      *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(Cb + (roff + n) * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 
 // ---- optional in-situ timing of every GEMM launch (bench.py's roofline leg): HIP events recorded on the
 //      launch stream around the kernel, summed after the fact.  Off by default (zero overhead).
@@ -1246,7 +1492,7 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int K, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 10) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
+  if (forced >= 0 && forced <= 11) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -1276,9 +1522,14 @@ template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
   int variant = pick_variant(a.M, a.N, a.K, a.splits);
   const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
-  if (variant == 10 && (a.w_blocked || a.a_idx || a_far)) variant = 5;             // v5: no gather, plain W only
+  if ((variant == 10 || variant == 11) && (a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 / v6: no gather, plain W only
+  if (variant == 10 && ACT == 0) {                  // TA355_GEMM_M32=1 (experiment): plain linears on the 32x32x16 form of the same tile (v6)
+    const char* e = getenv("TA355_GEMM_M32");
+    if (e && *e == '1') variant = 11;
+  }
+  if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
-  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : (variant == 10 ? 192 : 256));
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11) ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
   const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
@@ -1314,6 +1565,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 10) TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES, 0, true>), dim3(grid), dim3(256), 0, st, a);
+      else if (variant == 11) TA_LAUNCH((gemm_nt_kernel_v6<OUT_BF16, HAS_RES, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
@@ -1328,6 +1580,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 11) {
+    if constexpr (ACT == 0) TA_LAUNCH((gemm_nt_kernel_v6<OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
+  }
   else if (variant == 10) {
     const int ex = a.dbg >> 4;                                  // TA355_GEMM_DEBUG = 16 * EXP (plain bf16 GEMMs only)
     if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) {
@@ -1335,6 +1590,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       else if (ex == 2) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 2>), dim3(grid), dim3(256), 0, st, a);
       else if (ex == 3) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 3>), dim3(grid), dim3(256), 0, st, a);
       else if (ex == 4) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 4>), dim3(grid), dim3(256), 0, st, a);
+      else if (ex == 5) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 5>), dim3(grid), dim3(256), 0, st, a);
       else TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
     } else {
       TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
