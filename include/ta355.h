@@ -434,6 +434,12 @@ int ta_grad_sqnorm(const float* g, long n, float* accum, hipStream_t st);
 int ta_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, const float* sqnorm, float max_norm, float grad_scale,
                   const float* denom, hipStream_t st);
+/* the same update for a flat buffer of nseg parameter tensors in ONE launch (scripts/train.py:406-432: per-group learning rate and
+ * weight decay): segment s ends at element seg_end[s] (device long[nseg], multiples of 4, seg_end[nseg-1] == n), has learning
+ * rate seg_lr[s] * lr_mult and weight decay seg_wd[s] (device float[nseg]).  Bit-identical to ta_adamw_step per segment. */
+int ta_adamw_step_multi(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr,
+                        const float* seg_wd, int nseg, float lr_mult, float beta1, float beta2, float eps, int step,
+                        const float* sqnorm, float max_norm, float grad_scale, const float* denom, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -58,7 +58,7 @@ def test_full_training_step_plumbing(dry):
     assert tr.global_step == 1 and m.projector._pack_versions is None
     names = set(dry.calls)
     for must in ("ta_logmel_f32", "ta_encoder_forward", "ta_mlp_projector_forward", "ta_mlp_projector_backward",
-                 "ta_audio_index", "ta_lm_forward_loss", "ta_lm_backward", "ta_bernoulli_keep", "ta_grad_sqnorm", "ta_adamw_step"):
+                 "ta_audio_index", "ta_lm_forward_loss", "ta_lm_backward", "ta_bernoulli_keep", "ta_grad_sqnorm", "ta_adamw_step_multi"):
         assert must in names, must
     # random-init path + weight export round trip (bench.py's cpu_baseline leg)
     m2 = ASRModel(cfg, device="cpu", init="random", seed=3)

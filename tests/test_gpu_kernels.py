@@ -384,6 +384,28 @@ def test_adamw_and_clip():
     assert float(d.mean()) < 1e-7 and float(d.max()) < 3e-4
 
 
+def test_adamw_multi_matches_per_segment():
+    """One launch over a flat buffer of segments with their own (lr, weight decay) == one ta_adamw_step per segment, bit for bit."""
+    sizes = [1024, 12, 40000, 4, 5120 * 4, 8]
+    ends = torch.tensor(sizes).cumsum(0)
+    n = int(ends[-1])
+    lrs, wds = [1e-3, 1e-3, 2e-4, 2e-4, 1e-3, 5e-5], [0.01, 0.0, 0.01, 0.0, 0.1, 0.0]
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    pa, ma, va = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb, mb, vb = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sq, cnt = torch.zeros(1, device=DEV), torch.full((1,), 7.0, device=DEV)
+    seg_end, seg_lr, seg_wd = ends.to(DEV), torch.tensor(lrs, device=DEV), torch.tensor(wds, device=DEV)
+    for step in (1, 2, 3):
+        gs = g * step
+        sq.zero_(); ops.grad_sqnorm(gs, sq)
+        o = 0
+        for e, lr, wd in zip(ends.tolist(), lrs, wds):
+            ops.adamw_step(pa[o:e], gs[o:e], ma[o:e], va[o:e], lr * 0.5, 0.9, 0.999, 1e-8, wd, step, sqnorm=sq, max_norm=1.0, denom=cnt)
+            o = e
+        ops.adamw_step_multi(pb, gs, mb, vb, seg_end, seg_lr, seg_wd, 0.5, 0.9, 0.999, 1e-8, step, sqnorm=sq, max_norm=1.0, denom=cnt)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
 def test_bernoulli_keep():
     k = ops.bernoulli_keep(200000, 0.9, 123, DEV)
     assert set(k.unique().tolist()) <= {0.0, 1.0} and abs(float(k.mean()) - 0.9) < 5e-3

@@ -43,40 +43,69 @@ __global__ __launch_bounds__(256) void moe_norm_kernel(const bf16_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------- router (projectors.py:291-325)
-// one wave per token: logits = xn . Wr[e] (fp32), optional multiplicative jitter, fp32 softmax, top-2, renormalise
-// by (sum + 1e-6).  Accumulates sum_t probs[e] and sum_t logsumexp^2 for the aux loss.
+// one wave per ROUTER_TPW tokens (the router rows are read once per wave, not once per token: at one token per wave the kernel
+// streamed E * In floats of Wr per token through L2 -- 320 MB for 4000 tokens, 232 us): logits = xn . Wr[e] (fp32), optional
+// multiplicative jitter, fp32 softmax, top-2, renormalise by (sum + 1e-6).  Accumulates sum_t probs[e] and sum_t logsumexp^2
+// for the aux loss.
+#define ROUTER_TPW 4
 __global__ __launch_bounds__(256) void moe_router_kernel(const bf16_t* __restrict__ xn, const float* __restrict__ wr,
                                                          const float* __restrict__ noise, float* __restrict__ logits_out,
                                                          float* __restrict__ probs_out, int* __restrict__ topi,
                                                          float* __restrict__ topw, float* __restrict__ topraw,
                                                          float* __restrict__ lse_out, float* __restrict__ psum,
                                                          float* __restrict__ zsum, int T, int In, int E) {
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t >= T) return;
+  const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROUTER_TPW;
+  if (t0 >= T) return;
   const int lane = threadIdx.x & 63;
-  float acc[MOE_MAX_E];
+  float acc[ROUTER_TPW][MOE_MAX_E];
 #pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) acc[e] = 0.f;
+  for (int q = 0; q < ROUTER_TPW; ++q)
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) acc[q][e] = 0.f;
   for (int c = lane * 8; c < In; c += 512) {
-    const uint4 v = *(const uint4*)(xn + (long)t * In + c);
-    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-    float xv[8];
+    float xv[ROUTER_TPW][8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { xv[2 * j] = bf2f(u[j] & 0xffff); xv[2 * j + 1] = bf2f(u[j] >> 16); }
+    for (int q = 0; q < ROUTER_TPW; ++q) {
+      const int t = min(t0 + q, T - 1);
+      const uint4 v = *(const uint4*)(xn + (long)t * In + c);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[q][2 * j] = bf2f(u[j] & 0xffff); xv[q][2 * j + 1] = bf2f(u[j] >> 16); }
+    }
 #pragma unroll
     for (int e = 0; e < MOE_MAX_E; ++e) {
       if (e < E) {
         const float4 a = *(const float4*)(wr + (long)e * In + c), b = *(const float4*)(wr + (long)e * In + c + 4);
-        acc[e] += xv[0] * a.x + xv[1] * a.y + xv[2] * a.z + xv[3] * a.w + xv[4] * b.x + xv[5] * b.y + xv[6] * b.z + xv[7] * b.w;
+        // explicit fused multiply-adds in a fixed order: left to the compiler, the contraction of this sum came out differently
+        // for different q, and a token's logits depended (in the last bit) on its place in the group -- enough to flip a top-2 tie
+        const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < ROUTER_TPW; ++q) {
+          float r = acc[q][e];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r = __builtin_fmaf(xv[q][j], wv[j], r);
+          acc[q][e] = r;
+        }
       }
     }
   }
 #pragma unroll
-  for (int e = 0; e < MOE_MAX_E; ++e) acc[e] = wave_sum(acc[e]);
-  if (lane != 0) return;
+  for (int q = 0; q < ROUTER_TPW; ++q)
+#pragma unroll
+    for (int e = 0; e < MOE_MAX_E; ++e) acc[q][e] = __shfl(wave_sum(acc[q][e]), 0, 64);   // lane 0's sum for every token: the butterfly rounds
+                                                                                          // differently per lane, and a token's logits must not depend on its place in the group
+  if (lane >= ROUTER_TPW || t0 + lane >= T) return;
+  const int t = t0 + lane;                            // lane q finishes token t0 + q
   float lg[MOE_MAX_E], m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MOE_MAX_E; ++e) {
+    float a = acc[0][e];
+#pragma unroll
+    for (int q = 1; q < ROUTER_TPW; ++q) a = lane == q ? acc[q][e] : a;
+    lg[e] = a;
+  }
   for (int e = 0; e < E; ++e) {
-    lg[e] = acc[e] * (noise ? noise[(long)t * E + e] : 1.0f);
+    lg[e] = lg[e] * (noise ? noise[(long)t * E + e] : 1.0f);
     m = fmaxf(m, lg[e]);
   }
   float s = 0.f, p[MOE_MAX_E];
@@ -442,7 +471,7 @@ extern "C" int ta_moe_projector_forward(const ta_moe_weights* w, const void* x, 
   if (hipMemsetAsync(t.psum, 0, (MOE_MAX_E + 4) * 4 + 256, st) != hipSuccess) return TA_ERR_LAUNCH;   // psum and zsum are adjacent carves
   TA_LAUNCH(moe_norm_kernel, dim3(ta_cdiv(d.T, 4)), dim3(256), 0, st, (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In,
             w->norm_w, t.xn, t.rstd, d.T, d.In, w->eps);
-  TA_LAUNCH(moe_router_kernel, dim3(ta_cdiv(d.T, 4)), dim3(256), 0, st, t.xn, w->router_w, training ? noise : nullptr, t.logits,
+  TA_LAUNCH(moe_router_kernel, dim3(ta_cdiv(d.T, 4 * ROUTER_TPW)), dim3(256), 0, st, t.xn, w->router_w, training ? noise : nullptr, t.logits,
             t.probs, t.topi, t.topw, t.topraw, t.lse, training ? t.psum : nullptr, t.zsum, d.T, d.In, E);
   TA_LAUNCH(moe_plan_kernel, dim3(1), dim3(1024), 0, st, t.topi, d.T, E, d.Smax, t.seg, t.kr, t.perm, t.slot_of);
   TA_CHECK_LAUNCH();
@@ -472,6 +501,7 @@ extern "C" int ta_moe_projector_forward(const ta_moe_weights* w, const void* x, 
   return TA_OK;
 }
 
+#define CS_CH 128   // row chunks of the bias-gradient column sums: C / 256 x 128 workgroups (16 left a 4-16-workgroup grid: 38 us each)
 static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int S, const float* dy, float d_aux,
                              const float* d_aux_dev, const float* noise, int training, const void* tape, float* d_norm_w,
                              float* d_router_w, float* const* dW1, float* const* db1, float* const* dW2,
@@ -489,13 +519,13 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   TA_LAUNCH(moe_combine_bwd_kernel, dim3(ta_cdiv(d.T, 4)), dim3(256), 0, st, dy, t.y_e, t.slot_of, t.topw, s.dy_slot, s.dtopw,
             s.dout_b, d.T, d.D);
   // ---- shared expert
-  TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.D, 256), 16), dim3(256), 0, st, s.dout_b, d.D, (const int*)nullptr, d.T, db2[E], 16);
+  TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.D, 256), CS_CH), dim3(256), 0, st, s.dout_b, d.D, (const int*)nullptr, d.T, db2[E], CS_CH);
   MRC(ta_transpose_to_bf16(s.dout_b, 0, d.D, 0, 0, s.doutT, d.Tp, d.T, d.D, st));
   MRC(ta_transpose_to_bf16(t.act_s, 0, d.H, 0, 0, s.actsT, d.Tp, d.T, d.H, st));
   MRC(gemm_plain(s.doutT, s.actsT, dW2[E], d.D, d.H, d.Tp, nullptr, 0, moe_splits(d.D, d.H, d.Tp), s.skws, st));
   MRC(gemm_plain(s.dout_b, w->w2_t[E], s.dact_s, d.T, d.H, d.D, nullptr, 1, 1, nullptr, st));
   TA_LAUNCH(gelu_bwd_bf16_kernel, dim3(ew((long)d.T * d.H / 4)), dim3(256), 0, st, s.dact_s, t.h_s, s.dh_s, (long)d.T * d.H / 4);
-  TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.H, 256), 16), dim3(256), 0, st, s.dh_s, d.H, (const int*)nullptr, d.T, db1[E], 16);
+  TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.H, 256), CS_CH), dim3(256), 0, st, s.dh_s, d.H, (const int*)nullptr, d.T, db1[E], CS_CH);
   MRC(ta_transpose_to_bf16(s.dh_s, 0, d.H, 0, 0, s.dhsT, d.Tp, d.T, d.H, st));
   MRC(ta_transpose_to_bf16(t.xn, 0, d.In, 0, 0, s.xnT, d.Tp, d.T, d.In, st));
   MRC(gemm_plain(s.dhsT, s.xnT, dW1[E], d.H, d.In, d.Tp, nullptr, 0, moe_splits(d.H, d.In, d.Tp), s.skws, st));
@@ -508,7 +538,7 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   const long s_dw2 = expert_stride<float>((const void* const*)dW2, E), s_dw1 = expert_stride<float>((const void* const*)dW1, E);
   const bool grp = grouped_enabled();
   for (int e = 0; e < E; ++e)
-    TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.D, 256), 16), tb, 0, st, s.dy_slot, d.D, t.seg + 2 * e, 0, db2[e], 16);
+    TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.D, 256), CS_CH), tb, 0, st, s.dy_slot, d.D, t.seg + 2 * e, 0, db2[e], CS_CH);
   // dW2[e] = dy_e^T act_e: the contraction runs over expert e's (64-aligned) slot range -> the K-slice grouped form
   if (grp && s_dw2 > 0) MRC(ta_gemm_bf16_nt_grouped(s.dyT, s.acteT, dW2[0], d.D, d.H, d.Smax, nullptr, 0, 0, nullptr, nullptr, t.kr, E, 0, s_dw2, st));
   else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dyT, s.acteT, dW2[e], d.D, d.H, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
@@ -518,7 +548,7 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.H, 64), d.Smax / 64), tb, 0, st, s.dh_e, d.H, t.perm, 0, s.dheT, d.Smax);
   TA_LAUNCH(slot_transpose_kernel, dim3(ta_cdiv(d.In, 64), d.Smax / 64), tb, 0, st, t.xn, d.In, t.perm, 1, s.xngT, d.Smax);
   for (int e = 0; e < E; ++e)
-    TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.H, 256), 16), tb, 0, st, s.dh_e, d.H, t.seg + 2 * e, 0, db1[e], 16);
+    TA_LAUNCH(colsum_seg_kernel, dim3(ta_cdiv(d.H, 256), CS_CH), tb, 0, st, s.dh_e, d.H, t.seg + 2 * e, 0, db1[e], CS_CH);
   if (grp && s_dw1 > 0) MRC(ta_gemm_bf16_nt_grouped(s.dheT, s.xngT, dW1[0], d.H, d.In, d.Smax, nullptr, 0, 0, nullptr, nullptr, t.kr, E, 0, s_dw1, st));
   else for (int e = 0; e < E; ++e) MRC(gemm_seg(s.dheT, s.xngT, dW1[e], d.H, d.In, d.Smax, nullptr, 0, nullptr, nullptr, t.kr + 2 * e, st));
   if (grp && s_w1t > 0) MRC(ta_gemm_bf16_nt_grouped(s.dh_e, w->w1_t[0], s.dxn_slot, 2 * d.T, d.In, d.H, nullptr, 0, 0, nullptr, t.seg, nullptr, E, s_w1t, 0, st));
@@ -526,9 +556,9 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   // ---- router and input norm
   TA_LAUNCH(moe_router_bwd_kernel, dim3(ta_cdiv(d.T, 256)), tb, 0, st, s.dtopw, t.probs, t.topi, t.topraw, t.lse,
             training ? noise : nullptr, t.psum, s.dlogits, d.T, E, d_aux, d_aux_dev, w->aux_coef, w->z_coef, training);
-  TA_LAUNCH(moe_router_dw_kernel, dim3(ta_cdiv(d.In, 256), 16), tb, 0, st, s.dlogits, t.xn, d_router_w, d.T, d.In, E, 16);
-  TA_LAUNCH(moe_norm_bwd_kernel, dim3(ta_cdiv(d.In, 256), 32), tb, 0, st, s.dxn_sh, s.dxn_slot, t.slot_of, s.dlogits, w->router_w,
-            (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In, t.rstd, d_norm_w, d.T, d.In, E, 32);
+  TA_LAUNCH(moe_router_dw_kernel, dim3(ta_cdiv(d.In, 256), 64), tb, 0, st, s.dlogits, t.xn, d_router_w, d.T, d.In, E, 64);
+  TA_LAUNCH(moe_norm_bwd_kernel, dim3(ta_cdiv(d.In, 256), 128), tb, 0, st, s.dxn_sh, s.dxn_slot, t.slot_of, s.dlogits, w->router_w,
+            (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In, t.rstd, d_norm_w, d.T, d.In, E, 128);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

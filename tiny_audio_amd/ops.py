@@ -323,6 +323,14 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_nor
                               max_norm, grad_scale, ptr(denom), stream()), "ta_adamw_step")
 
 
+def adamw_step_multi(p, g, m, v, seg_end, seg_lr, seg_wd, lr_mult, beta1, beta2, eps, step, sqnorm=None, max_norm=0.0, grad_scale=1.0,
+                     denom=None):
+    """One launch over a flat buffer of parameter segments (seg_end int64, seg_lr / seg_wd f32, all on the device)."""
+    check(lib().ta_adamw_step_multi(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(seg_end), ptr(seg_lr), ptr(seg_wd), seg_end.numel(),
+                                    lr_mult, beta1, beta2, eps, step, ptr(sqnorm), max_norm, grad_scale, ptr(denom), stream()),
+          "ta_adamw_step_multi")
+
+
 # ----------------------------------------------------------------------------- trainable-projector primitives (nn_prims.hip)
 def gelu_fwd(h):
     _req(h, BF16)

@@ -197,6 +197,7 @@ class ASRTrainer:
         if lm is not None and getattr(lm, "train_base", False):
             lm.accumulate_into_grad = True      # d(loss) is 1 here: weight gradients go straight into the flat buffer
         self.sqnorm = torch.zeros(1, device=self.flat.flat_p.device, dtype=torch.float32)
+        self._adam_table = None
         self.global_step = 0
         self._micro = 0
         self.overlap_allreduce = bool(overlap_allreduce)
@@ -302,11 +303,16 @@ class ASRTrainer:
         self.sqnorm.zero_()
         ops.grad_sqnorm(f.grads, self.sqnorm)
         mult = lr_multiplier(self.global_step - 1, a)
-        for name, o, s, dec in zip(f.names, f.offsets, f.sizes, f.decay):
-            lr_p, wd_p = self.group_hparams(name, dec)
-            ops.adamw_step(f.flat_p[o:o + s], f.flat_g[o:o + s], f.flat_m[o:o + s], f.flat_v[o:o + s], lr_p * mult,
-                           a.adam_beta1, a.adam_beta2, a.adam_epsilon, wd_p, self.global_step,
-                           sqnorm=self.sqnorm, max_norm=a.max_grad_norm, grad_scale=1.0, denom=f.count_slot)
+        if self._adam_table is None:              # per-parameter (learning rate, weight decay) as a device table: ONE launch per step
+            hp = [self.group_hparams(name, dec) for name, dec in zip(f.names, f.decay)]
+            dev = f.flat_p.device
+            self._adam_table = (torch.tensor(f.offsets[1:], dtype=torch.int64, device=dev),
+                                torch.tensor([h[0] for h in hp], dtype=torch.float32, device=dev),
+                                torch.tensor([h[1] for h in hp], dtype=torch.float32, device=dev))
+        seg_end, seg_lr, seg_wd = self._adam_table
+        ops.adamw_step_multi(f.flat_p, f.grads, f.flat_m, f.flat_v, seg_end, seg_lr, seg_wd, mult, a.adam_beta1, a.adam_beta2,
+                             a.adam_epsilon, self.global_step, sqnorm=self.sqnorm, max_norm=a.max_grad_norm, grad_scale=1.0,
+                             denom=f.count_slot)
         with torch.no_grad():
             self._last.copy_(torch.cat([f.loss_slot, f.count_slot, self.sqnorm]))
         self._last_aux = self._aux_sum
