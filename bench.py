@@ -15,7 +15,8 @@ projector (dW) -> flat gradient all-reduce (RCCL, N>1) -> global-norm clip + Ada
 ids) are resident in HBM before the timed region; random-init weights at the true shapes (no checkpoints offline).
 
 The single JSON line carries `roofline` (dominant kernel = the MFMA GEMM, timed in situ with HIP events on
-its launch stream), `logits_full` (the same step with the reference's [B, L, V] logits materialised, timed in the same
+its launch stream), `host_inputs` (the same step fed from pinned host memory: the PCIe-inclusive rate, never `value`),
+`logits_full` (the same step with the reference's [B, L, V] logits materialised, timed in the same
 run) and, at N=1, `cpu_baseline` (the numpy oracle timed on the host cores on one clip: median of 3 after a warm-up).
 """
 import argparse
@@ -147,7 +148,17 @@ def main():
     ids_d, att_d, lab_d = (torch.from_numpy(x).to(dev) for x in (ids, att, lab))
     counts_d = torch.from_numpy(counts).to(dev)
 
-    def step(full_logits=False):
+    host = {}
+
+    def step(full_logits=False, from_host=False):
+        if from_host:                                             # the collator's hand-over: raw waveforms + token tensors in pinned host memory
+            wav_s = host["wav"].to(dev, non_blocking=True)
+            ids_s, att_s, lab_s, cnt_s = (host[k].to(dev, non_blocking=True) for k in ("ids", "att", "lab", "cnt"))
+            feats, _mask = fe.extract(wav_s, lens)
+            rows, tg, _n = ops.label_rows(lab_s)
+            trainer.training_step(dict(input_ids=ids_s, input_features=feats, attention_mask=att_s, labels=lab_s,
+                                       audio_token_counts=cnt_s, label_meta=(rows, tg, n_lab)), return_logits=full_logits)
+            return
         feats, _mask = fe.extract(wav, lens)                      # K1 on the GPU, inside the timed step
         # label positions: the device kernel runs inside the step; their COUNT is host knowledge of whoever built the
         # labels (the collator builds them on the CPU), which saves the one device->host sync of the reference's path
@@ -194,6 +205,18 @@ def main():
         logits_full = {"ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(world * B * 10.0 * k2 / dt2, 1), "steps": k2,
                        "note": "additionally writes outputs.logits [B, L, V] bf16 every step, as the reference's forward does"}
         trainer.last_logits = None
+
+    # the same step fed from HOST buffers (20.5 MB of f32 waveforms + the token tensors per step over PCIe, pinned, same stream):
+    # what the boundary costs when the dataloader hands over host memory.  Never `value`.
+    host_inputs = None
+    if not a.no_logits_full:
+        host.update(wav=wav.cpu().pin_memory(), ids=ids_d.cpu().pin_memory(), att=att_d.cpu().pin_memory(),
+                    lab=lab_d.cpu().pin_memory(), cnt=counts_d.cpu().pin_memory())
+        k3 = max(1, min(a.steps, 4))
+        dt3 = timed(k3, 1, full_logits=full, from_host=True)
+        host_inputs = {"ms_per_step": round(dt3 / k3 * 1e3, 3), "value": round(world * B * 10.0 * k3 / dt3, 1), "steps": k3,
+                       "note": "inputs copied from pinned host memory inside every step (PCIe-inclusive rate)"}
+        host.clear()
 
     roofline = None
     if not a.no_roofline:
@@ -264,7 +287,7 @@ def main():
                    "mode": "async on RCCL's stream, update applied after the next step's frozen-encoder forward" if overlap
                            else "synchronous on the compute stream",
                    "note": "events on the compute stream around the collective (sync) / around the wait for it (async)"},
-               "logits_full": logits_full, "roofline": roofline, "cpu_baseline": cpu}
+               "logits_full": logits_full, "host_inputs": host_inputs, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
