@@ -388,18 +388,22 @@ typedef struct { long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs; } ta
 int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
                         int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, const ta_attn_layout* lay,
                         hipStream_t st);
+/* backward of the causal GQA attention (head_dim 128).  QT / KT / dOT are IGNORED since round 2 (pass NULL): the kernels read the
+ * transposed fragments out of their row tiles with ds_read_b64_tr_b16, so no transposed image has to be produced or staged. */
 int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V, const void* dO,
                      long dO_stride, const void* dOT, const float* LSE, const float* Delta, const int* kmask,
                      void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal,
                      float scale, hipStream_t st);
 int ta_enc_qkv_post(const void* qkv, const float* cosT, const float* sinT, void* Q, void* K, void* VT, int B, int H,
                     int S, int Sp, hipStream_t st);
+/* QT / KT / VT: transposed images [B, heads, 128, Lp]; any of them may be NULL (not written).  The forward attention needs VT only. */
 int ta_lm_qkv_post_fwd(const void* qkv0, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
                        const int* pos, void* Q, void* K, void* V, void* QT, void* KT, void* VT, float* rq, float* rk,
                        int B, int Hq, int Hkv, int L, int Lp, float eps, hipStream_t st);
 int ta_lm_qkv_post_bwd(const void* dQ, const void* dK, const void* dV, const void* qkv0, const float* rq,
                        const float* rk, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
                        const int* pos, void* dqkv, float* dqn_accum, float* dkn_accum, int B, int Hq, int Hkv, int L, hipStream_t st);   /* dqn/dkn_accum [128] or NULL: += the q_norm / k_norm weight gradients */
+/* Delta = rowsum(dO o O); dOT (optional, may be NULL): the transposed dO image, no longer read by ta_attention_bwd */
 int ta_attn_bwd_prep(const void* dO, const void* O, float* Delta, void* dOT, int B, int Hq, int L, int Lp,
                      hipStream_t st);
 

@@ -267,8 +267,7 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
     p.q = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
     p.k = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
     p.v = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
-    p.qt = c.take<bf16_t>((size_t)B * d.nq * d.hd * d.Lp);
-    p.kt = c.take<bf16_t>((size_t)B * d.nkv * d.hd * d.Lp);
+    p.qt = nullptr; p.kt = nullptr;                 // no Q^T / K^T images: the attention backward reads them transposed out of its row tiles
     p.vt = c.take<bf16_t>((size_t)B * d.nkv * d.hd * d.Lp);
     p.ao = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
     p.lse = c.take<float>((size_t)B * d.nq * L);
@@ -325,7 +324,7 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dact = c.take<bf16_t>((size_t)d.M * d.F);
   s.dgu = c.take<bf16_t>((size_t)d.M * 2 * d.F);
   s.dao = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
-  s.dot = c.take<bf16_t>((size_t)B * d.nq * d.hd * d.Lp);
+  s.dot = nullptr;                                  // likewise no dO^T image
   s.delta = c.take<float>((size_t)B * d.nq * L);
   s.dq = c.take<bf16_t>((size_t)d.M * d.nq * d.hd);
   s.dk = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);

@@ -126,6 +126,24 @@ __device__ __forceinline__ bf16x8 read_colfrag(const char* tile, int row, int c0
   return r.v;
 }
 
+// The same fragment (row d = dt * 16 + l15 of the [d][64] image, columns [c0, c0+4) and [c1, c1+4)) read TRANSPOSED out of the
+// ROW tile ([64 rows][HD], RowTile layout) with ds_read_b64_tr_b16 (gfx950): in each group of 16 lanes, lane L receives element
+// (L & 3) of the 8-byte chunks addressed by lanes (L >> 2) + 4 j, j = 0..3.  Lane n of a group addresses (row c + (n >> 2),
+// columns dt * 16 + 4 (n & 3) ..): lane L then holds rows c .. c+3 of column dt * 16 + L.  The backward kernels use it for the
+// K^T / Q^T / dO^T operands, so the producers need not write (and the backward need not stage) transposed images.
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+template <int HD>
+__device__ __forceinline__ bf16x8 read_colfrag_tr(const char* rowtile, int dt, int l15, int c0, int c1) {
+  const int dcol = dt * 16 + 4 * (l15 & 3);                     // first of the 4 columns of this lane's 8-byte chunk
+  const int chunk = dcol >> 3, half = (dcol >> 2) & 1;
+  const int r0 = c0 + (l15 >> 2), r1 = c1 + (l15 >> 2);
+  const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off(r0, chunk) + half * 8));
+  const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off(r1, chunk) + half * 8));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 // ============================================================================ forward
 // cross-lane combines over the 4 lane groups (g = lane>>4) that share a query column, on the VALU (no LDS round trip):
 // permlane16_swap(x,x) leaves {own, partner(xor 16)} in the two results, permlane32_swap likewise for xor 32.
@@ -493,8 +511,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
                                                  int B, int Hq, int Hkv, int L, int Lp, float scale) {
   char* Ks = smem;
   char* Vs = Ks + RowTile<HD>::BYTES;
-  char* KTs = Vs + RowTile<HD>::BYTES;
-  int* Ms = (int*)(KTs + ColTile<HD>::BYTES);
+  int* Ms = (int*)(Vs + RowTile<HD>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int nq = (L + 63) / 64, grp = Hq / Hkv;
   int group, member;
@@ -506,7 +523,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
   const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
   const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
   const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
-  const bf16_t* KTb = KT + ((long)(b * Hkv + hk) * HD) * Lp;
+  (void)KT; (void)Lp;
   const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;   // token-major rows
   const float sl2 = scale * LOG2E;
   bf16x8 qf[HD / 32], dof[HD / 32];
@@ -527,7 +544,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     {
       RowStage<HD> a; a.load(Kb, HD, key0, L, tid); a.store(Ks, tid);
       RowStage<HD> c; c.load(Vb, HD, key0, L, tid); c.store(Vs, tid);
-      ColStage<HD> d; d.load(KTb, Lp, key0, tid); d.store(KTs, tid);
       if (tid < 64) { const int kk = key0 + tid; Ms[tid] = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
     }
     __syncthreads();
@@ -561,7 +577,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
       const bf16x8 dsb = pack_p(s[2 * kp], s[2 * kp + 1]);
 #pragma unroll
       for (int dt = 0; dt < HD / 16; ++dt) {
-        const bf16x8 ka = read_colfrag(KTs, dt * 16 + l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
+        const bf16x8 ka = read_colfrag_tr<HD>(Ks, dt, l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4);
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq[dt], 0, 0, 0);
       }
     }
@@ -591,9 +607,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
                                                   float scale) {
   char* Qs = smem;
   char* dOs = Qs + RowTile<HD>::BYTES;
-  char* QTs = dOs + RowTile<HD>::BYTES;
-  char* dOTs = QTs + ColTile<HD>::BYTES;
-  float* Ls = (float*)(dOTs + ColTile<HD>::BYTES);   // [64] lse * log2e
+  float* Ls = (float*)(dOs + RowTile<HD>::BYTES);    // [64] lse * log2e
   float* Ds = Ls + 64;                               // [64] delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int grp = Hq / Hkv;
@@ -620,16 +634,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   for (int hh = 0; hh < grp; ++hh) {
     const int h = hk * grp + hh;
     const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
-    const bf16_t* QTb = QT + ((long)(b * Hq + h) * HD) * Lp;
     const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;
-    const bf16_t* dOTb = dOT + ((long)(b * Hq + h) * HD) * Lp;
     for (int qt = qt_begin; qt < nq; ++qt) {
       const int q0 = qt * 64;
       {
         RowStage<HD> a; a.load(Qb, HD, q0, L, tid); a.store(Qs, tid);
         RowStage<HD> c; c.load(dOb, dO_stride, q0, L, tid); c.store(dOs, tid);
-        ColStage<HD> d; d.load(QTb, Lp, q0, tid); d.store(QTs, tid);
-        ColStage<HD> e; e.load(dOTb, Lp, q0, tid); e.store(dOTs, tid);
         if (tid < 64) {
           const int qq = q0 + tid;
           const bool v = qq < L;
@@ -674,8 +684,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
 #pragma unroll
         for (int dt = 0; dt < HD / 16; ++dt) {
           const int c0 = (2 * qp) * 16 + g * 4, c1 = (2 * qp + 1) * 16 + g * 4;
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag(dOTs, dt * 16 + l15, c0, c1), pb, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag(QTs, dt * 16 + l15, c0, c1), dsb, dk[dt], 0, 0, 0);
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag_tr<HD>(dOs, dt, l15, c0, c1), pb, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag_tr<HD>(Qs, dt, l15, c0, c1), dsb, dk[dt], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -786,8 +796,8 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
-  const size_t lds_q = 2 * RowTile<HD>::BYTES + ColTile<HD>::BYTES + 64 * 4;
-  const size_t lds_kv = 2 * RowTile<HD>::BYTES + 2 * ColTile<HD>::BYTES + 128 * 4;
+  const size_t lds_q = 2 * RowTile<HD>::BYTES + 64 * 4;
+  const size_t lds_kv = 2 * RowTile<HD>::BYTES + 128 * 4;      // K^T / Q^T / dO^T fragments are read transposed out of the row tiles
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void lm_qkv_post_fwd_kernel(const bf16_t* __re
   const long ld = (long)(Hq + 2 * Hkv) * HD;
   const long coff = (long)hh * HD;
   bf16_t* out = (sec == 0 ? Qo : (sec == 1 ? Ko : Vo)) + ((long)b * Hs + head) * L * HD;
-  bf16_t* outT = (sec == 0 ? QTo : (sec == 1 ? KTo : VTo)) + ((long)b * Hs + head) * HD * Lp;
+  bf16_t* outT_base = sec == 0 ? QTo : (sec == 1 ? KTo : VTo);      // null: that transposed image is not wanted (Q^T / K^T since the
+  bf16_t* outT = outT_base + ((long)b * Hs + head) * HD * Lp;       // backward reads them out of its row tiles; V^T feeds the forward)
   float w1[8], w2[8];
   if (sec < 2) { const float* nw = sec == 0 ? qn_w : kn_w; load8f(nw + 8 * j, w1); load8f(nw + 64 + 8 * j, w2); }
 #pragma unroll
@@ -159,10 +160,13 @@ __global__ __launch_bounds__(256) void lm_qkv_post_fwd_kernel(const bf16_t* __re
       *(uint4*)(out + (long)l * HD + 8 * j) = v1;
       *(uint4*)(out + (long)l * HD + 64 + 8 * j) = v2;
     }
-    bf16_t* tr = tile + tl * TS + 8 * j;            // rows are 264 B: 8-B aligned
-    *(uint2*)(tr) = make_uint2(v1.x, v1.y); *(uint2*)(tr + 4) = make_uint2(v1.z, v1.w);
-    *(uint2*)(tr + 64) = make_uint2(v2.x, v2.y); *(uint2*)(tr + 68) = make_uint2(v2.z, v2.w);
+    if (outT_base) {
+      bf16_t* tr = tile + tl * TS + 8 * j;          // rows are 264 B: 8-B aligned
+      *(uint2*)(tr) = make_uint2(v1.x, v1.y); *(uint2*)(tr + 4) = make_uint2(v1.z, v1.w);
+      *(uint2*)(tr + 64) = make_uint2(v2.x, v2.y); *(uint2*)(tr + 68) = make_uint2(v2.z, v2.w);
+    }
   }
+  if (!outT_base) return;
   __syncthreads();
   store_transposed<HD>(tile, TS, outT, Lp, l0, tid);
 }
@@ -266,10 +270,13 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
     for (int q = 0; q < 8; ++q) dot += a[q] * e[q] + c[q] * f[q];
     dot = oct_sum(dot);
     if (l < L && j == 0) Delta[((long)b * Hq + h) * L + l] = dot;
-    bf16_t* tr = tile + tl * TS + 8 * j;
-    *(uint2*)(tr) = make_uint2(d1.x, d1.y); *(uint2*)(tr + 4) = make_uint2(d1.z, d1.w);
-    *(uint2*)(tr + 64) = make_uint2(d2.x, d2.y); *(uint2*)(tr + 68) = make_uint2(d2.z, d2.w);
+    if (dOT) {
+      bf16_t* tr = tile + tl * TS + 8 * j;
+      *(uint2*)(tr) = make_uint2(d1.x, d1.y); *(uint2*)(tr + 4) = make_uint2(d1.z, d1.w);
+      *(uint2*)(tr + 64) = make_uint2(d2.x, d2.y); *(uint2*)(tr + 68) = make_uint2(d2.z, d2.w);
+    }
   }
+  if (!dOT) return;                                  // the backward reads dO^T out of its row tiles (ds_read_b64_tr_b16): no image needed
   __syncthreads();
   store_transposed<HD>(tile, TS, dOT + ((long)b * Hq + h) * HD * Lp, Lp, l0, tid);
 }
