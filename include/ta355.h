@@ -394,6 +394,13 @@ int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* K
                      long dO_stride, const void* dOT, const float* LSE, const float* Delta, const int* kmask,
                      void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal,
                      float scale, hipStream_t st);
+/* the same with ta_lm_qkv_post_bwd fused into its epilogue (frozen q_norm / k_norm): d(qkv0) token-major [B*L, (Hq + 2 Hkv) * 128] is
+ * written directly from the f32 accumulators; no head-major dQ / dK / dV (tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 backward) */
+int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
+                         const float* Delta, const int* kmask, const void* qkv0, const float* rq, const float* rk,
+                         const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
+                         void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                         hipStream_t st);
 int ta_enc_qkv_post(const void* qkv, const float* cosT, const float* sinT, void* Q, void* K, void* VT, int B, int H,
                     int S, int Sp, hipStream_t st);
 /* QT / KT / VT: transposed images [B, heads, 128, Lp]; any of them may be NULL (not written).  The forward attention needs VT only. */

@@ -283,6 +283,32 @@ def test_lm_qkv_post_fwd_bwd():
     assert relerr(ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn.detach(), kn.detach(), cos, sin, B, Hq, Hkv, L), dqkv) == 0.0
 
 
+@pytest.mark.parametrize("L,masked", [(192, True), (70, False), (150, True)])
+def test_attention_bwd_with_fused_qkv_post(L, masked):
+    """ta_attention_bwd_qkv (RoPE^T + per-head RMSNorm backward + head-major -> token-major in the epilogue, from the f32
+    accumulators) against ta_attention_bwd followed by ta_lm_qkv_post_bwd (which rounds dQ / dK / dV to bf16 in between)."""
+    B, Hq, Hkv, hd = 2, 4, 2, 128
+    NQKV = (Hq + 2 * Hkv) * hd
+    x0 = rnd(B * L, NQKV, seed=1).to(BF16)
+    qn, kn = 1 + 0.1 * rnd(hd, seed=2), 1 + 0.1 * rnd(hd, seed=3)
+    cos, sin = rope_tables(256, hd, 1e6)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn, kn, cos, sin, B, Hq, Hkv, L)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, L, dtype=torch.int32, device=DEV); kmask[1, L - 9:] = 0
+    scale = hd ** -0.5
+    O, lse = ops.attention_fwd(Q, K, VT, L, True, scale, kmask=kmask)
+    dO = rnd(B * L, Hq * hd, seed=9).to(BF16)
+    delta, dOT = ops.attn_bwd_prep(dO, O, B, Hq, L)
+    dQ, dK, dV = ops.attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, True, scale, kmask=kmask)
+    ref = ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn, kn, cos, sin, B, Hq, Hkv, L)
+    got = ops.attention_bwd_qkv(Q, K, V, dO, lse, delta, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+    assert torch.isfinite(got.float()).all()
+    assert relerr(got, ref) < 1.5e-2 and cos_sim(got, ref) > 0.9999
+    # the v section is a pure relayout of the same accumulators: identical
+    assert torch.equal(got.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:], ref.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:])
+
+
 # ----------------------------------------------------------------------------- element-wise / movement
 def test_swiglu():
     M, F = 300, 768

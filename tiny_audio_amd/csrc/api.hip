@@ -685,10 +685,18 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
-    RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
-                        B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
-    RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv,
-                          g ? g->dqn : nullptr, g ? g->dkn : nullptr, B, d.nq, d.nkv, L, st));
+    // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue (TA355_ATTN_BWD_FUSED=0:
+    // head-major dQ / dK / dV + ta_lm_qkv_post_bwd, which also serves the trainable-norm case)
+    static const bool fuse_post = [] { const char* e = getenv("TA355_ATTN_BWD_FUSED"); return !(e && *e == '0'); }();
+    if (fuse_post && !(g && (g->dqn || g->dkn))) {
+      RC(ta_attention_bwd_qkv(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
+                              w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    } else {
+      RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,
+                          B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+      RC(ta_lm_qkv_post_bwd(s.dq, s.dk, s.dv, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, s.dqkv,
+                            g ? g->dqn : nullptr, g ? g->dkn : nullptr, B, d.nq, d.nkv, L, st));
+    }
     if (g) RC(wgrad(s.dqkv, d.NQKV, p.xn_s, d.D, g->dwqkv));
     if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
     RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));

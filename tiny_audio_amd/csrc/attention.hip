@@ -500,6 +500,71 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
   }   // pass
 }
 
+// ---- optional fused epilogue of the backward: the q|k|v post-processing backward (RoPE^T, per-head RMSNorm backward, head-major ->
+// token-major) applied to the f32 accumulators, so dQ / dK / dV never travel through memory.  qkv0 == nullptr: plain head-major
+// dQ / dK / dV as before (ta_lm_qkv_post_bwd then does this work; it is still needed when the q_norm / k_norm weights train).
+// Math as lm_qkv_post_bwd_kernel (qkv_post.hip), TF:models/qwen3/modeling_qwen3.py:50-64,211-240.
+struct QkvPostBwd {
+  const bf16_t* qkv0;                // pre-norm q | k | v, token-major [B*L, (Hq + 2 Hkv) * 128]
+  const float *rq, *rk;              // 1 / rms of every (token, head) row
+  const float *qn_w, *kn_w;          // q_norm / k_norm weights [128]
+  const float *cosT, *sinT;          // [positions][64]
+  const int* pos;                    // position of token (b, l), or null = l
+  bf16_t* dqkv;                      // out: token-major gradient of qkv0
+};
+// acc[dt]: lane (l15, g) holds columns dt * 16 + 4 g .. + 3 of ONE row (the four g lanes share the row); columns d and d + 64
+// (dt and dt + 4) are RoPE partners and sit in the same lane.  sec 0 = q head `head`, 1 = k head.  All 64 lanes take part (rows
+// beyond L are clamped by the caller and not stored).
+template <int HD>
+__device__ __forceinline__ void qkv_post_bwd_row(const f32x4* acc, const QkvPostBwd& F, int sec, long tok, int pos_row, int head, int Hq,
+                                                 int Hkv, int g, bool store) {
+  static_assert(HD == 128, "Qwen3 head_dim");
+  const long ld = (long)(Hq + 2 * Hkv) * HD;
+  const int Hs = sec == 0 ? Hq : Hkv;
+  const long coff = (long)(sec == 0 ? head : Hq + head) * HD;
+  const bf16_t* src = F.qkv0 + tok * ld + coff;
+  const float* nw = sec == 0 ? F.qn_w : F.kn_w;
+  const float r = (sec == 0 ? F.rq : F.rk)[tok * Hs + head];
+  const int p = F.pos ? F.pos[tok] : pos_row;
+  float d1[4][4], d2[4][4], x1[4][4], x2[4][4];
+  float dot = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int col = dt * 16 + g * 4;
+    const uint2 xa = *(const uint2*)(src + col), xb = *(const uint2*)(src + 64 + col);
+    const float4 c = *(const float4*)(F.cosT + (long)p * 64 + col), sn = *(const float4*)(F.sinT + (long)p * 64 + col);
+    const float4 wa = *(const float4*)(nw + col), wb = *(const float4*)(nw + 64 + col);
+    const float xs1[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
+    const float xs2[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
+    const float cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+    const float w1[4] = {wa.x, wa.y, wa.z, wa.w}, w2[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = acc[dt][e], bq = acc[dt + 4][e];
+      const float dn1 = a * cs[e] + bq * ss[e], dn2 = bq * cs[e] - a * ss[e];      // RoPE^T
+      x1[dt][e] = xs1[e] * r; x2[dt][e] = xs2[e] * r;                              // x-hat
+      d1[dt][e] = dn1 * w1[e]; d2[dt][e] = dn2 * w2[e];
+      dot += d1[dt][e] * x1[dt][e] + d2[dt][e] * x2[dt][e];
+    }
+  }
+  dot += __shfl_xor(dot, 16, 64);
+  dot += __shfl_xor(dot, 32, 64);
+  const float md = dot / (float)HD;
+  if (!store) return;
+  bf16_t* dst = F.dqkv + tok * ld + coff;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int col = dt * 16 + g * 4;
+    uint2 o1, o2;
+    o1.x = pack2bf(r * (d1[dt][0] - x1[dt][0] * md), r * (d1[dt][1] - x1[dt][1] * md));
+    o1.y = pack2bf(r * (d1[dt][2] - x1[dt][2] * md), r * (d1[dt][3] - x1[dt][3] * md));
+    o2.x = pack2bf(r * (d2[dt][0] - x2[dt][0] * md), r * (d2[dt][1] - x2[dt][1] * md));
+    o2.y = pack2bf(r * (d2[dt][2] - x2[dt][2] * md), r * (d2[dt][3] - x2[dt][3] * md));
+    *(uint2*)(dst + col) = o1;
+    *(uint2*)(dst + 64 + col) = o2;
+  }
+}
+
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
 template <int HD, bool CAUSAL>
@@ -508,7 +573,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
                                                  const bf16_t* __restrict__ dO, long dO_stride,
                                                  const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                  const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
-                                                 int B, int Hq, int Hkv, int L, int Lp, float scale) {
+                                                 int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F) {
   char* Ks = smem;
   char* Vs = Ks + RowTile<HD>::BYTES;
   int* Ms = (int*)(Vs + RowTile<HD>::BYTES);
@@ -583,6 +648,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     }
     __syncthreads();
   }
+  if (F.qkv0) {
+    if constexpr (HD == 128) qkv_post_bwd_row<HD>(dq, F, 0, (long)b * L + qr, qr, h, Hq, Hkv, g, qrow < L);
+    return;
+  }
   if (qrow < L) {
     bf16_t* drow = dQ + ((long)(b * Hq + h) * L + qrow) * HD;
 #pragma unroll
@@ -604,7 +673,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
                                                   const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                   const int* __restrict__ kmask, bf16_t* __restrict__ dK,
                                                   bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
-                                                  float scale) {
+                                                  float scale, const QkvPostBwd& F) {
   char* Qs = smem;
   char* dOs = Qs + RowTile<HD>::BYTES;
   float* Ls = (float*)(dOs + RowTile<HD>::BYTES);    // [64] lse * log2e
@@ -691,6 +760,21 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       __syncthreads();
     }
   }
+  if (F.qkv0) {
+    if constexpr (HD == 128) {
+      const long tok = (long)b * L + kr;
+      qkv_post_bwd_row<HD>(dk, F, 1, tok, kr, hk, Hq, Hkv, g, krow < L);
+      if (krow < L) {                                          // dV: head-major -> token-major, nothing else
+        bf16_t* vro = F.dqkv + tok * ((long)(Hq + 2 * Hkv) * HD) + (long)(Hq + Hkv + hk) * HD;
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          uint2 u; u.x = pack2bf(dv[dt][0], dv[dt][1]); u.y = pack2bf(dv[dt][2], dv[dt][3]);
+          *(uint2*)(vro + dt * 16 + g * 4) = u;
+        }
+      }
+    }
+    return;
+  }
   if (krow < L) {
     bf16_t* kro = dK + ((long)(b * Hkv + hk) * L + krow) * HD;
     bf16_t* vro = dV + ((long)(b * Hkv + hk) * L + krow) * HD;
@@ -714,7 +798,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
                                                        const bf16_t* __restrict__ dOT, const float* __restrict__ LSE,
                                                        const float* __restrict__ Delta, const int* __restrict__ kmask,
                                                        bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
-                                                       int B, int Hq, int Hkv, int L, int Lp, float scale, int n_dkv) {
+                                                       int B, int Hq, int Hkv, int L, int Lp, float scale, int n_dkv,
+                                                       const QkvPostBwd F) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (n_dkv < 0) {
     // interleaved order (TA355_ATTN_BWD_MERGED=2): the nq dK/dV workgroups and the grp * nq dQ workgroups of one (clip, kv head) get CONSECUTIVE ids
@@ -725,15 +810,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     if (!decode_group(blockIdx.x, gsz, B * Hkv, group, member)) return;
     const int xcd = group & 7, j = group >> 3;
     if (member < nq)
-      attn_bwd_dkv_body<HD, CAUSAL>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale);
+      attn_bwd_dkv_body<HD, CAUSAL>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F);
     else
-      attn_bwd_dq_body<HD, CAUSAL>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale);
+      attn_bwd_dq_body<HD, CAUSAL>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F);
     return;
   }
   if ((int)blockIdx.x < n_dkv)
-    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale);
+    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F);
   else
-    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale);
+    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F);
 }
 
 // ----------------------------------------------------------------------------- C-ABI
@@ -789,14 +874,12 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
   return TA_OK;
 }
 
-extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V,
-                                const void* dO, long dO_stride, const void* dOT, const float* LSE, const float* Delta,
-                                const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp,
-                                int head_dim, int causal, float scale, hipStream_t st) {
+static int attention_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
+                                const float* Delta, const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L,
+                                int Lp, int head_dim, int causal, float scale, const QkvPostBwd& F, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
-  const size_t lds_q = 2 * RowTile<HD>::BYTES + 64 * 4;
   const size_t lds_kv = 2 * RowTile<HD>::BYTES + 128 * 4;      // K^T / Q^T / dO^T fragments are read transposed out of the row tiles
   static bool attr_done = false;
   if (!attr_done) {
@@ -805,7 +888,6 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
     attr_done = true;
   }
   const int n_dq = grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv), n_dkv = grouped_grid(ta_cdiv(L, 64), B * Hkv);
-  (void)lds_q;
   dim3 grid(n_dq + n_dkv), blk(256);
   static const bool split = [] { const char* e = getenv("TA355_ATTN_BWD_MERGED"); return e && *e == '0'; }();   // experiment: two launches
   // TA355_ATTN_BWD_MERGED=2 (experiment): the dK/dV and dQ workgroups of one (clip, kv head) interleaved on one XCD instead of every
@@ -813,27 +895,41 @@ extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, co
   // than the shared L2 lines help
   static const bool interleaved = [] { const char* e = getenv("TA355_ATTN_BWD_MERGED"); return e && *e == '2'; }();
   const int n_dkv_arg = interleaved ? -1 : n_dkv;
-  if (split) {
-    // the same bodies as two launches: n_dkv = grid (all dK / dV) resp. n_dkv = 0 (all dQ)
-    if (causal) {
-      TA_LAUNCH((attn_bwd_kernel<HD, true>), dim3(n_dq), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, 0);
-      TA_LAUNCH((attn_bwd_kernel<HD, true>), dim3(n_dkv), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
-    } else {
-      TA_LAUNCH((attn_bwd_kernel<HD, false>), dim3(n_dq), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, 0);
-      TA_LAUNCH((attn_bwd_kernel<HD, false>), dim3(n_dkv), blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-                (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv);
-    }
-  } else if (causal)
-    TA_LAUNCH((attn_bwd_kernel<HD, true>), grid, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-              (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK,
-              (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv_arg);
-  else
-    TA_LAUNCH((attn_bwd_kernel<HD, false>), grid, blk, lds_kv, st, (const bf16_t*)Q, (const bf16_t*)QT, (const bf16_t*)K, (const bf16_t*)KT,
-              (const bf16_t*)V, (const bf16_t*)dO, dO_stride, (const bf16_t*)dOT, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK,
-              (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv_arg);
+  const bf16_t* nul = nullptr;
+#define BWD(C_, GRID_, NDKV_)                                                                                                       \
+  TA_LAUNCH((attn_bwd_kernel<HD, C_>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V,      \
+            (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F)
+  if (split) {                                       // the same bodies as two launches: n_dkv = 0 (all dQ) resp. n_dkv = grid (all dK / dV)
+    if (causal) { BWD(true, dim3(n_dq), 0); BWD(true, dim3(n_dkv), n_dkv); }
+    else { BWD(false, dim3(n_dq), 0); BWD(false, dim3(n_dkv), n_dkv); }
+  } else if (causal) {
+    BWD(true, grid, n_dkv_arg);
+  } else {
+    BWD(false, grid, n_dkv_arg);
+  }
+#undef BWD
   TA_CHECK_LAUNCH();
   return TA_OK;
+}
+
+extern "C" int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V,
+                                const void* dO, long dO_stride, const void* dOT, const float* LSE, const float* Delta,
+                                const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp,
+                                int head_dim, int causal, float scale, hipStream_t st) {
+  (void)QT; (void)KT; (void)dOT;
+  QkvPostBwd F = {};
+  return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, Delta, kmask, dQ, dK, dV, B, Hq, Hkv, L, Lp, head_dim, causal, scale, F, st);
+}
+
+// The same with the q|k|v post-processing backward fused into the epilogue: writes d(qkv0) token-major [B*L, (Hq + 2 Hkv) * 128]
+// directly (RoPE^T, per-head RMSNorm backward of q and k, v copied through); no head-major dQ / dK / dV.  Frozen q_norm / k_norm only.
+extern "C" int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
+                                    const float* Delta, const int* kmask, const void* qkv0, const float* rq, const float* rk,
+                                    const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
+                                    void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                                    hipStream_t st) {
+  if (!qkv0 || !dqkv || !rq || !rk || !qn_w || !kn_w || !cosT || !sinT) return TA_ERR_ARG;
+  QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
+  return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, Delta, kmask, nullptr, nullptr, nullptr, B, Hq, Hkv, L, Lp, head_dim, causal,
+                              scale, F, st);
 }

@@ -185,6 +185,17 @@ def attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, causal, scale, kmask=
     return dQ, dK, dV
 
 
+def attention_bwd_qkv(Q, K, V, dO, lse, delta, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
+    """Causal GQA attention backward with the q|k|v post-processing backward in its epilogue: returns d(qkv0) token-major."""
+    B, Hq, _, hd = Q.shape
+    Hkv, Lp = K.shape[1], pad64(L)
+    dqkv = torch.empty_like(qkv0)
+    check(lib().ta_attention_bwd_qkv(ptr(Q), ptr(K), ptr(V), ptr(dO), dO.shape[-1], ptr(lse), ptr(delta), ptr(kmask), ptr(qkv0),
+                                     ptr(rq), ptr(rk), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv,
+                                     L, Lp, hd, 1, scale, stream()), "ta_attention_bwd_qkv")
+    return dqkv
+
+
 def lm_qkv_post_fwd(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, eps=1e-6, pos=None):
     hd, Lp, dev = 128, pad64(L), qkv0.device
     mk = lambda h: torch.empty((B, h, L, hd), device=dev, dtype=BF16)
