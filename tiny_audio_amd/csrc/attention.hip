@@ -512,56 +512,78 @@ struct QkvPostBwd {
   const int* pos;                    // position of token (b, l), or null = l
   bf16_t* dqkv;                      // out: token-major gradient of qkv0
 };
-// acc[dt]: lane (l15, g) holds columns dt * 16 + 4 g .. + 3 of ONE row (the four g lanes share the row); columns d and d + 64
-// (dt and dt + 4) are RoPE partners and sit in the same lane.  sec 0 = q head `head`, 1 = k head.  All 64 lanes take part (rows
-// beyond L are clamped by the caller and not stored).
-template <int HD>
-__device__ __forceinline__ void qkv_post_bwd_row(const f32x4* acc, const QkvPostBwd& F, int sec, long tok, int pos_row, int head, int Hq,
-                                                 int Hkv, int g, bool store) {
-  static_assert(HD == 128, "Qwen3 head_dim");
+// The workgroup's 64 rows x 128 columns of f32 accumulators are first laid out row-major in LDS (the tiles are free by then), then
+// re-read with the producer kernels' mapping -- 8 lanes per row, lane j owning columns [8j, 8j+8) and [64+8j, 64+8j+8), RoPE partners
+// in the same lane -- so that qkv0, the tables and the result move as 16-byte chunks of whole rows.  (A first version applied the
+// same math in the accumulator layout, 8-byte accesses of 16 different rows per instruction: 20 us per layer instead of ~9.)
+constexpr int QP_PITCH = 128 * 4 + 16;               // bytes per staged f32 row
+__device__ __forceinline__ float oct_sum8(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+// stage: lane (l15, g) of wave w writes row w * 16 + l15, columns dt * 16 + 4 g .. + 3 of acc[dt]
+__device__ __forceinline__ void qkv_stage_f32(char* st, const f32x4* acc, int wave, int l15, int g) {
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+    *(float4*)(st + (wave * 16 + l15) * QP_PITCH + (dt * 16 + g * 4) * 4) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
+}
+// sec 0 / 1: RoPE^T + RMSNorm backward of q / k head `head`; sec 2: v, copied through.  row0 = first sequence row of the tile.
+__device__ __forceinline__ void qkv_post_bwd_tile(const char* st, const QkvPostBwd& F, int sec, int b, int row0, int L, int head,
+                                                  int Hq, int Hkv, int tid) {
+  constexpr int HD = 128;
   const long ld = (long)(Hq + 2 * Hkv) * HD;
-  const int Hs = sec == 0 ? Hq : Hkv;
-  const long coff = (long)(sec == 0 ? head : Hq + head) * HD;
-  const bf16_t* src = F.qkv0 + tok * ld + coff;
-  const float* nw = sec == 0 ? F.qn_w : F.kn_w;
-  const float r = (sec == 0 ? F.rq : F.rk)[tok * Hs + head];
-  const int p = F.pos ? F.pos[tok] : pos_row;
-  float d1[4][4], d2[4][4], x1[4][4], x2[4][4];
-  float dot = 0.f;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const int col = dt * 16 + g * 4;
-    const uint2 xa = *(const uint2*)(src + col), xb = *(const uint2*)(src + 64 + col);
-    const float4 c = *(const float4*)(F.cosT + (long)p * 64 + col), sn = *(const float4*)(F.sinT + (long)p * 64 + col);
-    const float4 wa = *(const float4*)(nw + col), wb = *(const float4*)(nw + 64 + col);
-    const float xs1[4] = {bf2f((bf16_t)(xa.x & 0xffff)), bf2f((bf16_t)(xa.x >> 16)), bf2f((bf16_t)(xa.y & 0xffff)), bf2f((bf16_t)(xa.y >> 16))};
-    const float xs2[4] = {bf2f((bf16_t)(xb.x & 0xffff)), bf2f((bf16_t)(xb.x >> 16)), bf2f((bf16_t)(xb.y & 0xffff)), bf2f((bf16_t)(xb.y >> 16))};
-    const float cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
-    const float w1[4] = {wa.x, wa.y, wa.z, wa.w}, w2[4] = {wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a = acc[dt][e], bq = acc[dt + 4][e];
-      const float dn1 = a * cs[e] + bq * ss[e], dn2 = bq * cs[e] - a * ss[e];      // RoPE^T
-      x1[dt][e] = xs1[e] * r; x2[dt][e] = xs2[e] * r;                              // x-hat
-      d1[dt][e] = dn1 * w1[e]; d2[dt][e] = dn2 * w2[e];
-      dot += d1[dt][e] * x1[dt][e] + d2[dt][e] * x2[dt][e];
-    }
+  const int Hs = sec == 0 ? Hq : Hkv, j = tid & 7;
+  const long coff = (long)(sec == 0 ? head : (sec == 1 ? Hq + head : Hq + Hkv + head)) * HD;
+  float w1[8], w2[8];
+  if (sec < 2) {
+    const float* nw = sec == 0 ? F.qn_w : F.kn_w;
+    const float4 a = *(const float4*)(nw + 8 * j), b4 = *(const float4*)(nw + 8 * j + 4), c = *(const float4*)(nw + 64 + 8 * j), d = *(const float4*)(nw + 64 + 8 * j + 4);
+    w1[0] = a.x; w1[1] = a.y; w1[2] = a.z; w1[3] = a.w; w1[4] = b4.x; w1[5] = b4.y; w1[6] = b4.z; w1[7] = b4.w;
+    w2[0] = c.x; w2[1] = c.y; w2[2] = c.z; w2[3] = c.w; w2[4] = d.x; w2[5] = d.y; w2[6] = d.z; w2[7] = d.w;
   }
-  dot += __shfl_xor(dot, 16, 64);
-  dot += __shfl_xor(dot, 32, 64);
-  const float md = dot / (float)HD;
-  if (!store) return;
-  bf16_t* dst = F.dqkv + tok * ld + coff;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const int col = dt * 16 + g * 4;
-    uint2 o1, o2;
-    o1.x = pack2bf(r * (d1[dt][0] - x1[dt][0] * md), r * (d1[dt][1] - x1[dt][1] * md));
-    o1.y = pack2bf(r * (d1[dt][2] - x1[dt][2] * md), r * (d1[dt][3] - x1[dt][3] * md));
-    o2.x = pack2bf(r * (d2[dt][0] - x2[dt][0] * md), r * (d2[dt][1] - x2[dt][1] * md));
-    o2.y = pack2bf(r * (d2[dt][2] - x2[dt][2] * md), r * (d2[dt][3] - x2[dt][3] * md));
-    *(uint2*)(dst + col) = o1;
-    *(uint2*)(dst + 64 + col) = o2;
+  for (int it = 0; it < 2; ++it) {
+    const int tl = (tid >> 3) + it * 32, l = row0 + tl;
+    const bool live = l < L;
+    const int lc = live ? l : L - 1;                  // clamped rows compute (the octet shuffles stay uniform) but never store
+    const long tok = (long)b * L + lc;
+    const float* sr = (const float*)(st + tl * QP_PITCH);
+    float d1[8], d2[8];
+    { const float4 a = *(const float4*)(sr + 8 * j), b4 = *(const float4*)(sr + 8 * j + 4), c = *(const float4*)(sr + 64 + 8 * j), d = *(const float4*)(sr + 64 + 8 * j + 4);
+      d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w; d1[4] = b4.x; d1[5] = b4.y; d1[6] = b4.z; d1[7] = b4.w;
+      d2[0] = c.x; d2[1] = c.y; d2[2] = c.z; d2[3] = c.w; d2[4] = d.x; d2[5] = d.y; d2[6] = d.z; d2[7] = d.w; }
+    if (sec < 2) {
+      const bf16_t* src = F.qkv0 + tok * ld + coff;
+      const uint4 xa = *(const uint4*)(src + 8 * j), xb = *(const uint4*)(src + 64 + 8 * j);
+      const uint32_t ua[4] = {xa.x, xa.y, xa.z, xa.w}, ub[4] = {xb.x, xb.y, xb.z, xb.w};
+      float x1[8], x2[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        x1[2 * k] = bf2f((bf16_t)(ua[k] & 0xffff)); x1[2 * k + 1] = bf2f((bf16_t)(ua[k] >> 16));
+        x2[2 * k] = bf2f((bf16_t)(ub[k] & 0xffff)); x2[2 * k + 1] = bf2f((bf16_t)(ub[k] >> 16));
+      }
+      const int p = F.pos ? F.pos[tok] : lc;
+      const float4 c0 = *(const float4*)(F.cosT + (long)p * 64 + 8 * j), c1 = *(const float4*)(F.cosT + (long)p * 64 + 8 * j + 4);
+      const float4 s0 = *(const float4*)(F.sinT + (long)p * 64 + 8 * j), s1 = *(const float4*)(F.sinT + (long)p * 64 + 8 * j + 4);
+      const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float r = (sec == 0 ? F.rq : F.rk)[tok * Hs + head];
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dn1 = d1[e] * cs[e] + d2[e] * sn[e], dn2 = d2[e] * cs[e] - d1[e] * sn[e];     // RoPE^T
+        x1[e] *= r; x2[e] *= r;                                                               // x-hat
+        d1[e] = dn1 * w1[e]; d2[e] = dn2 * w2[e];
+        dot += d1[e] * x1[e] + d2[e] * x2[e];
+      }
+      const float md = oct_sum8(dot) / (float)HD;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { d1[e] = r * (d1[e] - x1[e] * md); d2[e] = r * (d2[e] - x2[e] * md); }
+    }
+    if (live) {
+      bf16_t* dst = F.dqkv + ((long)b * L + l) * ld + coff;
+      *(uint4*)(dst + 8 * j) = make_uint4(pack2bf(d1[0], d1[1]), pack2bf(d1[2], d1[3]), pack2bf(d1[4], d1[5]), pack2bf(d1[6], d1[7]));
+      *(uint4*)(dst + 64 + 8 * j) = make_uint4(pack2bf(d2[0], d2[1]), pack2bf(d2[2], d2[3]), pack2bf(d2[4], d2[5]), pack2bf(d2[6], d2[7]));
+    }
   }
 }
 
@@ -649,7 +671,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     __syncthreads();
   }
   if (F.qkv0) {
-    if constexpr (HD == 128) qkv_post_bwd_row<HD>(dq, F, 0, (long)b * L + qr, qr, h, Hq, Hkv, g, qrow < L);
+    if constexpr (HD == 128) {
+      qkv_stage_f32(smem, dq, wave, l15, g);                 // the last loop iteration ended with a barrier: the tiles are free
+      __syncthreads();
+      qkv_post_bwd_tile(smem, F, 0, b, qt * 64, L, h, Hq, Hkv, tid);
+    }
     return;
   }
   if (qrow < L) {
@@ -762,16 +788,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   }
   if (F.qkv0) {
     if constexpr (HD == 128) {
-      const long tok = (long)b * L + kr;
-      qkv_post_bwd_row<HD>(dk, F, 1, tok, kr, hk, Hq, Hkv, g, krow < L);
-      if (krow < L) {                                          // dV: head-major -> token-major, nothing else
-        bf16_t* vro = F.dqkv + tok * ((long)(Hq + 2 * Hkv) * HD) + (long)(Hq + Hkv + hk) * HD;
-#pragma unroll
-        for (int dt = 0; dt < HD / 16; ++dt) {
-          uint2 u; u.x = pack2bf(dv[dt][0], dv[dt][1]); u.y = pack2bf(dv[dt][2], dv[dt][3]);
-          *(uint2*)(vro + dt * 16 + g * 4) = u;
-        }
-      }
+      qkv_stage_f32(smem, dk, wave, l15, g);
+      __syncthreads();
+      qkv_post_bwd_tile(smem, F, 1, b, kt_idx * 64, L, hk, Hq, Hkv, tid);
+      __syncthreads();
+      qkv_stage_f32(smem, dv, wave, l15, g);
+      __syncthreads();
+      qkv_post_bwd_tile(smem, F, 2, b, kt_idx * 64, L, hk, Hq, Hkv, tid);
     }
     return;
   }
@@ -880,7 +903,8 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
-  const size_t lds_kv = 2 * RowTile<HD>::BYTES + 128 * 4;      // K^T / Q^T / dO^T fragments are read transposed out of the row tiles
+  // K^T / Q^T / dO^T fragments are read transposed out of the row tiles; the fused epilogue re-uses the space for a [64][128] f32 image
+  const size_t lds_kv = (2 * RowTile<HD>::BYTES + 128 * 4 > 64 * (size_t)QP_PITCH) ? 2 * RowTile<HD>::BYTES + 128 * 4 : 64 * (size_t)QP_PITCH;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
