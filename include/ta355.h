@@ -388,6 +388,13 @@ typedef struct { long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs; } ta
 int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT, void* O, float* LSE, const int* kmask, int B,
                         int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale, const ta_attn_layout* lay,
                         hipStream_t st);
+/* ta_lm_qkv_post_fwd + ta_attention_fwd in ONE launch for short causal sequences (head_dim 128, L <= 192, (Hq / Hkv) * ceil(L / 32)
+ * <= 12; otherwise TA_ERR_ARG and nothing is launched): qkv0 is the pre-norm q | k | v GEMM output [B*L, (Hq + 2 Hkv) * 128]; writes
+ * O [B*L, Hq*128], LSE and the backward's operands Q / K (normalised, rotated) and V head-major [B, heads, L, 128], rq / rk (1 / rms per
+ * (token, head)).  tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 forward. */
+int ta_attention_fwd_qkv(const void* qkv0, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
+                         const int* pos, void* Q, void* K, void* V, float* rq, float* rk, void* O, float* LSE,
+                         const int* kmask, int B, int Hq, int Hkv, int L, float scale, float eps, hipStream_t st);
 /* backward of the causal GQA attention (head_dim 128).  QT / KT / dOT are IGNORED since round 2 (pass NULL): the kernels read the
  * transposed fragments out of their row tiles with ds_read_b64_tr_b16, so no transposed image has to be produced or staged. */
 int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* KT, const void* V, const void* dO,

@@ -283,6 +283,29 @@ def test_lm_qkv_post_fwd_bwd():
     assert relerr(ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn.detach(), kn.detach(), cos, sin, B, Hq, Hkv, L), dqkv) == 0.0
 
 
+@pytest.mark.parametrize("L,masked", [(192, True), (70, False), (150, True), (33, False)])
+def test_attention_fwd_with_fused_qkv_post(L, masked):
+    """ta_attention_fwd_qkv (QK-norm + RoPE + head split in the attention kernel's staging, V read transposed out of its row tile)
+    against ta_lm_qkv_post_fwd followed by ta_attention_fwd."""
+    B, Hq, Hkv, hd = 2, 4, 2, 128
+    NQKV = (Hq + 2 * Hkv) * hd
+    x0 = rnd(B * L, NQKV, seed=1).to(BF16)
+    qn, kn = 1 + 0.1 * rnd(hd, seed=2), 1 + 0.1 * rnd(hd, seed=3)
+    cos, sin = rope_tables(256, hd, 1e6)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn, kn, cos, sin, B, Hq, Hkv, L)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, L, dtype=torch.int32, device=DEV); kmask[1, L - 9:] = 0
+    scale = hd ** -0.5
+    O, lse = ops.attention_fwd(Q, K, VT, L, True, scale, kmask=kmask)
+    O2, lse2, Q2, K2, V2, rq2, rk2 = ops.attention_fwd_qkv(x0, qn, kn, cos, sin, B, Hq, Hkv, L, scale, kmask=kmask)
+    assert torch.equal(V2, V)
+    assert relerr(rq2, rq) < 1e-6 and relerr(rk2, rk) < 1e-6
+    assert relerr(Q2, Q) < 4e-3 and relerr(K2, K) < 4e-3          # the sums of squares are reduced in a different order: last-bit differences of 1/rms
+    assert relerr(O2, O) < 1e-2 and cos_sim(O2, O) > 0.9999
+    assert float((lse2 - lse).abs().max()) < 2e-2
+
+
 @pytest.mark.parametrize("L,masked", [(192, True), (70, False), (150, True)])
 def test_attention_bwd_with_fused_qkv_post(L, masked):
     """ta_attention_bwd_qkv (RoPE^T + per-head RMSNorm backward + head-major -> token-major in the epilogue, from the f32

@@ -445,15 +445,22 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
     if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
     RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
-    RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
-                          p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
+    // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging (TA355_ATTN_FWD_FUSED=0: two kernels)
+    static const bool fuse_fwd = [] { const char* e = getenv("TA355_ATTN_FWD_FUSED"); return !(e && *e == '0'); }();
+    const bool fused_fwd = fuse_fwd && d.hd == 128 && L <= 192 && (d.nq / d.nkv) * ((L + 31) / 32) <= 12;
+    if (fused_fwd)
+      RC(ta_attention_fwd_qkv(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.rq, p.rk, p.ao, p.lse, kmask,
+                              B, d.nq, d.nkv, L, scale, w->eps, st));
+    else
+      RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
+                            p.rk, B, d.nq, d.nkv, L, d.Lp, w->eps, st));
     if (kcache) {   // greedy decoding: keys / values of the prompt go to the cache [layer, B, Hkv, Lmax, hd]
       const size_t row = (size_t)L * d.hd * 2, pitch = (size_t)Lmax * d.hd * 2, rows = (size_t)B * d.nkv;
       if (hipMemcpy2DAsync(kcache + (size_t)l * rows * Lmax * d.hd, pitch, p.k, row, row, rows, hipMemcpyDeviceToDevice, st) != hipSuccess ||
           hipMemcpy2DAsync(vcache + (size_t)l * rows * Lmax * d.hd, pitch, p.v, row, row, rows, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return TA_ERR_LAUNCH;
     }
-    RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    if (!fused_fwd) RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
     RC(res_gemm(p.ao, Lw.wo, p.x1, d.nq * d.hd, p.x_in));
     bf16_t* xn2 = keep ? p.xn2_s : s.xn;

@@ -500,6 +500,249 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
   }   // pass
 }
 
+// ============================================================================ forward, short sequences, straight from the q|k|v GEMM output
+// attn_fwd_gqa_kernel with ta_lm_qkv_post_fwd folded in: one workgroup = one (clip, kv head) reads the PRE-norm q | k | v rows of its
+// GQA group from the token-major GEMM output, applies the per-head RMSNorm (q_norm / k_norm) and RoPE while staging
+// (TF:models/qwen3/modeling_qwen3.py:50-64,211-240), keeps K and V as ROW tiles in LDS (the V^T operand of the second product is read
+// transposed with ds_read_b64_tr_b16, the row of ones that accumulates the softmax denominator is a constant fragment) and writes
+// what the backward needs -- normalised Q / K and V head-major, 1/rms per (token, head) -- on the way.  No separate post kernel, no
+// V^T image.
+//   staging: 16 lanes per key row (one 16-B chunk of 8 dims each; chunk c and c + 8 are RoPE partners, 8 lanes apart)
+//   queries: in the MFMA fragment layout (lane = row l15, dims ks * 32 + g * 8 ..): the 4 g lanes share a row, dims d and d + 64 are
+//            fragments ks and ks + 2 of the same lane
+template <int HD, int MAXT, int QSUB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t* __restrict__ qkv0, const float* __restrict__ qn_w,
+                                                               const float* __restrict__ kn_w, const float* __restrict__ cosT,
+                                                               const float* __restrict__ sinT, const int* __restrict__ pos,
+                                                               bf16_t* __restrict__ Qo, bf16_t* __restrict__ Ko, bf16_t* __restrict__ Vo,
+                                                               float* __restrict__ rq, float* __restrict__ rk, bf16_t* __restrict__ O,
+                                                               float* __restrict__ LSE, const int* __restrict__ kmask, int B, int Hq,
+                                                               int Hkv, int L, float scale, float eps) {
+  static_assert(HD == 128, "Qwen3 head_dim");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ND = HD / 16, NT_ = NW * 64;
+  char* Ks = smem;                                   // MAXT row tiles of normalised, rotated K
+  char* Vs = smem + MAXT * RowTile<HD>::BYTES;       // MAXT row tiles of V
+  int* Ms = (int*)(Vs + MAXT * RowTile<HD>::BYTES);  // key mask, MAXT * 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
+  const int grp = Hq / Hkv, cph = (L + 16 * QSUB - 1) / (16 * QSUB), nchunk = grp * cph;
+  const long ld = (long)(Hq + 2 * Hkv) * HD;
+  const float sl2 = scale * LOG2E;
+  const int ntiles = (L + KV_TILE - 1) / KV_TILE;
+  // ---- stage K and V once: all global loads first, then the per-row work (PER chunks of K and of V per thread)
+  constexpr int PER = (MAXT * 64 * (HD / 8) + NT_ - 1) / NT_;
+  uint4 kreg[PER], vreg[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+    if (t < ntiles) {
+      const int r = w / (HD / 8), c = w % (HD / 8);
+      int gr = t * KV_TILE + r; if (gr > L - 1) gr = L - 1;
+      const bf16_t* row = qkv0 + ((long)b * L + gr) * ld;
+      kreg[i] = *(const uint4*)(row + (long)(Hq + hk) * HD + c * 8);
+      vreg[i] = *(const uint4*)(row + (long)(Hq + Hkv + hk) * HD + c * 8);
+    }
+  }
+  {
+    const int c = tid & 15;                           // NT_ is a multiple of 16: a thread keeps its chunk column in every pass
+    const float4 wa = *(const float4*)(kn_w + c * 8), wb = *(const float4*)(kn_w + c * 8 + 4);
+    const float wk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+      if (t < ntiles) {                               // whole 16-lane rows take the same branch
+        const int r = w / (HD / 8);
+        const int krow = t * KV_TILE + r, gr = krow > L - 1 ? L - 1 : krow;
+        const long tok = (long)b * L + gr;
+        const uint32_t u[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+        float x[8], ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        const float rr = rsqrtf(ss / (float)HD + eps);
+        const int p = pos ? pos[tok] : gr;
+        const float4 c0 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8), c1 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8 + 4);
+        const float4 s0 = *(const float4*)(sinT + (long)p * 64 + (c & 7) * 8), s1 = *(const float4*)(sinT + (long)p * 64 + (c & 7) * 8 + 4);
+        const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float n = x[e] * rr * wk[e];
+          const float np = __shfl_xor(n, 8, 64);      // the RoPE partner (dims d <-> d + 64) sits 8 lanes away
+          y[e] = c < 8 ? n * cs[e] - np * sn[e] : n * cs[e] + np * sn[e];
+        }
+        const uint4 kv = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
+        *(uint4*)(Ks + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c)) = kv;
+        *(uint4*)(Vs + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c)) = vreg[i];
+        if (krow < L) {
+          *(uint4*)(Ko + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = kv;
+          *(uint4*)(Vo + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = vreg[i];
+          if (c == 0) rk[tok * Hkv + hk] = rr;
+        }
+      }
+    }
+  }
+  for (int i = tid; i < ntiles * 64; i += NT_) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
+  __syncthreads();
+  const bf16x8 ones = (bf16x8){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8 zeros = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16x8 one_row = l15 == 0 ? ones : zeros;     // row 0 of the extra block is all ones: it accumulates l = sum_k P[q, k]
+  for (int pass = 0; pass < 2; ++pass) {
+  const int chunk = pass == 0 ? wave : nchunk - 1 - wave;
+  if (chunk >= nchunk || (pass == 1 && chunk < NW)) continue;          // wave-uniform
+  const int h = hk * grp + chunk / cph;
+  const int q0 = (chunk % cph) * 16 * QSUB;
+  bf16x8 qf[QSUB][HD / 32];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) {
+    const int qrow = q0 + sub * 16 + l15, qr = qrow > L - 1 ? L - 1 : qrow;
+    const long tok = (long)b * L + qr;
+    const bf16_t* src = qkv0 + tok * ld + (long)h * HD;
+    float x[HD / 32][8], ss = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const uint4 v = *(const uint4*)(src + ks * 32 + g * 8);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { x[ks][2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); x[ks][2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[ks][e] * x[ks][e];
+    }
+    ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+    const float rr = rsqrtf(ss / (float)HD + eps);
+    const int p = pos ? pos[tok] : qr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                   // dims d = ks * 32 + g * 8 + e < 64 and their partners d + 64 (fragment ks + 2)
+      const int d0 = ks * 32 + g * 8;
+      const float4 c0 = *(const float4*)(cosT + (long)p * 64 + d0), c1 = *(const float4*)(cosT + (long)p * 64 + d0 + 4);
+      const float4 s0 = *(const float4*)(sinT + (long)p * 64 + d0), s1 = *(const float4*)(sinT + (long)p * 64 + d0 + 4);
+      const float4 wa = *(const float4*)(qn_w + d0), wb = *(const float4*)(qn_w + d0 + 4);
+      const float4 wc = *(const float4*)(qn_w + 64 + d0), wd = *(const float4*)(qn_w + 64 + d0 + 4);
+      const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float w1[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w}, w2[8] = {wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w};
+      float y1[8], y2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float n1 = x[ks][e] * rr * w1[e], n2 = x[ks + 2][e] * rr * w2[e];
+        y1[e] = n1 * cs[e] - n2 * sn[e];
+        y2[e] = n2 * cs[e] + n1 * sn[e];
+      }
+      union { bf16x8 v; uint4 u; } a, c;
+      a.u = make_uint4(pack2bf(y1[0], y1[1]), pack2bf(y1[2], y1[3]), pack2bf(y1[4], y1[5]), pack2bf(y1[6], y1[7]));
+      c.u = make_uint4(pack2bf(y2[0], y2[1]), pack2bf(y2[2], y2[3]), pack2bf(y2[4], y2[5]), pack2bf(y2[6], y2[7]));
+      qf[sub][ks] = a.v; qf[sub][ks + 2] = c.v;
+      if (qrow < L) {
+        bf16_t* qdst = Qo + ((long)(b * Hq + h) * L + qrow) * HD;
+        *(uint4*)(qdst + d0) = a.u;
+        *(uint4*)(qdst + 64 + d0) = c.u;
+      }
+    }
+    if (qrow < L && g == 0) rq[tok * Hq + h] = rr;
+  }
+  f32x4 o[QSUB][ND + 1];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub)
+#pragma unroll
+    for (int i = 0; i <= ND; ++i) o[sub][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run[QSUB];
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) m_run[sub] = NEG_BIG;
+  const int my_tiles = min(ntiles, (q0 + 16 * QSUB - 1) / KV_TILE + 1);      // causal: keys beyond the wave's last query never count
+  for (int t = 0; t < my_tiles; ++t) {
+    const int key0 = t * KV_TILE;
+    const char* Kt = Ks + t * RowTile<HD>::BYTES;
+    const char* Vt = Vs + t * RowTile<HD>::BYTES;
+    f32x4 s[QSUB][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int sub = 0; sub < QSUB; ++sub) s[sub][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Kt + RowTile<HD>::off(kt * 16 + l15, ks * 4 + g));
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          s[sub][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[sub][ks], s[sub][kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int sub = 0; sub < QSUB; ++sub) {
+      const int qrow = q0 + sub * 16 + l15;
+      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (key0 + KV_TILE - 1 <= q0 + sub * 16);
+      if (!full) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const int4 mk = *(const int4*)(Ms + key0 + kt * 16 + g * 4);
+          const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = key0 + kt * 16 + g * 4 + r;
+            const bool v = (key <= qrow) & (mkv[r] != 0);
+            s[sub][kt][r] = v ? s[sub][kt][r] : -INFINITY;
+          }
+        }
+      }
+      float mloc = max3(s[sub][0][0], s[sub][0][1], s[sub][0][2]);
+      mloc = max3(mloc, s[sub][0][3], s[sub][1][0]);
+      mloc = max3(mloc, s[sub][1][1], s[sub][1][2]);
+      mloc = max3(mloc, s[sub][1][3], s[sub][2][0]);
+      mloc = max3(mloc, s[sub][2][1], s[sub][2][2]);
+      mloc = max3(mloc, s[sub][2][3], s[sub][3][0]);
+      mloc = max3(mloc, s[sub][3][1], s[sub][3][2]);
+      mloc = fmaxf(mloc, s[sub][3][3]);
+      const float m_new = fmaxf(m_run[sub], group_max(mloc));
+      if (__any(m_new != m_run[sub])) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run[sub] - m_new) * sl2);
+#pragma unroll
+        for (int i = 0; i <= ND; ++i) { o[sub][i][0] *= alpha; o[sub][i][1] *= alpha; o[sub][i][2] *= alpha; o[sub][i][3] *= alpha; }
+        m_run[sub] = m_new;
+      }
+      const float mb = m_new * sl2;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[sub][kt][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][kt][r], sl2, -mb));
+    }
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      bf16x8 pb[QSUB];
+#pragma unroll
+      for (int sub = 0; sub < QSUB; ++sub) pb[sub] = pack_p(s[sub][2 * kp], s[sub][2 * kp + 1]);
+#pragma unroll
+      for (int dt = 0; dt <= ND; ++dt) {
+        const bf16x8 va = dt < ND ? read_colfrag_tr<HD>(Vt, dt, l15, (2 * kp) * 16 + g * 4, (2 * kp + 1) * 16 + g * 4) : one_row;
+#pragma unroll
+        for (int sub = 0; sub < QSUB; ++sub)
+          o[sub][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[sub], o[sub][dt], 0, 0, 0);
+        if (dt & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int sub = 0; sub < QSUB; ++sub) {
+    const int qrow = q0 + sub * 16 + l15;
+    const float l_run = __shfl(o[sub][ND][0], l15, 64);
+    if (qrow < L) {
+      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      bf16_t* orow = O + ((long)b * L + qrow) * ((long)Hq * HD) + (long)h * HD;
+#pragma unroll
+      for (int dt = 0; dt < ND; dt += 2) {
+        const uint32_t x0 = pack2bf(o[sub][dt][0] * inv, o[sub][dt][1] * inv), x1 = pack2bf(o[sub][dt][2] * inv, o[sub][dt][3] * inv);
+        const uint32_t y0 = pack2bf(o[sub][dt + 1][0] * inv, o[sub][dt + 1][1] * inv), y1 = pack2bf(o[sub][dt + 1][2] * inv, o[sub][dt + 1][3] * inv);
+        const auto a = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        *(uint4*)(orow + 16 * (dt + (g & 1)) + 8 * (g >> 1)) = make_uint4(a[0], c[0], a[1], c[1]);
+      }
+      if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
+    }
+  }
+  }   // pass
+}
+
 // ---- optional fused epilogue of the backward: the q|k|v post-processing backward (RoPE^T, per-head RMSNorm backward, head-major ->
 // token-major) applied to the f32 accumulators, so dQ / dK / dV never travel through memory.  qkv0 == nullptr: plain head-major
 // dQ / dK / dV as before (ta_lm_qkv_post_bwd then does this work; it is still needed when the q_norm / k_norm weights train).
@@ -932,6 +1175,26 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
     BWD(false, grid, n_dkv_arg);
   }
 #undef BWD
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// ta_lm_qkv_post_fwd + ta_attention_fwd in one launch for the LM's short causal sequences (head_dim 128, L <= 192, GQA group x
+// ceil(L / 32) <= 12): reads the pre-norm q | k | v GEMM output, writes O, LSE and the backward's operands (Q, K, V head-major,
+// rq, rk).  Returns TA_ERR_ARG when the shape is outside that envelope (callers fall back to the two-kernel path).
+extern "C" int ta_attention_fwd_qkv(const void* qkv0, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
+                                    const int* pos, void* Q, void* K, void* V, float* rq, float* rk, void* O, float* LSE,
+                                    const int* kmask, int B, int Hq, int Hkv, int L, float scale, float eps, hipStream_t st) {
+  if (B <= 0 || L <= 0) return TA_OK;
+  if (!qkv0 || !Q || !K || !V || !rq || !rk || !O || Hkv <= 0 || Hq % Hkv) return TA_ERR_ARG;
+  const int grp = Hq / Hkv;
+  if (L > 192 || grp * ((L + 31) / 32) > 12) return TA_ERR_ARG;
+  constexpr int MAXT = 3, QS = 2, NW = 6;
+  const size_t lds = 2 * MAXT * RowTile<128>::BYTES + MAXT * 64 * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  TA_LAUNCH((attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>), dim3(B * Hkv), dim3(NW * 64), lds, st, (const bf16_t*)qkv0, qn_w, kn_w, cosT, sinT,
+            pos, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, rq, rk, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, scale, eps);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

@@ -185,6 +185,19 @@ def attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, causal, scale, kmask=
     return dQ, dK, dV
 
 
+def attention_fwd_qkv(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, scale, eps=1e-6, kmask=None, pos=None):
+    """ta_lm_qkv_post_fwd + ta_attention_fwd in one launch (short causal sequences): returns O, LSE, Q, K, V, rq, rk."""
+    hd, dev = 128, qkv0.device
+    mk = lambda h: torch.empty((B, h, L, hd), device=dev, dtype=BF16)
+    Q, K, V = mk(Hq), mk(Hkv), mk(Hkv)
+    rq = torch.empty((B * L, Hq), device=dev, dtype=F32); rk = torch.empty((B * L, Hkv), device=dev, dtype=F32)
+    O = torch.empty((B * L, Hq * hd), device=dev, dtype=BF16)
+    lse = torch.empty((B, Hq, L), device=dev, dtype=F32)
+    check(lib().ta_attention_fwd_qkv(ptr(qkv0), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(Q), ptr(K), ptr(V), ptr(rq),
+                                     ptr(rk), ptr(O), ptr(lse), ptr(kmask), B, Hq, Hkv, L, scale, eps, stream()), "ta_attention_fwd_qkv")
+    return O, lse, Q, K, V, rq, rk
+
+
 def attention_bwd_qkv(Q, K, V, dO, lse, delta, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
     """Causal GQA attention backward with the q|k|v post-processing backward in its epilogue: returns d(qkv0) token-major."""
     B, Hq, _, hd = Q.shape
