@@ -151,6 +151,22 @@ __device__ __forceinline__ bf16x8 read_colfrag_tr(const char* rowtile, int dt, i
 // hazard recognizer does not see inside asm, and once no other VALU work separated it from the QK^T MFMAs it read their
 // accumulators before the matrix pipe had written them -- a stale, smaller row maximum, i.e. run-to-run 1-ulp noise.)
 __device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// the same for a sum; and sums / exchanges inside a 16-lane row on the DPP path (no LDS crossbar: __shfl_xor lowers to ds_bpermute)
+__device__ __forceinline__ float group_sum(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum8(float v) {                 // over the 8 lanes of a half row: quad, quad, half-row mirror
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float row_sum16(float v) { v = row_sum8(v); v += dpp_mov<0x140>(v); return v; }   // + row mirror
+__device__ __forceinline__ float row_xor8(float v) { return dpp_mov<0x128>(v); }                              // row_ror:8 = lane ^ 8
 __device__ __forceinline__ float group_max(float x) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
         for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+        ss = row_sum16(ss);
         const float rr = rsqrtf(ss / (float)HD + eps);
         const int p = pos ? pos[tok] : gr;
         const float4 c0 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8), c1 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8 + 4);
@@ -571,7 +587,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float n = x[e] * rr * wk[e];
-          const float np = __shfl_xor(n, 8, 64);      // the RoPE partner (dims d <-> d + 64) sits 8 lanes away
+          const float np = row_xor8(n);               // the RoPE partner (dims d <-> d + 64) sits 8 lanes away
           y[e] = c < 8 ? n * cs[e] - np * sn[e] : n * cs[e] + np * sn[e];
         }
         const uint4 kv = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss += x[ks][e] * x[ks][e];
     }
-    ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+    ss = group_sum(ss);
     const float rr = rsqrtf(ss / (float)HD + eps);
     const int p = pos ? pos[tok] : qr;
 #pragma unroll
@@ -760,10 +776,7 @@ struct QkvPostBwd {
 // in the same lane -- so that qkv0, the tables and the result move as 16-byte chunks of whole rows.  (A first version applied the
 // same math in the accumulator layout, 8-byte accesses of 16 different rows per instruction: 20 us per layer instead of ~9.)
 constexpr int QP_PITCH = 128 * 4 + 16;               // bytes per staged f32 row
-__device__ __forceinline__ float oct_sum8(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-  return v;
-}
+__device__ __forceinline__ float oct_sum8(float v) { return row_sum8(v); }
 // stage: lane (l15, g) of wave w writes row w * 16 + l15, columns dt * 16 + 4 g .. + 3 of acc[dt]
 __device__ __forceinline__ void qkv_stage_f32(char* st, const f32x4* acc, int wave, int l15, int g) {
 #pragma unroll
