@@ -57,7 +57,7 @@ def parse():
                     help="full decoder fine-tuning (configs/experiments/embedded.yaml): freeze_language_model=False, MLP projector "
                          "H=2048, decoder lr 1e-4; every LM weight trains (0.6 B fp32 masters, AdamW, bf16 W / W^T images rebuilt per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-logits-full", action="store_true", help="skip the extra timed leg with materialised outputs.logits")
+    ap.add_argument("--no-logits-full", action="store_true", help="skip the two extra timed legs: materialised outputs.logits, and inputs fed from pinned host memory")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: all-reduce synchronously on the compute stream")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
