@@ -1,0 +1,300 @@
+"""-m gpu, round 3: parity WHERE THE BENCHMARK RUNS (VERDICT r02 "Next round" item 1).
+
+  (a) ONE 10 s clip through the full-depth model (32 encoder + 28 LM layers, V = 151 670, the benchmarked widths)
+      against the fp32 numpy oracle -- MLP (configs[1]), MoE with jitter 0 (configs[3]) and LoRA with B != 0 (configs[4]):
+      loss, per-token NLL, gradient cosines.  The measured bf16-vs-fp32 drift of each run is written to
+      gpurun_out/r03_full_depth_drift.json (and quoted in DESIGN.md section 1a).
+  (b) B = 32 (the bench batch) against the same clips run as 8 x B = 4: other tile variants / grids, same numbers.
+  (c) every distinct (M, N, K, epilogue) GEMM the B = 32 step launches, under the AUTOMATIC tile choice, vs an fp32 matmul.
+
+Stated tolerances (bf16 MFMA operands and bf16 residual streams -- the reference's model_dtype -- against an fp32 oracle over
+60 layers): loss relative 1e-2; per-token NLL max-abs 0.25 and RMS 0.08 (values ~ ln V = 11.9); projector / adapter
+gradient cosine >= 0.995 per tensor (0.999 at depth 2 in test_gpu_parity.py).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import features as OF
+from oracle import model as OM
+from oracle import weights as OW
+
+if torch.cuda.is_available():
+    from tiny_audio_amd import ops
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.asr_processing import LogMelFeatureExtractor
+
+DEV = "cuda"
+BF16, F32 = torch.bfloat16, torch.float32
+LOSS_REL, NLL_MAXABS, NLL_RMS, GRAD_COS = 1e-2, 0.25, 0.08, 0.995
+
+
+def cosine(a, b):
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    if not a.any() and not b.any():
+        return 1.0
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def npy(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _oracle_cfgs(cfg):
+    enc, lm = cfg.audio_config, cfg.text_config
+    ecfg = OW.enc_config(enc.hidden_size, enc.intermediate_size, enc.num_hidden_layers, enc.num_attention_heads)
+    lcfg = OW.lm_config(lm.vocab_size, lm.hidden_size, lm.intermediate_size, lm.num_hidden_layers, lm.num_attention_heads,
+                        lm.num_key_value_heads, lm.head_dim, lm.rms_norm_eps, lm.rope_theta)
+    return ecfg, lcfg
+
+
+def _record_drift(name, rec):
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "r03_full_depth_drift.json")
+        cur = {}
+        if os.path.exists(path):
+            with open(path) as fh:
+                cur = json.load(fh)
+        cur[name] = rec
+        with open(path, "w") as fh:
+            json.dump(cur, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[full-depth drift] {name}: {json.dumps(rec)}")
+
+
+# ============================================================================ (a) full depth, true vocabulary, one clip
+@pytest.mark.parametrize("kind", ["mlp", "moe", "lora"])
+def test_full_depth_one_clip_vs_oracle(kind):
+    """ASRModel.forward + backward (tiny_audio/asr_modeling.py:481-533; TF:models/qwen3/modeling_qwen3.py:448-508;
+    TF:loss/loss_utils.py:33-71) at the benchmarked depth and vocabulary, log-mel included, vs oracle/model.py."""
+    torch.manual_seed(0)
+    cfg = ASRConfig(projector_type="moe" if kind == "moe" else "mlp", audio_token_dropout=0.0, router_jitter_noise=0.0,
+                    use_lora=kind == "lora", freeze_projector=kind == "lora")
+    m = ASRModel(cfg, device=DEV, init="random", seed=0)
+    m.train()
+    train = {k: p for k, p in m.named_parameters() if p.requires_grad}
+    if kind == "lora":                                  # B = 0 at initialisation would make the adapters invisible
+        with torch.no_grad():
+            gen = torch.Generator(device=DEV); gen.manual_seed(5)
+            for k, p in train.items():
+                if "lb_" in k:
+                    p.copy_(torch.randn(p.shape, device=DEV, generator=gen) * 0.02)
+    V, L = cfg.text_config.vocab_size, 192
+    assert V == 151670 and cfg.audio_config.num_hidden_layers == 32 and cfg.text_config.num_hidden_layers == 28
+    wave = OW.synthetic_wave(0)
+    fe = LogMelFeatureExtractor(128, DEV)
+    f = fe([wave], sampling_rate=16000)
+    ids, att, lab, counts = OW.synthetic_tokens(1, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    out = m(input_ids=torch.from_numpy(ids), input_features=f["input_features"], attention_mask=torch.from_numpy(att),
+            labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), return_logits=False)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    # ---- the oracle on the same weights (the frozen models' bf16 images widened to fp32; fp32 arithmetic throughout)
+    ecfg, lcfg = _oracle_cfgs(cfg)
+    W = dict(encoder=m.audio_tower.export_state_dict_hf(), lm=m.language_model.export_state_dict_hf(),
+             projector={k: npy(v) for k, v in m.projector.state_dict().items()})
+    ocfg = dict(enc=ecfg, lm=lcfg, projector_type="moe" if kind == "moe" else "mlp", k=4, audio_token_id=cfg.audio_token_id,
+                router_aux_loss_coef=getattr(cfg, "router_aux_loss_coef", 0.01))
+    if kind == "lora":
+        W["lora"] = {k: npy(v) for k, v in m.language_model.export_lora_state_dict(prefix="model.", suffix="").items()}
+        ocfg["lora_scale"] = 4.0                        # alpha / r = 32 / 8 (tiny_audio/asr_config.py:71-76)
+    wav, lens = OF.pad_batch([wave])
+    feats, _ = OF.log_mel(wav, lens)
+    batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
+    ref = OM.asr_forward(batch, W, ocfg, training=True)
+    grads, _ = OM.asr_backward(ref, W, ocfg)
+    # per-token NLL of the oracle: position p predicts token p + 1 (TF:loss/loss_utils.py:59-63)
+    lg = ref["logits"][0].astype(np.float64)
+    tgt = lab[0, 1:]
+    pos = np.nonzero(tgt != -100)[0]
+    z = lg[pos]
+    ref_nll = (np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1)) + z.max(-1) - z[np.arange(len(pos)), tgt[pos]])
+    got_nll = npy(out.nll).astype(np.float64)
+    assert out.n_label_tokens == ref["n_label_tokens"] == len(pos) == 36
+    d = got_nll - ref_nll
+    loss, rl = float(out.loss), float(ref["loss"])
+    rec = {"loss_hip": loss, "loss_oracle": rl, "loss_rel": abs(loss - rl) / rl, "nll_maxabs": float(np.abs(d).max()),
+           "nll_rms": float(np.sqrt((d ** 2).mean())), "feat_maxabs": float(np.abs(npy(f["input_features"]) - feats).max())}
+    if kind == "moe":
+        rec["aux_hip"], rec["aux_oracle"] = float(out.aux_loss), float(ref["aux_loss"])
+    cos = {}
+    if kind == "lora":
+        lm = m.language_model
+        for p_ in lm.lora_parameters():
+            p_.data.copy_(p_.grad)
+        got_g = lm.export_lora_state_dict(prefix="model.", suffix="")
+        for k, v in got_g.items():
+            cos[k] = cosine(npy(v), grads["lora." + k])
+        assert all(p.grad is None for p in m.projector.parameters())
+    else:
+        for k, p in m.projector.named_parameters():
+            cos[k] = cosine(npy(p.grad), grads[k])
+    worst = min(cos, key=cos.get)
+    rec.update(grad_cos_min=cos[worst], grad_cos_min_name=worst, grad_cos_mean=float(np.mean(list(cos.values()))), n_grad_tensors=len(cos))
+    _record_drift(kind, rec)
+    assert rec["feat_maxabs"] < 5e-4
+    assert rec["loss_rel"] < LOSS_REL, rec
+    assert rec["nll_maxabs"] < NLL_MAXABS and rec["nll_rms"] < NLL_RMS, rec
+    if kind == "moe":
+        assert abs(rec["aux_hip"] - rec["aux_oracle"]) < 2e-2 * abs(rec["aux_oracle"]) + 1e-6, rec
+    assert rec["grad_cos_min"] > GRAD_COS, rec
+
+
+# ============================================================================ (b) the bench batch vs the same clips at B = 4
+def test_b32_step_equals_eight_b4_steps():
+    """B = 32 runs other GEMM tile variants (252-tile persistent rounds, 192x128 one-tile-per-CU) and other attention grids
+    than B = 4: per-token NLLs and projector gradients must agree (same kernels' arithmetic, different tilings)."""
+    torch.manual_seed(0)
+    cfg = ASRConfig(audio_token_dropout=0.0)
+    m = ASRModel(cfg, device=DEV, init="random", seed=0)
+    m.train()
+    B, L, V = 32, 192, cfg.text_config.vocab_size
+    g = torch.Generator(device=DEV); g.manual_seed(1234)
+    wav = 0.1 * torch.randn(B, 160000, device=DEV, generator=g)
+    fe = LogMelFeatureExtractor(128, DEV)
+    feats, _ = fe.extract(wav, torch.full((B,), 160000, device=DEV, dtype=torch.int64))
+    ids, att, lab, counts = OW.synthetic_tokens(B, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    T = lambda x, s=slice(None): torch.from_numpy(x[s])
+    n_items = 36 * B
+    out = m(input_ids=T(ids), input_features=feats, attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts),
+            return_logits=False, num_items_in_batch=n_items)
+    out.loss.backward()
+    nll32 = out.nll.clone()
+    g32 = {k: p.grad.clone() for k, p in m.projector.named_parameters()}
+    loss32 = float(out.loss)
+    m.zero_grad()
+    nll4, loss4 = [], 0.0
+    for c in range(B // 4):
+        s = slice(4 * c, 4 * c + 4)
+        o = m(input_ids=T(ids, s), input_features=feats[s], attention_mask=T(att, s), labels=T(lab, s),
+              audio_token_counts=T(counts, s), return_logits=False, num_items_in_batch=n_items)
+        o.loss.backward()                                # accumulates into .grad
+        nll4.append(o.nll.clone()); loss4 += float(o.loss)
+    nll4 = torch.cat(nll4)
+    assert nll32.shape == nll4.shape == (n_items,)
+    dn = (nll32 - nll4).abs()
+    assert float(dn.max()) < 2e-2 and float(dn.mean()) < 2e-3, (float(dn.max()), float(dn.mean()))
+    assert abs(loss32 - loss4) < 2e-4 * loss4
+    for k, p in m.projector.named_parameters():
+        assert cosine(npy(p.grad), npy(g32[k])) > 0.9995, k
+        assert abs(float(p.grad.norm() / g32[k].norm()) - 1.0) < 5e-3, k
+
+
+# ============================================================================ (c) the step's own GEMM shapes, automatic tile choice
+def rnd(*shape, seed=0, scale=1.0, dtype=F32):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _pick_splits(M, N, K):
+    """csrc/host_util.h pick_splits (what the composites pass to their split-K launches)."""
+    tiles, s = -(-M // 128) * -(-N // 128), 1
+    while tiles * s < 512 and K // 64 // (s * 2) >= 8 and s < 64:
+        s *= 2
+    return s
+
+
+# name, M, N, K, epilogue  -- B = 32: encoder M = 32 * 500, LM M = 32 * 192, projector M = 32 * 125, 1152 labelled rows
+ENC_M, LM_M, PJ_M, N_LAB, VP = 16000, 6144, 4000, 1152, 151680
+STEP_GEMMS = [
+    ("enc.q|k rope", ENC_M, 2560, 1280, "rope"),
+    ("enc.V^T", 1280, ENC_M, 1280, "plain_bf16"),
+    ("enc.o_proj", ENC_M, 1280, 1280, "bias_res_bf16_inplace"),
+    ("enc.fc1", ENC_M, 5120, 1280, "bias_gelu_bf16"),
+    ("enc.fc2", ENC_M, 1280, 5120, "bias_res_bf16_inplace"),
+    ("proj.linear_2", PJ_M, 1024, 1024, "plain_f32"),
+    ("proj.dA1", PJ_M, 1024, 1024, "plain_f32"),
+    ("proj.dW2", 1024, 1024, 4032, "splitk"),
+    ("proj.dW1", 1024, 5120, 4032, "splitk"),
+    ("lm.q|k|v", LM_M, 4096, 1024, "plain_bf16"),
+    ("lm.o_proj", LM_M, 1024, 2048, "res_bf16"),
+    ("lm.gate|up", LM_M, 6144, 1024, "plain_bf16"),
+    ("lm.down", LM_M, 1024, 3072, "res_bf16"),
+    ("lm.head (labelled rows)", N_LAB, VP, 1024, "plain_bf16"),
+    ("lm.d(hidden) over the vocabulary", N_LAB, 1024, VP, "splitk"),
+    ("lm.d(act)", LM_M, 3072, 1024, "plain_bf16"),
+    ("lm.d(xn) over gate|up", LM_M, 1024, 6144, "plain_bf16"),
+    ("lm.d(attn-out)", LM_M, 2048, 1024, "plain_bf16"),
+    ("lm.d(xn) over q|k|v", LM_M, 1024, 4096, "plain_bf16"),
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,epi", STEP_GEMMS, ids=[g[0] for g in STEP_GEMMS])
+def test_gemm_step_shapes(name, M, N, K, epi):
+    """csrc/api.hip's launches at B = 32 (profiles/r02_e_kernel_steps.md), no TA355_GEMM_VARIANT: pick_variant decides."""
+    assert "TA355_GEMM_VARIANT" not in os.environ
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    ref = A.float() @ W.float().T
+    if epi == "plain_bf16":
+        assert relerr(ops.gemm_nt(A, W, out_dtype=BF16), ref) < 1.5e-2
+    elif epi == "plain_f32":
+        assert relerr(ops.gemm_nt(A, W, out_dtype=F32), ref) < 2e-3
+    elif epi == "splitk":
+        assert relerr(ops.gemm_nt(A, W, out_dtype=F32, splits=_pick_splits(M, N, K)), ref) < 2e-3
+    elif epi == "bias_gelu_bf16":
+        bias = rnd(N, seed=3)
+        assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=BF16), torch.nn.functional.gelu(ref + bias)) < 1.5e-2
+    elif epi in ("bias_res_bf16_inplace", "res_bf16"):
+        bias = rnd(N, seed=3) if epi.startswith("bias") else None
+        xr = rnd(M, N, seed=4, dtype=BF16)
+        want = ref + xr.float() + (bias if bias is not None else 0.0)
+        if epi == "bias_res_bf16_inplace":               # the encoder: xr += A W^T + b on the bf16 stream
+            x = xr.clone()
+            ops.gemm_nt(A, W, bias=bias, out=x, residual_bf16=x)
+        else:                                            # the LM: x1 = x_in + A W^T (separate buffers)
+            x = ops.gemm_nt(A, W, out_dtype=BF16, residual_bf16=xr)
+        assert relerr(x, want) < 1.5e-2
+    elif epi == "rope":
+        from tests.test_gpu_kernels import il_perm, rope_tables, rot_half
+        S, nh = 500, N // 128
+        bias = 0.1 * rnd(N, seed=3)
+        cos, sin = rope_tables(1500, 32, 10000.0)
+        tab = torch.stack([cos, sin], -1).contiguous()
+        rows = (torch.arange(2 * nh)[:, None] * 64 + il_perm()[None, :]).reshape(-1).to(DEV)
+        out = ops.gemm_nt(A, W[rows].contiguous(), bias=bias[rows].contiguous(), act=2, rope=(tab, S))
+        y = (ref + bias).reshape(M // S, S, 2 * nh, 64)
+        c = torch.cat([cos[:S], cos[:S]], -1)[None, :, None]; s = torch.cat([sin[:S], sin[:S]], -1)[None, :, None]
+        want = torch.cat([y[..., :32] * c + rot_half(y[..., :32]) * s, y[..., 32:]], -1)
+        assert relerr(out, want[..., il_perm().to(DEV)].reshape(M, N)) < 8e-3
+    else:
+        raise AssertionError(epi)
+
+
+def test_gemm_step_shapes_conv_and_frame_stack():
+    """The three row-mapped launches of the B = 32 step: conv1 (overlapping rows of the padded mel buffer, GELU, mapped output),
+    conv2 (stride 2), and the projector's frame stack (k = 4 encoder rows per projector row, tail dropped)."""
+    B, T, NM, H = 32, 1000, 128, 1280
+    x0 = torch.zeros(B, T + 2, NM, device=DEV, dtype=BF16); x0[:, 1:T + 1] = rnd(B, T, NM, seed=1, dtype=BF16)
+    w1, b1 = rnd(H, 3 * NM, seed=2, scale=1 / math.sqrt(3 * NM), dtype=BF16), rnd(H, seed=3)
+    x1 = torch.zeros(B, T + 2, H, device=DEV, dtype=BF16)
+    ops.gemm_nt(x0, w1, M=B * T, N=H, K=3 * NM, bias=b1, act=1, out=x1, a_map=(NM, T, (T + 2) * NM), c_map=(H, T, (T + 2) * H, H))
+    win = torch.cat([x0[:, 0:T], x0[:, 1:T + 1], x0[:, 2:T + 2]], -1).float().reshape(B * T, 3 * NM)
+    ref1 = torch.nn.functional.gelu(win @ w1.float().T + b1).reshape(B, T, H)
+    assert relerr(x1[:, 1:T + 1], ref1) < 1.5e-2
+    assert float(x1[:, 0].float().abs().max()) == 0.0 and float(x1[:, T + 1].float().abs().max()) == 0.0
+    S = T // 2
+    w2, b2 = rnd(H, 3 * H, seed=4, scale=1 / math.sqrt(3 * H), dtype=BF16), rnd(H, seed=5)
+    xr = ops.gemm_nt(x1, w2, M=B * S, N=H, K=3 * H, bias=b2, act=1, out_dtype=BF16, a_map=(2 * H, S, (T + 2) * H))
+    win2 = torch.cat([x1[:, 0:T:2], x1[:, 1:T + 1:2], x1[:, 2:T + 2:2]], -1).float().reshape(B * S, 3 * H)
+    assert relerr(xr, torch.nn.functional.gelu(win2 @ w2.float().T + b2)) < 1.5e-2
+    # frame stack: [B, 500, 1280] -> rows of 4 consecutive frames (projectors.py:79-87)
+    k, E, Hd, N = 4, H, 1024, S // 4
+    xe = rnd(B, S, E, seed=6, dtype=BF16)
+    wp = rnd(Hd, k * E, seed=7, scale=1 / math.sqrt(k * E), dtype=BF16)
+    h1 = ops.gemm_nt(xe, wp, M=B * N, N=Hd, K=k * E, out_dtype=F32, a_map=(k * E, N, S * E))
+    assert relerr(h1, xe[:, :N * k].reshape(B * N, k * E).float() @ wp.float().T) < 2e-3
