@@ -5,8 +5,11 @@
 
 N > 1: one rank per GPU over RCCL.  The driver launches the ranks itself (python -m torch.distributed.run ... bench.py
 --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment); a plain `python bench.py --gpus N`
-re-launches itself the same way.  The line then carries `n_gpus` = N, `rccl_ranks` (counted by an actual all-reduce)
-and `allreduce.ms_exposed_per_step`.
+re-launches itself the same way.  The line then carries `n_gpus` = N, `rccl_ranks` (counted by an actual all-reduce),
+`allreduce` (bytes, exposed ms per step in the overlapped mode AND -- a second short leg of the same invocation -- in the
+synchronous mode) and `replicas` (weight checksum / optimizer step count min == max over the ranks, per-rank ms_per_step,
+RCCL version, transports named in RCCL's own NCCL_DEBUG log): the run validates itself.  An exception on ANY rank prints one
+JSON line with an "error" field and the process exits non-zero.
 
 One "step" = one full optimizer step of BASELINE.json configs[1]: B synthetic 10 s / 16 kHz clips per GPU ->
 GPU log-mel -> frozen GLM-ASR encoder (32 layers) -> MLP projector (H=D=1024) -> frozen Qwen3-0.6B (28 layers,
@@ -60,22 +63,97 @@ def parse():
     ap.add_argument("--no-logits-full", action="store_true", help="skip the two extra timed legs: materialised outputs.logits, and inputs fed from pinned host memory")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: all-reduce synchronously on the compute stream")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check WITHOUT a GPU: tiny model on the CPU, every kernel launch a marshalling-only stub, gloo instead "
+                         "of RCCL.  Exercises the N > 1 control flow of this script (tests/test_host_logic.py); its numbers mean nothing")
     return ap.parse_args()
 
 
-def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=3072, full_ft=False):
-    """BASELINE.md section 3 (2*MAC, dense).  lm_head is counted at the positions actually computed."""
+def algorithmic_gflop_per_clip(L, V, n_label, full_logits, H=1024, D=1024, F=3072, full_ft=False, projector="mlp", lora=False,
+                               lora_rank=8, n_audio=125):
+    """BASELINE.md section 3 / SURVEY.md 8(d) (2*MAC, dense).  lm_head is counted at the positions actually computed.
+    MoE (configs[3]): every token runs the shared expert + 2 routed experts = 3x the adapter (5120 -> H -> D), forward and
+    backward (dW1, dW2, d(act), and d(xn) for the RMSNorm / router gradients).  LoRA (configs[4]): 2*L*r*(in+out) per adapted
+    linear forward and twice that backward, 7 linears x 28 layers; the projector is frozen there (no weight gradients).
+    QFormer / MOSA projectors are counted as the MLP (their own flops are not modelled: understated, conservative)."""
     conv = 0.983 + 4.915
     enc = 32 * (2 * 500 * 4 * 1280 ** 2 + 4 * 500 ** 2 * 1280 + 4 * 500 * 1280 * 5120) / 1e9
-    proj_f = 2 * 125 * (5120 * H + H * D) / 1e9
-    proj_b = 2 * 125 * (2 * 5120 * H + 2 * H * D) / 1e9 - 2 * 125 * 5120 * H / 1e9        # dW1, dW2, dA1 (no dX)
+    N = n_audio
+    if projector == "moe":
+        adapter = 2 * N * (5120 * H + H * D) / 1e9
+        proj_f = 3 * adapter + 2 * N * 5120 * 4 / 1e9                                    # + the fp32 router
+        proj_b = 3 * (2 * adapter + 2 * N * 5120 * H / 1e9) + 2 * 2 * N * 5120 * 4 / 1e9  # dW1, dW2, d(act), d(xn); router dW + dX
+    else:
+        proj_f = 2 * N * (5120 * H + H * D) / 1e9
+        proj_b = 2 * N * (2 * 5120 * H + 2 * H * D) / 1e9 - 2 * N * 5120 * H / 1e9        # dW1, dW2, dA1 (no dX)
     lm_body = 28 * (2 * L * (D * 2048 + 2 * D * 1024 + 2048 * D + 3 * D * F) + 2 * L * L * 2048) / 1e9   # 16 q / 8 kv heads x 128
     head_rows = (L if full_logits else 0) + n_label
     head = 2 * head_rows * D * V / 1e9 + 2 * n_label * D * V / 1e9                        # fwd (+ labelled dH backward)
     lm_w = 0.0
     if full_ft:     # weight gradients: one more pass over every linear (no attention term) + the tied head's dE at the labelled rows
         lm_w = 28 * (2 * L * (D * 2048 + 2 * D * 1024 + 2048 * D + 3 * D * F)) / 1e9 + 2 * n_label * D * V / 1e9
-    return conv + enc + proj_f + proj_b + 2 * lm_body + head + lm_w
+    lora_gf = 0.0
+    if lora:
+        io = (D + 2048) + 2 * (D + 1024) + (2048 + D) + 2 * (D + F) + (F + D)             # q, k, v, o, gate, up, down: in + out
+        lora_gf = 3 * 28 * 2 * L * lora_rank * io / 1e9                                   # forward + 2x backward (dX and dA / dB)
+        proj_b = 0.0                                                                      # freeze_projector
+    return conv + enc + proj_f + proj_b + 2 * lm_body + head + lm_w + lora_gf
+
+
+def replica_report(flat_p, global_step, ms_per_step, group=None):
+    """Are the data-parallel replicas still identical after the timed steps?  One MAX all-reduce of
+    [s, -s, q, -q, step, -step, ms, -ms] (s / q = float64 sum / sum of squares of the flat trainable-parameter buffer) gives
+    max and min of each over the ranks.  Pure torch (RCCL on GPUs, gloo in the CPU tests); a single process reports itself."""
+    p = flat_p.detach().double()
+    v = torch.stack([p.sum(), p.square().sum(), torch.tensor(float(global_step), dtype=torch.float64, device=p.device),
+                     torch.tensor(float(ms_per_step), dtype=torch.float64, device=p.device)])
+    t = torch.stack([v, -v], 1).reshape(-1).contiguous()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    t = t.cpu().tolist()
+    mx, mn = t[0::2], [-x for x in t[1::2]]
+    return {"replicas_identical": bool(mx[0] == mn[0] and mx[1] == mn[1] and mx[2] == mn[2]),
+            "weight_checksum": {"sum_min": mn[0], "sum_max": mx[0], "sumsq_min": mn[1], "sumsq_max": mx[1]},
+            "global_step": {"min": int(mn[2]), "max": int(mx[2])},
+            "ms_per_step_by_rank": {"min": round(mn[3], 3), "max": round(mx[3], 3)}}
+
+
+def parse_rccl_log(text):
+    """Transports RCCL reports in its NCCL_DEBUG=INFO log: how many channel connections go `via P2P/...` (xGMI / PCIe peer
+    access), `via SHM` (host memory) or `via NET` (sockets / IB), whether the topology dump names XGMI links, and the library
+    version line.  Counts, not a verdict: the log format is RCCL's own."""
+    import re
+    out = {"via_p2p": len(re.findall(r"via P2P", text)), "via_shm": len(re.findall(r"via SHM", text)),
+           "via_net": len(re.findall(r"via NET", text)), "xgmi_mentions": len(re.findall(r"(?i)xgmi", text)),
+           "channels": None, "version_line": None}
+    m = re.search(r"(\d+) coll channels", text)
+    if m:
+        out["channels"] = int(m.group(1))
+    m = re.search(r"(?m)^.*(?:RCCL|NCCL) version[^\n]*$", text)
+    if m:
+        out["version_line"] = m.group(0).strip()[-120:]
+    if out["via_p2p"] and not out["via_shm"] and not out["via_net"]:
+        out["transport"] = "p2p (xGMI)" if out["xgmi_mentions"] else "p2p"
+    elif out["via_p2p"] or out["via_shm"] or out["via_net"]:
+        out["transport"] = "+".join(k[4:] for k in ("via_p2p", "via_shm", "via_net") if out[k])
+    else:
+        out["transport"] = "unknown (no channel lines in the log)"
+    return out
+
+
+def guarded(body, rank=0, world=1, out=sys.stdout):
+    """Run ``body()``; an exception on this rank becomes ONE parseable JSON line with an "error" field (the launcher forwards
+    every rank's stdout) and exit code 1 -- torch.distributed.run then tears the other ranks down."""
+    try:
+        return body()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": None, "unit": "audio-s/s", "n_gpus": world,
+               "error": f"{type(e).__name__}: {e}", "rank": rank, "traceback": traceback.format_exc()[-1500:]}
+        print(json.dumps(rec), file=out, flush=True)
+        raise SystemExit(1)
 
 
 def relaunch_if_needed(a):
@@ -85,7 +163,7 @@ def relaunch_if_needed(a):
         return
     import socket
     import subprocess
-    n = torch.cuda.device_count()
+    n = a.gpus if getattr(a, "dry_run", False) else torch.cuda.device_count()
     if n < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} GPU(s) visible on this node")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -99,17 +177,41 @@ def main():
     relaunch_if_needed(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    guarded(lambda: run(a), rank, world)
+
+
+def run(a):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the ta355 hot path has no CPU fallback)")
+    dry = bool(a.dry_run)
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the ta355 hot path has no CPU fallback; --dry-run checks the plumbing only)")
     if world != max(a.gpus, 1) and rank == 0:
         print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    rccl_ranks = 1
-    if world > 1:
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    rccl_ranks, rccl_log = 1, None
+    if world > 1 and dry:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)            # RCCL over xGMI
+        dist.init_process_group("gloo")
+        probe = torch.ones(1)
+        dist.all_reduce(probe)
+        rccl_ranks = int(probe.item())
+    elif world > 1:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the host driver only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's own account of what it connected (parsed into the line: replicas.rccl); a user's NCCL_DEBUG settings win
+        if "NCCL_DEBUG" not in os.environ:
+            rccl_log = f"/tmp/ta355_rccl_{os.getpid()}_r{rank}.log"
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))     # RCCL over xGMI
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                                    # an actual collective: the number of ranks RCCL connected
         rccl_ranks = int(probe.item())
@@ -125,8 +227,17 @@ def main():
     text = dict(hidden_size=2048, intermediate_size=6144) if a.lm == "1.7b" else None
     if a.full_ft:
         a.proj_hidden = 2048 if a.proj_hidden == 1024 else a.proj_hidden
-    cfg = ASRConfig(text_config=text, freeze_language_model=not a.full_ft, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
-                    use_lora=a.lora, freeze_projector=a.lora)
+    audio, extra = None, {}
+    n_samples = 160000
+    if dry:                                                       # a toy model: only the control flow is exercised
+        _lib.DRY_RUN = True
+        audio = dict(hidden=256, ffn=512, layers=1, heads=4, n_mels=128, head_dim=64, rope_theta=10000.0, partial_rotary=0.5, ln_eps=1e-5)
+        text = dict(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2, head_dim=128, rms_eps=1e-6, rope_theta=1e6)
+        extra = dict(audio_token_id=999)
+        a.proj_hidden, a.batch, a.seq_len, n_samples = 128, min(a.batch, 2), 64, 16000
+        a.no_cpu_baseline = a.no_roofline = True
+    cfg = ASRConfig(audio_config=audio, text_config=text, freeze_language_model=not a.full_ft, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
+                    use_lora=a.lora, freeze_projector=a.lora, **extra)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
     model.train()
@@ -141,10 +252,14 @@ def main():
     B, L, V = a.batch, a.seq_len, cfg.text_config.vocab_size
     # synthetic inputs of SURVEY.md 8(d), resident in HBM: wav = 0.1 * N(0,1), 160000 samples per clip
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-    wav = 0.1 * torch.randn(B, 160000, device=dev, generator=g)
-    lens = torch.full((B,), 160000, device=dev, dtype=torch.int64)
-    n_audio = int(model.projector.get_output_length(500))         # 125 for the frame-stacking projectors, 102 for the QFormer
-    ids, att, lab, counts, n_lab = token_batch(B, n_audio, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=L)
+    wav = 0.1 * torch.randn(B, n_samples, device=dev, generator=g)
+    if rank == 0:                                                 # clip 0 = SURVEY 8(d)'s numpy clip: the one cpu_baseline's oracle runs
+        from tiny_audio_amd.synthetic import synthetic_wave
+        wav[0].copy_(torch.from_numpy(synthetic_wave(0, n_samples)))
+    lens = torch.full((B,), n_samples, device=dev, dtype=torch.int64)
+    n_audio = int(model.projector.get_output_length(n_samples // 320))   # 125 for the frame-stacking projectors, 102 for the QFormer
+    ids, att, lab, counts, n_lab = token_batch(B, n_audio, V, cfg.audio_token_id, 990 if dry else cfg.pad_token_id, 991 if dry else cfg.eos_token_id, L=L,
+                                               **(dict(n_suffix=4, n_text=10) if dry else {}))
     ids_d, att_d, lab_d = (torch.from_numpy(x).to(dev) for x in (ids, att, lab))
     counts_d = torch.from_numpy(counts).to(dev)
 
@@ -170,7 +285,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def timed(n_steps, n_warm, **kw):
         for _ in range(n_warm):
@@ -196,25 +311,45 @@ def main():
     loss = trainer.last_loss()
     ms = dt / a.steps * 1e3
     value = world * B * 10.0 * a.steps / dt
+    # N > 1: (i) are the replicas still identical (weights, step count), who was slow; (ii) the other all-reduce mode in the same
+    # invocation (a short leg): what the deferred update buys
+    replicas, ar_other = None, None
+    if world > 1:
+        kr = max(2, min(a.steps, 4))
+        sync(); t_local = time.perf_counter()                     # this rank's own clock, no barrier: who is slow
+        for _ in range(kr):
+            step(full_logits=full)
+        trainer.flush(); sync()
+        replicas = replica_report(trainer.flat.flat_p, trainer.global_step, (time.perf_counter() - t_local) / kr * 1e3)
+        trainer.flush()
+        trainer.overlap_allreduce = not overlap
+        k4 = max(2, min(a.steps, 8))
+        dt4 = timed(k4, 1, full_logits=full)
+        ar_other = {"mode": "synchronous" if overlap else "async / deferred update", "steps": k4, "ms_per_step": round(dt4 / k4 * 1e3, 3),
+                    "ms_exposed_per_step": round(trainer.allreduce_exposed_ms() / k4, 4)}
+        trainer.flush()
+        trainer.overlap_allreduce = overlap
 
     # the same step with the reference's materialised outputs.logits [B, L, V] (bf16), on record beside the default line
     logits_full = None
     if not full and not a.no_logits_full:
-        k2 = max(1, min(a.steps, 4))
-        dt2 = timed(k2, 1, full_logits=True)
+        k2 = max(1, a.steps)
+        dt2 = timed(k2, max(2, a.warmup), full_logits=True)       # warm-ups: the 1.9 GB logits buffer is first-touched outside the timed region
         logits_full = {"ms_per_step": round(dt2 / k2 * 1e3, 3), "value": round(world * B * 10.0 * k2 / dt2, 1), "steps": k2,
+                       "warmup": max(2, a.warmup),
                        "note": "additionally writes outputs.logits [B, L, V] bf16 every step, as the reference's forward does"}
         trainer.last_logits = None
 
     # the same step fed from HOST buffers (20.5 MB of f32 waveforms + the token tensors per step over PCIe, pinned, same stream):
     # what the boundary costs when the dataloader hands over host memory.  Never `value`.
     host_inputs = None
-    if not a.no_logits_full:
+    if not a.no_logits_full and not dry:
         host.update(wav=wav.cpu().pin_memory(), ids=ids_d.cpu().pin_memory(), att=att_d.cpu().pin_memory(),
                     lab=lab_d.cpu().pin_memory(), cnt=counts_d.cpu().pin_memory())
-        k3 = max(1, min(a.steps, 4))
-        dt3 = timed(k3, 1, full_logits=full, from_host=True)
+        k3 = max(1, a.steps)
+        dt3 = timed(k3, max(2, a.warmup), full_logits=full, from_host=True)
         host_inputs = {"ms_per_step": round(dt3 / k3 * 1e3, 3), "value": round(world * B * 10.0 * k3 / dt3, 1), "steps": k3,
+                       "warmup": max(2, a.warmup),
                        "note": "inputs copied from pinned host memory inside every step (PCIe-inclusive rate)"}
         host.clear()
 
@@ -257,16 +392,29 @@ def main():
                         "algorithmic_gflop_per_launch": round(tfl.value / max(nl.value, 1) / 1e9, 3),
                         "hbm_kernels": hbm_kernel_rates(B, L, cfg, fe, wav, lens)}
 
-    cpu = None
+    cpu, parity = None, None
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.projector == "mlp" and not a.lora and a.proj_hidden == 1024 and a.lm == "0.6b" and not a.full_ft:
+        # Untimed: clip 0 alone through the GPU path with the frame dropout off (the timed steps drop 10 % of the frames with a
+        # device RNG the oracle cannot replay), against the oracle's loss for the same clip and weights (cpu_baseline computes it).
+        # The trainer has updated the projector since step 0: both sides read the CURRENT weights.
+        with torch.no_grad():
+            f0, _ = fe.extract(wav[:1].contiguous(), lens[:1].contiguous())
+            o0 = model(input_ids=ids_d[:1], input_features=f0, attention_mask=att_d[:1], labels=lab_d[:1],
+                       audio_token_counts=counts_d[:1], return_logits=False, frame_keep=torch.ones(500, device=dev))
+            gpu_loss0 = float(o0.loss)
         cpu = cpu_baseline(model, cfg, L)
+        ol = cpu.pop("_loss")
+        parity = {"clip": "clip 0 of the batch = synthetic_wave(0), dropout off, current weights",
+                  "loss_gpu": round(gpu_loss0, 5), "loss_oracle_fp32": round(ol, 5), "rel_diff": round(abs(gpu_loss0 - ol) / ol, 6),
+                  "stated_tolerance": 1e-2}
 
     if rank == 0:
         D_, F_ = cfg.text_config.hidden_size, cfg.text_config.intermediate_size
-        gf = algorithmic_gflop_per_clip(L, V, n_lab // B, full, H=a.proj_hidden, D=D_, F=F_, full_ft=a.full_ft)
+        gf = algorithmic_gflop_per_clip(L, V, n_lab // B, full, H=a.proj_hidden, D=D_, F=F_, full_ft=a.full_ft,
+                                            projector=a.projector, lora=a.lora, n_audio=n_audio)
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", **({"dry_run": True} if dry else {}),
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes; the same batch every step)",
                "config": {"workload": ("embedded.yaml: full decoder fine-tuning, MLP projector (H=%d) + every LM weight" % a.proj_hidden if a.full_ft else
                                        "configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
@@ -284,11 +432,22 @@ def main():
                "rccl_ranks": rccl_ranks,
                "allreduce": None if world == 1 else {
                    "ms_exposed_per_step": round(ar_ms, 4), "elements": trainer.flat.n + trainer.flat.EXTRA,
+                   "bytes": 4 * (trainer.flat.n + trainer.flat.EXTRA), "other_mode": ar_other,
                    "mode": "async on RCCL's stream, update applied after the next step's frozen-encoder forward" if overlap
                            else "synchronous on the compute stream",
                    "note": "events on the compute stream around the collective (sync) / around the wait for it (async)"},
-               "logits_full": logits_full, "host_inputs": host_inputs, "roofline": roofline, "cpu_baseline": cpu}
+               "replicas": replicas,
+               "logits_full": logits_full, "host_inputs": host_inputs, "roofline": roofline, "cpu_baseline": cpu,
+               "parity": parity}
+        if replicas is not None:
+            replicas["rccl_version"] = "gloo (dry run)" if dry else ".".join(str(x) for x in torch.cuda.nccl.version())
+            if rccl_log and os.path.exists(rccl_log):
+                with open(rccl_log, errors="replace") as fh:
+                    replicas["rccl"] = parse_rccl_log(fh.read())
+            replicas["env"] = {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_P2P_DISABLE", "NCCL_SHM_DISABLE")}
         print(json.dumps(rec), flush=True)
+        if replicas is not None and not replicas["replicas_identical"]:
+            raise RuntimeError(f"data-parallel replicas diverged: {replicas}")
     if world > 1:
         dist.destroy_process_group()
 
@@ -353,7 +512,7 @@ def cpu_baseline(model, cfg, L, reps=3):
             times.append(time.perf_counter() - t0)
         loss = float(out["loss"])
     dt = sorted(times)[len(times) // 2]
-    return {"value": round(10.0 / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(10.0 / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port", "_loss": loss,
             "sample": "1 clip x 1 full-depth training step (log-mel + fwd + bwd, fp32 numpy/OpenBLAS oracle): median of "
                       f"{reps} passes after 1 warm-up, {dt:.1f} s each ({min(times):.1f}-{max(times):.1f}), loss {loss:.4f}"}
 

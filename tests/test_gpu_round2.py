@@ -446,6 +446,12 @@ def test_hf_trainer_drives_the_model_unchanged(tmp_path):
         b = collator([{"audio": {"array": rows[0]["audio"]["array"].copy(), "sampling_rate": 16000}, "text": rows[0]["text"]}])
         o = model(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()})
     assert np.isfinite(float(o.loss))
+    # Trainer.predict (prediction_loss_only = False): prediction_step concatenates every item of the output but "loss" over the
+    # batches -- the output must hold tensors only (None fields / an int among the items raised TypeError there)
+    pred = trainer.predict(DS())
+    logits = pred.predictions[0] if isinstance(pred.predictions, tuple) else pred.predictions
+    assert logits.shape[0] == len(rows) and logits.shape[-1] == 4096 and np.isfinite(pred.metrics["test_loss"])
+    assert pred.label_ids.shape[0] == len(rows)
 
 
 # ============================================================================ grouped GEMM (MoE experts in one launch)

@@ -8,8 +8,10 @@
   (c) every distinct (M, N, K, epilogue) GEMM the B = 32 step launches, under the AUTOMATIC tile choice, vs an fp32 matmul.
 
 Stated tolerances (bf16 MFMA operands and bf16 residual streams -- the reference's model_dtype -- against an fp32 oracle over
-60 layers): loss relative 1e-2; per-token NLL max-abs 0.25 and RMS 0.08 (values ~ ln V = 11.9); projector / adapter
-gradient cosine >= 0.995 per tensor (0.999 at depth 2 in test_gpu_parity.py).
+60 layers): loss relative 1e-3; per-token NLL max-abs 0.15 and RMS 0.05 (values ~ ln V = 11.9); gradient cosine >= 0.999 per
+projector tensor, >= 0.995 per LoRA tensor with the mean over the 392 adapter tensors >= 0.999.
+Measured (profiles/r03_a_full_depth_drift.json): loss relative 2.5e-5 ... 5.7e-5, NLL max-abs 0.049 ... 0.059, RMS 0.019 ... 0.022,
+gradient cosines >= 0.9997 (MLP, MoE), LoRA minimum 0.9987 (one layer-23 lora_A), mean 0.9997.
 """
 import json
 import math
@@ -33,7 +35,7 @@ if torch.cuda.is_available():
 
 DEV = "cuda"
 BF16, F32 = torch.bfloat16, torch.float32
-LOSS_REL, NLL_MAXABS, NLL_RMS, GRAD_COS = 1e-2, 0.25, 0.08, 0.995
+LOSS_REL, NLL_MAXABS, NLL_RMS, GRAD_COS, GRAD_COS_LORA = 1e-3, 0.15, 0.05, 0.999, 0.995
 
 
 def cosine(a, b):
@@ -122,7 +124,7 @@ def test_full_depth_one_clip_vs_oracle(kind):
     got_nll = npy(out.nll).astype(np.float64)
     assert out.n_label_tokens == ref["n_label_tokens"] == len(pos) == 36
     d = got_nll - ref_nll
-    loss, rl = float(out.loss), float(ref["loss"])
+    loss, rl = float(out.loss.detach()), float(ref["loss"])
     rec = {"loss_hip": loss, "loss_oracle": rl, "loss_rel": abs(loss - rl) / rl, "nll_maxabs": float(np.abs(d).max()),
            "nll_rms": float(np.sqrt((d ** 2).mean())), "feat_maxabs": float(np.abs(npy(f["input_features"]) - feats).max())}
     if kind == "moe":
@@ -147,7 +149,7 @@ def test_full_depth_one_clip_vs_oracle(kind):
     assert rec["nll_maxabs"] < NLL_MAXABS and rec["nll_rms"] < NLL_RMS, rec
     if kind == "moe":
         assert abs(rec["aux_hip"] - rec["aux_oracle"]) < 2e-2 * abs(rec["aux_oracle"]) + 1e-6, rec
-    assert rec["grad_cos_min"] > GRAD_COS, rec
+    assert rec["grad_cos_min"] > (GRAD_COS_LORA if kind == "lora" else GRAD_COS) and rec["grad_cos_mean"] > GRAD_COS, rec
 
 
 # ============================================================================ (b) the bench batch vs the same clips at B = 4

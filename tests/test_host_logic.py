@@ -469,7 +469,11 @@ def test_torch_library_operators_are_registered():
         x = torch.empty(2, 500, 1280, dtype=torch.bfloat16)
         y, xb, tape = torch.ops.ta355.mlp_projector(x, torch.empty(1024, 5120), torch.empty(1024), torch.empty(1024, 1024),
                                                     torch.empty(1024), h)
-        assert y.shape == (2, 125, 1024) and y.dtype == torch.float32 and xb.shape == x.shape
+        # a contiguous bf16 input IS the image the kernels read: the operator returns an empty placeholder for it (no copy)
+        assert y.shape == (2, 125, 1024) and y.dtype == torch.float32 and xb.shape == (0,)
+        y32, xb32, _ = torch.ops.ta355.mlp_projector(x.float(), torch.empty(1024, 5120), torch.empty(1024), torch.empty(1024, 1024),
+                                                     torch.empty(1024), h)
+        assert xb32.shape == x.shape and xb32.dtype == torch.bfloat16
     with pytest.raises(Exception):
         torch_ops.module_of(10 ** 9)
 
@@ -512,3 +516,137 @@ def test_hub_snapshot_loaders(tmp_path):
     assert "lm_head.weight" not in sl and sl["model.embed_tokens.weight"].shape == (320, 64)
     with pytest.raises(KeyError):
         hub_weights.encoder_state_dict(str(q))
+    # an UNTIED head (tie_word_embeddings = false, the larger Qwen3 models) must be refused, not loaded as if it were tied
+    wl["lm_head.weight"] = wl["lm_head.weight"] + 0.01
+    u = tmp_path / "untied"; u.mkdir()
+    save_file(wl, str(u / "model.safetensors"))
+    with pytest.raises(ValueError, match="not tied"):
+        hub_weights.lm_state_dict(str(u))
+    wl.pop("lm_head.weight")
+    c = tmp_path / "untied_cfg"; c.mkdir()
+    save_file(wl, str(c / "model.safetensors")); json.dump({"tie_word_embeddings": False}, open(c / "config.json", "w"))
+    with pytest.raises(ValueError, match="not tied"):
+        hub_weights.lm_state_dict(str(c))
+
+
+def test_causal_lm_output_is_model_output_shaped():
+    """No None / Python scalars among the items (HF Trainer.prediction_step concatenates every item but "loss"), index and
+    slice access, extras as attributes."""
+    from tiny_audio_amd.asr_modeling import CausalLMOutput
+    o = CausalLMOutput(loss=torch.tensor(1.5), logits=None, nll=torch.ones(3), n_label_tokens=3, aux_loss=None, loss_ce=torch.tensor(1.5))
+    assert list(o.keys()) == ["loss"] and o.logits is None and o["loss"] is o[0] is o.loss
+    assert o.n_label_tokens == 3 and o.aux_loss is None and float(o.loss_ce) == 1.5 and o.nll.shape == (3,)
+    o2 = CausalLMOutput(loss=torch.tensor(2.0), logits=torch.zeros(2, 4, 8), n_label_tokens=5)
+    assert tuple(v for k, v in o2.items() if k != "loss")[0] is o2.logits and o2[1:] == (o2.logits,) and o2.to_tuple()[1] is o2.logits
+    o3 = CausalLMOutput(logits=torch.zeros(1))
+    assert o3.loss is None and o3[0] is o3.logits
+    with pytest.raises(AttributeError):
+        o3.hidden_states
+
+
+def test_register_module_handles_survive_deepcopy():
+    """A deep copy carries the original's handle attribute; it must get its own handle instead of rebinding the original's."""
+    import copy
+    from tiny_audio_amd import torch_ops
+
+    class M:
+        pass
+    a = M()
+    ha = torch_ops.register_module(a)
+    b = copy.deepcopy(a)
+    assert b.__dict__["_ta355_handle"] == ha
+    hb = torch_ops.register_module(b)
+    assert hb != ha and torch_ops.module_of(ha) is a and torch_ops.module_of(hb) is b
+    assert torch_ops.register_module(a) == ha and torch_ops.register_module(b) == hb          # idempotent
+    del a
+    import gc; gc.collect()
+    with pytest.raises(Exception, match="stale"):
+        torch_ops.module_of(ha)
+
+
+# ----------------------------------------------------------------------------- bench.py: the N > 1 line validates itself (round 3)
+def _replica_worker(rank, world, port, q, diverge):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    torch.manual_seed(0)
+    p = torch.randn(1000)
+    if diverge and rank == 1:
+        p[17] += 1e-6                                   # one replica drifts by one ulp-scale step of one weight
+    q.put((rank, bench.replica_report(p, 7 + (rank if diverge else 0), 40.0 + rank)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("diverge", [False, True])
+def test_bench_replica_report_two_ranks(diverge):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q, diverge)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res[0] == res[1]                             # every rank holds the same report (it came out of one all-reduce)
+    r = res[0]
+    assert r["replicas_identical"] is (not diverge)
+    assert r["ms_per_step_by_rank"] == {"min": 40.0, "max": 41.0}
+    assert r["global_step"] == ({"min": 7, "max": 8} if diverge else {"min": 7, "max": 7})
+    if diverge:
+        assert r["weight_checksum"]["sum_min"] < r["weight_checksum"]["sum_max"]
+
+
+def test_bench_parse_rccl_log_and_error_line(capsys):
+    import io
+    import json
+    import bench
+    log = """host:1:1 [0] NCCL INFO RCCL version 2.22.3+hip6.4 HEAD:abc
+host:1:1 [0] NCCL INFO === System : maxBw 48.0 totalBw 336.0 ===  GPU/0 -XGMI-> GPU/1
+host:1:9 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC
+host:1:9 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC
+host:1:9 [0] NCCL INFO Connected all rings
+host:1:9 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 16 p2p channels
+"""
+    r = bench.parse_rccl_log(log)
+    assert r["via_p2p"] == 2 and r["via_shm"] == 0 and r["channels"] == 16 and r["transport"] == "p2p (xGMI)"
+    assert "RCCL version 2.22.3" in r["version_line"]
+    assert bench.parse_rccl_log("x via SHM/direct\ny via P2P/IPC\n")["transport"] == "p2p+shm"
+    assert bench.parse_rccl_log("")["transport"].startswith("unknown")
+    # any rank's exception -> one JSON line with "error" + a non-zero exit code
+    buf = io.StringIO()
+    with pytest.raises(SystemExit) as e:
+        bench.guarded(lambda: (_ for _ in ()).throw(RuntimeError("boom on this rank")), rank=3, world=8, out=buf)
+    assert e.value.code == 1
+    rec = json.loads(buf.getvalue())
+    assert rec["error"] == "RuntimeError: boom on this rank" and rec["rank"] == 3 and rec["n_gpus"] == 8 and rec["value"] is None
+    assert bench.guarded(lambda: 5) == 5
+
+
+def test_bench_flop_model_counts_moe_and_lora():
+    import bench
+    mlp = bench.algorithmic_gflop_per_clip(192, 151670, 36, False)
+    moe = bench.algorithmic_gflop_per_clip(192, 151670, 36, False, projector="moe")
+    lora = bench.algorithmic_gflop_per_clip(192, 151670, 36, False, lora=True)
+    assert abs(mlp - 1048.5) < 0.1
+    assert 3 * 1.57 - 1.57 < (moe - mlp) < 20                 # 3x the adapter forward (+ its backward) on top of one adapter
+    assert abs((lora - mlp) - (3 * 1.94 - 1.84)) < 0.05        # + 5.8 GF of adapter work, - the frozen projector's dW
+
+
+def test_bench_dry_run_two_ranks_end_to_end():
+    """`bench.py --gpus 2 --dry-run`: the whole N > 1 control flow of the script (launcher re-exec on 127.0.0.1, process group,
+    rank counting, deferred all-reduce, the synchronous A/B leg, replica report, the JSON line) on CPU ranks under gloo with
+    stubbed kernels.  The driver is the first to run this path on real GPUs: it must at least be free of host-side errors."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] is True and rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["config"]["global_batch"] == 4
+    assert rec["replicas"]["replicas_identical"] is True and rec["replicas"]["global_step"]["min"] == rec["replicas"]["global_step"]["max"] > 0
+    ar = rec["allreduce"]
+    assert ar["bytes"] == 4 * ar["elements"] and ar["other_mode"]["mode"] == "synchronous" and ar["other_mode"]["steps"] >= 2
+    assert "error" not in rec

@@ -24,26 +24,36 @@ from .projectors import PROJECTOR_CLASSES
 
 
 class CausalLMOutput(dict):
-    """What ``ASRModel.forward`` returns: attribute access (``out.loss``), key access (``out["loss"]``) and positional access
-    (``out[0]`` = the first field that is not None) like transformers' ``CausalLMOutputWithPast``, which HF
-    ``Trainer.compute_loss`` relies on (TF:trainer.py: ``outputs["loss"] if isinstance(outputs, dict) else outputs[0]``)."""
+    """What ``ASRModel.forward`` returns.  Like transformers' ``ModelOutput`` (``CausalLMOutputWithPast``): the dict holds only
+    the fields that are not None, in order -- ``loss``, ``logits`` -- with attribute, key, index and slice access (HF
+    ``Trainer.compute_loss`` reads ``outputs["loss"]`` / ``outputs[0]``; ``Trainer.prediction_step`` builds
+    ``tuple(v for k, v in outputs.items() if k != "loss")`` and concatenates it over batches, so no None and no Python scalar
+    may sit among the items).  This path's extras are plain attributes, not items: ``nll`` (per label token),
+    ``n_label_tokens`` (int), ``aux_loss``, ``loss_ce`` (the LM's cross-entropy alone: loss = loss_ce + aux_loss)."""
 
-    _order = ("loss", "logits", "nll", "n_label_tokens", "aux_loss", "loss_ce")
+    _items = ("loss", "logits")
+    _extras = ("nll", "n_label_tokens", "aux_loss", "loss_ce")
 
     def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None, loss_ce=None):
-        # loss_ce: the LM's cross-entropy alone (loss = loss_ce + aux_loss)
-        super().__init__(loss=loss, logits=logits, nll=nll, n_label_tokens=n_label_tokens, aux_loss=aux_loss, loss_ce=loss_ce)
+        super().__init__()
+        for k, v in (("loss", loss), ("logits", logits)):
+            if v is not None:
+                dict.__setitem__(self, k, v)
+        for k, v in (("nll", nll), ("n_label_tokens", n_label_tokens), ("aux_loss", aux_loss), ("loss_ce", loss_ce)):
+            object.__setattr__(self, k, v)
 
-    def __getattr__(self, k):
-        try:
-            return dict.__getitem__(self, k)
-        except KeyError:
-            raise AttributeError(k) from None
+    def __getattr__(self, k):                     # reached only when the normal lookup fails: an item, or an absent item
+        if k in CausalLMOutput._items:
+            return dict.get(self, k)
+        raise AttributeError(k)
 
     def __getitem__(self, k):
-        if isinstance(k, int):
-            return [dict.__getitem__(self, n) for n in self._order if dict.__getitem__(self, n) is not None][k]
+        if isinstance(k, (int, slice)):
+            return tuple(self.values())[k]
         return dict.__getitem__(self, k)
+
+    def to_tuple(self):
+        return tuple(self.values())
 
 
 def _is_cjk(ch: str) -> bool:

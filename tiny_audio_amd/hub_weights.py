@@ -65,7 +65,26 @@ def lm_state_dict(path: str) -> Dict[str, torch.Tensor]:
     """Qwen3ForCausalLM state dict (``model.embed_tokens.weight`` ... ; a tied ``lm_head.weight`` is dropped).  The embedding
     keeps the checkpoint's row count; ``Qwen3MI355X.load_state_dict_hf`` cuts it to the tokenizer's vocabulary."""
     sd = read_tensors(path, lambda k: k.startswith("model.") or k == "lm_head.weight")
-    sd.pop("lm_head.weight", None)
+    head = sd.pop("lm_head.weight", None)
     if "model.embed_tokens.weight" not in sd:
         raise KeyError(f"{path}: no model.embed_tokens.weight -- not a causal-LM checkpoint?")
+    # Qwen3MI355X ties the output head to embed_tokens (Qwen3-0.6B / 1.7B: tie_word_embeddings = true).  A checkpoint with an
+    # UNTIED head (the larger Qwen3 models) would load silently and produce wrong logits: refuse it.
+    tied = _config_says_tied(path)
+    if tied is False or (head is not None and (head.shape != sd["model.embed_tokens.weight"].shape
+                                               or not torch.equal(head, sd["model.embed_tokens.weight"]))):
+        raise ValueError(f"{path}: lm_head.weight is not tied to model.embed_tokens.weight (tie_word_embeddings = false); "
+                         "Qwen3MI355X implements the tied head only")
     return sd
+
+
+def _config_says_tied(path: str):
+    """tie_word_embeddings of the snapshot's config.json (top level or text_config); None when there is no config."""
+    import json
+    cfg = os.path.join(path, "config.json")
+    if not os.path.exists(cfg):
+        return None
+    with open(cfg) as fh:
+        c = json.load(fh)
+    v = c.get("tie_word_embeddings", c.get("text_config", {}).get("tie_word_embeddings"))
+    return None if v is None else bool(v)

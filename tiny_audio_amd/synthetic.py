@@ -34,3 +34,9 @@ def token_batch(B, n_audio, vocab, audio_id, pad_id, eos_id, L=None, n_prefix=3,
     # shifted labels: position p predicts token p+1, so every labelled token except one at column 0 is a target
     n_label = int((lab[:, 1:] != -100).sum())
     return ids, att, lab, np.full(B, n_audio, dtype=np.int64), n_label
+
+
+def synthetic_wave(b: int, n: int = 160000) -> np.ndarray:
+    """wav[b] = 0.1 * N(0, 1) from ``RandomState(1234 + b)``, float32 -- the recipe of the reference's
+    tests/test_data_collator.py:68-75 (the oracle keeps its own copy of this two-liner for the tests)."""
+    return (0.1 * np.random.RandomState(1234 + b).standard_normal(n)).astype(np.float32)

@@ -37,9 +37,14 @@ _NEXT = [1]
 
 
 def register_module(mod) -> int:
-    """-> integer handle of a weight-owning module (feature extractor, encoder, projector, LM); idempotent."""
+    """-> integer handle of a weight-owning module (feature extractor, encoder, projector, LM); idempotent.
+    A handle names ONE object: ``copy.deepcopy`` / pickling duplicate the ``_ta355_handle`` attribute with the rest of
+    ``__dict__``, so a module that arrives with a handle somebody else holds (an EMA or reference copy of a model) is given a
+    fresh one instead of rebinding the original's -- a later backward of the original would otherwise resolve its handle to
+    the copy's packed weights."""
     h = mod.__dict__.get("_ta355_handle")
-    if h is None:
+    owner = _MODULES.get(h) if h is not None else None
+    if h is None or (owner is not None and owner is not mod):
         h = _NEXT[0]
         _NEXT[0] += 1
         object.__setattr__(mod, "_ta355_handle", h)
@@ -56,6 +61,21 @@ def module_of(handle: int):
 
 def _empty(dev):
     return torch.empty(0, device=dev)
+
+
+def _is_bf16_image(x) -> bool:
+    return x.dtype == BF16 and x.is_contiguous()
+
+
+def _bf16_image(x):
+    """-> (the bf16 tensor the kernels read, what the operator returns as its "bf16 image of x" output).  An operator's outputs
+    must not alias its inputs: when x already IS a contiguous bf16 tensor (the frozen encoder's output) the output is an empty
+    placeholder and the autograd formula saves the INPUT instead -- no copy of [B, S, E] per step (41 MB at B = 32)."""
+    xd = x.detach()
+    if _is_bf16_image(xd):
+        return xd, torch.empty(0, device=x.device, dtype=BF16)
+    xb = xd.to(BF16).contiguous()
+    return xb, xb
 
 
 # ============================================================================ log-mel
@@ -94,17 +114,14 @@ def mlp_projector(x: Tensor, w1: Tensor, g1: Tensor, w2: Tensor, g2: Tensor, han
     the kernels read the module's packed bf16 images of them."""
     mod = module_of(handle)
     B, S, _ = x.shape
-    xb = x.detach()
-    xb = (xb if xb.dtype == BF16 else xb.to(BF16)).contiguous()
-    if xb.data_ptr() == x.data_ptr():
-        xb = xb.clone()                                   # an operator's outputs must not alias its inputs
+    xb, xb_out = _bf16_image(x)
     wts = mod._packed_weights()
     L_ = _lib.lib()
     N = mod.get_output_length(S)
     tape = torch.empty(L_.ta_mlp_tape_bytes(C.byref(wts), B, S), device=x.device, dtype=torch.uint8)
     y = torch.empty((B, N, mod.llm_dim), device=x.device, dtype=F32)
     _lib.check(L_.ta_mlp_projector_forward(C.byref(wts), ptr(xb), B, S, ptr(y), ptr(tape), stream()), "ta_mlp_projector_forward")
-    return y, xb, tape
+    return y, xb_out, tape
 
 
 @mlp_projector.register_fake
@@ -112,8 +129,8 @@ def _(x, w1, g1, w2, g2, handle):
     mod = module_of(handle)
     B, S, _ = x.shape
     n_tape = _lib.lib().ta_mlp_tape_bytes(C.byref(mod._packed_weights_meta()), B, S)        # host-only size query
-    return (x.new_empty((B, mod.get_output_length(S), mod.llm_dim), dtype=F32), x.new_empty(x.shape, dtype=BF16),
-            x.new_empty((n_tape,), dtype=torch.uint8))
+    return (x.new_empty((B, mod.get_output_length(S), mod.llm_dim), dtype=F32),
+            x.new_empty((0,) if _is_bf16_image(x) else x.shape, dtype=BF16), x.new_empty((n_tape,), dtype=torch.uint8))
 
 
 @torch.library.custom_op("ta355::mlp_projector_backward", mutates_args=())
@@ -144,8 +161,9 @@ def _(dy, xb, tape, handle):
 
 def _mlp_setup(ctx, inputs, output):
     ctx.handle = inputs[5]
+    ctx.module = module_of(ctx.handle)       # the graph keeps its module alive: the handle cannot go stale before the backward
     ctx.set_materialize_grads(False)         # or autograd zero-fills a gradient for the saved-state outputs (xb, tape) every step
-    ctx.save_for_backward(output[1], output[2])
+    ctx.save_for_backward(output[1] if output[1].numel() else inputs[0], output[2])
 
 
 def _mlp_bwd(ctx, dy, _dxb, _dtape):
@@ -167,10 +185,7 @@ def moe_projector(x: Tensor, noise: Optional[Tensor], params: Sequence[Tensor], 
     fc1.weight, fc1.bias, fc2.weight, fc2.bias of routed experts 0..E-1 and of the shared expert (``_param_list``)."""
     mod = module_of(handle)
     B, S, _ = x.shape
-    xb = x.detach()
-    xb = (xb if xb.dtype == BF16 else xb.to(BF16)).contiguous()
-    if xb.data_ptr() == x.data_ptr():
-        xb = xb.clone()
+    xb, xb_out = _bf16_image(x)
     wts = mod._packed_weights()
     L_ = _lib.lib()
     dev = x.device
@@ -180,7 +195,7 @@ def moe_projector(x: Tensor, noise: Optional[Tensor], params: Sequence[Tensor], 
     aux = torch.zeros((), device=dev, dtype=F32)
     _lib.check(L_.ta_moe_projector_forward(C.byref(wts), ptr(xb), B, S, ptr(noise), int(training), ptr(y), ptr(aux), ptr(tape),
                                            stream()), "ta_moe_projector_forward")
-    return y, aux, xb, tape
+    return y, aux, xb_out, tape
 
 
 @moe_projector.register_fake
@@ -189,7 +204,7 @@ def _(x, noise, params, handle, training):
     B, S, _ = x.shape
     n_tape = _lib.lib().ta_moe_tape_bytes(C.byref(mod._packed_weights_meta()), B, S)
     return (x.new_empty((B, mod.get_output_length(S), mod.llm_dim), dtype=F32), x.new_empty((), dtype=F32),
-            x.new_empty(x.shape, dtype=BF16), x.new_empty((n_tape,), dtype=torch.uint8))
+            x.new_empty((0,) if _is_bf16_image(x) else x.shape, dtype=BF16), x.new_empty((n_tape,), dtype=torch.uint8))
 
 
 @torch.library.custom_op("ta355::moe_projector_backward", mutates_args=())
@@ -237,8 +252,9 @@ def _(dy, d_aux, xb, noise, tape, handle, training):
 def _moe_setup(ctx, inputs, output):
     x, noise, params, handle, training = inputs
     ctx.handle, ctx.training, ctx.has_noise, ctx.n_params = handle, training, noise is not None, len(params)
+    ctx.module = module_of(handle)
     ctx.set_materialize_grads(False)
-    ctx.save_for_backward(output[2], output[3], *([noise] if noise is not None else []))
+    ctx.save_for_backward(output[2] if output[2].numel() else x, output[3], *([noise] if noise is not None else []))
 
 
 def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
@@ -316,6 +332,7 @@ def _(tape, ws, handle, input_ids, src_row, kmask, label_rows, n_label_rows, n_a
 def _lm_setup(ctx, inputs, output):
     (audio, trainable, handle, input_ids, src_row, kmask, label_rows, _targets, n_label_rows, _scale, _want) = inputs
     ctx.handle, ctx.n_label_rows, ctx.n_audio, ctx.n_train = handle, n_label_rows, audio.shape[0], len(trainable)
+    ctx.module = module_of(handle)
     ctx.want_d_audio = audio.requires_grad
     # without this autograd materialises ZERO gradients for the unused outputs on every backward -- the tape alone is
     # 8.9 GB at B = 32 (a 1.35 ms fill per step, measured), the workspace 1.2 GB
