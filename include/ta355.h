@@ -24,7 +24,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define TA_ERR_ARG 1
 #define TA_ERR_LAUNCH 2
 
-int ta_version(void); /* ABI version, currently 1 */
+int ta_version(void); /* ABI version, currently 2 (round 3: ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa, ta_attention_enc_fwd,
+                          ta_logmel_f32's scratch contract) */
 
 /* ============================================================================================
  * Composite ops (what a binding would call)
@@ -68,6 +69,14 @@ typedef struct {
    *   w1_ln  = bf16(gamma2 o W1),     c1_1  = row sums of w1_ln,  c2_1 = W1 beta2 + b1                    [F] */
   const void *wqk_ln, *wv_ln, *w1_ln;
   const float *c1_qk, *c2_qk, *c1_v, *c1_1, *c2_1, *bo_fold2;
+  /* Optional (round 3; both NULL = the paths above): the image of the ta_attention_enc_fwd path.
+   *   wqkv_fa bf16 [3H, H]: q rows and k rows in the interleaved order of wqk_il, the q rows MULTIPLIED by
+   *           head_dim^-0.5 * log2(e) (the softmax then runs in base 2 with no per-score multiply), then the v rows as they are;
+   *   bqkv_fa [3H] likewise (q part scaled, k part zero, v part = v_proj.bias).
+   * q | k | v then come out of ONE GEMM (rope on the first 2H columns: ta_gemm_opts.rope_cols) as a token-major [M, 3H]
+   * buffer that the attention kernel reads in place -- no V^T image, no M % 8 restriction. */
+  const void* wqkv_fa;
+  const float* bqkv_fa;
 } ta_enc_layer;
 
 typedef struct {
@@ -285,6 +294,11 @@ int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const int* kmask,
  * Primitive kernels (exported for the parity tests; also what the composites are built from)
  * ============================================================================================ */
 
+/* GLM-ASR encoder self-attention straight from the q|k|v GEMM output (TF:models/glmasr/modeling_glmasr.py:187-217: non-causal,
+ * no mask, head_dim 64).  qkv bf16 [B*S, 3*heads*64] token-major, thirds q | k | v, head h at columns h*64 of each third; the
+ * q values must already carry head_dim^-0.5 * log2(e) (ta_enc_layer.wqkv_fa): out = softmax_base2(q k^T) v, bf16 [B*S, heads*64]. */
+int ta_attention_enc_fwd(const void* qkv, void* out, int B, int heads, int S, hipStream_t st);
+
 /* C = epilogue(A[M,K] x W[N,K]^T).  A/C rows are mapped  row -> (row / rpb) * bs + (row % rpb) * ld
  * (rpb <= 0 means "no batching").  act: 0 none, 1 erf-GELU.  residual: f32, C's row map.
  * splits > 1: split-K through splitk_ws (f32 [splits, M, N]); then no bias/act, plain C layout. */
@@ -326,6 +340,7 @@ typedef struct {
    *   lnf_mode 1 (rows of C are tokens; act 1 or 2):        C = act(acc rstd[m] + (-mean rstd)[m] c1[n] + bias[n])
    *   lnf_mode 2 (columns of C are tokens; act 0, bf16 out): C = acc rstd[n] + (-mean rstd)[n] c1[m] */
   const float* lnf_stats; const float* lnf_c1; int lnf_mode;
+  int rope_cols;   /* act == 2: the rotary embedding applies to columns [0, rope_cols) only (0 = all N columns); % 64 == 0 */
 } ta_gemm_opts;
 int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
                         long ldc, int c_rpb, long c_bs, long c_off, const float* bias, const float* residual, int act,

@@ -34,7 +34,7 @@ def cos_sim(a, b):
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 1280, 1280), (77, 384, 3840), (2048, 1024, 4096), (333, 1284, 128), (515, 5128, 64)])
 @pytest.mark.parametrize("out_bf16", [True, False])
-@pytest.mark.parametrize("variant", [None, "3", "4", "10", "11"])     # automatic choice; persistent ping-pong tiles (v4); one 192x128 tile per CU (v5)
+@pytest.mark.parametrize("variant", [None, "3", "4", "10", "11", "12"])     # automatic choice; persistent ping-pong tiles (v4); one 192x128 tile per CU (v5)
 def test_gemm_plain(M, N, K, out_bf16, variant, monkeypatch):
     if variant is not None:
         monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
@@ -59,7 +59,7 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 64, 256), (1000, 1024, 1024), (6144, 4096, 1024), (4100, 1024, 3072)])
-@pytest.mark.parametrize("variant", [None, "0", "1", "3", "4", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "0", "1", "3", "4", "10", "11", "12"])
 def test_gemm_k_extension(M, N, K, variant, monkeypatch):
     """C = A W^T + A2 W2^T in one launch (one extra 64-wide K tile: the fused LoRA update), every tile variant."""
     if variant is not None:
@@ -76,7 +76,7 @@ def test_gemm_k_extension(M, N, K, variant, monkeypatch):
 
 
 @pytest.mark.parametrize("splits", [2, 5, 16])
-@pytest.mark.parametrize("variant", [None, "4", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "4", "10", "11", "12"])
 def test_gemm_splitk(splits, variant, monkeypatch):
     if variant is not None:
         monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
@@ -88,7 +88,7 @@ def test_gemm_splitk(splits, variant, monkeypatch):
     assert relerr(ops.gemm_nt(A, W, out_dtype=F32, splits=splits, residual=add), ref + add) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [None, "4", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "4", "10", "11", "12"])
 def test_gemm_conv_rowmap(variant, monkeypatch):
     """Conv1d(k=3, pad=1, stride s) as a row-mapped GEMM over a zero-padded time-major buffer."""
     if variant is not None:
@@ -553,7 +553,7 @@ def test_relu_and_mix():
     assert relerr(dob, ot.grad) < 1e-2 and relerr(dlg, lt.grad) < 1e-4
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11", "12"])
 def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     """dX GEMM of down_proj with the SwiGLU backward in its epilogue == GEMM followed by ta_swiglu_bwd."""
     if variant is not None:
@@ -571,7 +571,7 @@ def test_gemm_fused_swiglu_bwd(variant, monkeypatch):
     assert relerr(ops.gemm_nt(dx, W, out_dtype=F32), dact) < 2e-3             # one-shot
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11", "12"])
 def test_gemm_bf16_residual_in_place(variant, monkeypatch):
     """x += A W^T + b with a bf16 residual stream aliased to the output (the encoder's residual GEMMs)."""
     if variant is not None:
@@ -621,7 +621,7 @@ def il_perm():
     return torch.where(p < 32, (p >> 1) + 16 * (p & 1), p)
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11", "12"])
 def test_gemm_rope_epilogue(variant, monkeypatch):
     """act = 2: q|k = rope(A W^T + b) with W's rows in the interleaved pair order == HF rotate-half rope on the plain
     projection, column-permuted (TF:models/glmasr/modeling_glmasr.py:153-168)."""
@@ -661,6 +661,60 @@ def test_attention_fwd_strided_layout(S):
     assert relerr(O, ref) < 1e-6, relerr(O, ref)
     ref32, _ = ref_attention(q.float(), k.float(), vh.float(), False, 0.125, None)
     assert relerr(O, ref32.transpose(1, 2).reshape(M, H)) < 2e-2
+
+
+@pytest.mark.parametrize("B,nh,S", [(3, 5, 500), (2, 3, 77), (1, 2, 64), (2, 2, 129), (1, 20, 1500), (4, 1, 7)])
+def test_attention_enc_fwd(B, nh, S):
+    """ta_attention_enc_fwd (round 3: DMA-staged K / V row tiles, V read transposed, base-2 softmax on pre-scaled scores, running
+    maximum as the MFMA C operand) == softmax(ln 2 * q k^T) v in fp32; ragged last key tile, ragged last query tile, one tile,
+    30 s clips, a sequence shorter than one fragment."""
+    H = nh * 64
+    qkv = torch.cat([rnd(B * S, H, seed=1, scale=1.5), rnd(B * S, H, seed=2), rnd(B * S, H, seed=3)], 1).to(BF16).contiguous()
+    out = ops.attention_enc_fwd(qkv, B, nh, S)
+    q, k, v = (qkv[:, i * H:(i + 1) * H].float().reshape(B, S, nh, 64).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) * math.log(2.0), -1)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, H)
+    assert relerr(out, ref) < 2e-2, relerr(out, ref)
+    assert cos_sim(out, ref) > 0.9999
+
+
+def test_attention_enc_fwd_moving_maximum_and_determinism():
+    """The rescale branch (a later key tile raises a row's maximum: scores grow with the key index, and one spiked key in the
+    LAST tile) and bitwise run-to-run reproducibility."""
+    B, nh, S = 2, 2, 500
+    H = nh * 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B * S, H, generator=g)
+    k = torch.randn(B * S, H, generator=g) * (0.2 + torch.arange(B * S)[:, None] % S / S * 1.5)      # later keys score higher
+    k[S - 3] *= 6.0                                                                                  # a spike in the ragged last tile
+    v = torch.randn(B * S, H, generator=g)
+    qkv = torch.cat([q, k, v], 1).to(DEV).to(BF16).contiguous()
+    out = ops.attention_enc_fwd(qkv, B, nh, S).clone()
+    qf, kf, vf = (qkv[:, i * H:(i + 1) * H].float().reshape(B, S, nh, 64).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * math.log(2.0), -1) @ vf).transpose(1, 2).reshape(B * S, H)
+    assert relerr(out, ref) < 2e-2, relerr(out, ref)
+    for _ in range(5):
+        assert torch.equal(ops.attention_enc_fwd(qkv, B, nh, S), out)
+
+
+def test_gemm_rope_epilogue_column_limit():
+    """ta_gemm_opts.rope_cols: the q | k | v GEMM of the encoder rotates the first 2H columns only."""
+    B, S, nh, K = 2, 100, 5, 256
+    M, H = B * S, nh * 64
+    N = 3 * H
+    A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    bias = 0.1 * rnd(N, seed=3)
+    cos, sin = rope_tables(128, 32, 10000.0)
+    tab = torch.stack([cos, sin], -1).contiguous()
+    rows = (torch.arange(2 * nh)[:, None] * 64 + il_perm()[None, :]).reshape(-1).to(DEV)
+    rows = torch.cat([rows, 2 * H + torch.arange(H, device=DEV)])
+    out = ops.gemm_nt(A, W[rows].contiguous(), bias=bias[rows].contiguous(), act=2, rope=(tab, S, 2 * H))
+    y = (A.float() @ W.float().T + bias)
+    yqk = y[:, :2 * H].reshape(B, S, 2 * nh, 64)
+    c = torch.cat([cos[:S], cos[:S]], -1)[None, :, None]; s = torch.cat([sin[:S], sin[:S]], -1)[None, :, None]
+    rq = torch.cat([yqk[..., :32] * c + rot_half(yqk[..., :32]) * s, yqk[..., 32:]], -1)[..., il_perm().to(DEV)].reshape(M, 2 * H)
+    assert relerr(out[:, :2 * H], rq) < 8e-3
+    assert relerr(out[:, 2 * H:], y[:, 2 * H:]) < 8e-3              # the v columns: bias only, no rotation
 
 
 # ----------------------------------------------------------------------------- trainable-LM helpers
@@ -709,7 +763,7 @@ def test_attention_fwd_is_deterministic():
         assert torch.equal(o2, r2)
 
 
-@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11"])
+@pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "11", "12"])
 def test_gemm_w_blocked(variant, monkeypatch):
     """W handed over as [N/64][K/64][64][64] blocks (8 KB contiguous per K tile of 64 rows) == the row-major call."""
     if variant is not None:

@@ -455,7 +455,7 @@ def test_hf_trainer_drives_the_model_unchanged(tmp_path):
 
 
 # ============================================================================ grouped GEMM (MoE experts in one launch)
-@pytest.mark.parametrize("variant", ["", "0", "3", "4", "5", "7", "10", "11"])
+@pytest.mark.parametrize("variant", ["", "0", "3", "4", "5", "7", "10", "11", "12"])
 def test_grouped_gemm_rows_and_kslices(variant, monkeypatch):
     """ta_gemm_bf16_nt_grouped against fp32 matmuls of the same bf16 operands: ragged segments incl. an EMPTY expert and
     partial tiles, a gather list, bias + GELU; the K-slice form with an empty slice (its gradient must be exactly zero)."""

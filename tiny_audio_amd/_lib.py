@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
-SOURCES = ["gemm.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
+SOURCES = ["gemm.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
            "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "api.hip"]
 
 
@@ -32,7 +32,8 @@ class Ta355Error(RuntimeError):
 class EncLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo",
                                           "w1", "b1", "w2", "b2", "wqk_il", "bqk_il", "bo_fold",
-                                          "wqk_ln", "wv_ln", "w1_ln", "c1_qk", "c2_qk", "c1_v", "c1_1", "c2_1", "bo_fold2")]
+                                          "wqk_ln", "wv_ln", "w1_ln", "c1_qk", "c2_qk", "c1_v", "c1_1", "c2_1", "bo_fold2",
+                                          "wqkv_fa", "bqkv_fa")]
 
 
 class EncoderWeights(C.Structure):
@@ -65,7 +66,7 @@ class LmLayer(C.Structure):
 class GemmOpts(C.Structure):
     _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
                 ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int),
-                ("lnf_stats", C.c_void_p), ("lnf_c1", C.c_void_p), ("lnf_mode", C.c_int)]
+                ("lnf_stats", C.c_void_p), ("lnf_c1", C.c_void_p), ("lnf_mode", C.c_int), ("rope_cols", C.c_int)]
 
 
 class AttnLayout(C.Structure):
@@ -140,13 +141,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made
     # the attention kernels shuttle every score / output fragment through v_accvgpr_read/write around the softmax.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
+    # attention_enc.hip: no NaN can reach its row maxima (scores are finite MFMA sums; masked keys are -1e30, not -inf), and
+    # without this every fmaxf on an MFMA result is preceded by a canonicalising v_max_f32 x, x (12 extra VALU per key tile)
+    extra = {"attention_enc.hip": ["-fno-honor-nans"]}
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
             return obj, None
-        cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
+        cmd = [hipcc_path(), *flags, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -6,7 +6,7 @@
 #include "internal.h"
 #include "../../include/ta355.h"
 
-extern "C" int ta_version(void) { return 1; }
+extern "C" int ta_version(void) { return 2; }
 
 #include <algorithm>
 #include "host_util.h"
@@ -88,6 +88,8 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   // epilogues cost more than the two LayerNorm kernels (19 us each) they replace.
   const char* lz = getenv("TA355_ENC_LN_FOLD");
   const bool lnfold = lz && *lz == '1';
+  const char* az = getenv("TA355_ENC_ATTN_V2");               // 0 = the round-2 attention path (V^T GEMM + attn_fwd_kernel); read per call
+  const bool fa = !(az && *az == '0') && !(fz && *fz == '0') && w->rope_il && !lnfold && (H / nh) == 64;
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_enc_layer& L = w->layers[l];
     const bool fold = fused && lnfold && rb && L.wqk_ln && L.wv_ln && L.w1_ln && L.c1_qk && L.c2_qk && L.c1_v && L.c1_1 &&
@@ -112,7 +114,15 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
       continue;
     }
     RC(ln(L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr));
-    if (fused && L.wqk_il && L.bqk_il && L.bo_fold) {
+    if (fa && L.wqkv_fa && L.bqkv_fa) {
+      // Round 3: q | k | v out of ONE GEMM as a token-major [M, 3H] buffer (rope on the q | k columns, q pre-scaled by
+      // head_dim^-0.5 log2 e through the weight image), read in place by the DMA-staged base-2 attention kernel
+      // (csrc/attention_enc.hip): no V^T GEMM, no transposed image, any M.
+      ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S; o.rope_cols = 2 * H;
+      RC(gemm_opt(e.xn, L.wqkv_fa, e.qkv, M, 3 * H, H, L.bqkv_fa, nullptr, 2, 1, o, st));
+      RC(ta_attention_enc_fwd(e.qkv, e.ao, B, nh, S, st));
+      RC(res_gemm(e.ao, L.wo, H, L.bo));
+    } else if (fused && L.wqk_il && L.bqk_il && L.bo_fold) {
       // q|k = rope(xn Wqk^T + b) straight from the GEMM epilogue (token-major [M, 2H], heads' rotary pairs interleaved),
       // V^T [H, M] = Wv xn^T as a second GEMM (its bias lives in bo_fold); attention reads both in place.
       ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S;

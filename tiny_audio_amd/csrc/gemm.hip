@@ -47,7 +47,7 @@ struct GemmArgs {
   // act == 2: partial rotary embedding in the epilogue (GLM-ASR q|k projection).  Heads are 64 columns; the first 32
   // columns of every head hold the 16 rotation pairs INTERLEAVED (pair i = columns 2i, 2i+1), so both members of a pair
   // sit in one lane; rope_tab [rope_rows][16][2] = (cos, sin) of pair i at position (logical row % rope_rows)
-  const float* rope_tab; int rope_rows;
+  const float* rope_tab; int rope_rows; int rope_cols;   // rope on columns [0, rope_cols)
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
   int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
@@ -77,6 +77,7 @@ struct GemmArgs {
 #define TA355_RATE_256x256_PP 1.40  /* per unit tile area vs the 128x128 kernel, fitted on profiles/r01_f_gemm_variants.txt (lm_qkv 56 vs 62 us, sq8192 1330 vs 1050 TF/s) */
 #define TA355_RATE_96x128 0.93      /* 3x4 instead of 4x4 MFMAs per fragment set; estimate, to be refitted */
 #define TA355_RATE_192x128 1.1      /* v5 (one 192x128 tile per CU), cold operands, profiles/r02_gemm_v5_ab_cold.txt: 1.05-1.15 in one round (lm o / down / dX: 43.5 / 58.5 / 61.7 / 97.2 us vs 49.4 / 68.4 / 74.3 / 120.2 for 96x128), 0.9-1.03 over several rounds; in the step 1.0 / 1.1 / 1.25 are equal for Qwen3-0.6B and 1.1 is 1 ms better than 1.0 for the 1.7B widths (2-round N = 2048 shapes); 0 = never chosen */
+#define TA355_RATE_192x256_PP 1.30  /* round 3: v4 on a 192-row tile (variant 12), see pick_variant */
 #define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
@@ -140,7 +141,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       }
       if (BASE == 2) {
         const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
-        if (pc < 32) {
+        if (pc < 32 && n < p.rope_cols) {
           const float4 t = *(const float4*)(p.rope_tab + ((long)(m % p.rope_rows) * 16 + (pc >> 1)) * 2);   // c0 s0 c1 s1
           const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
           v[0] = a0 * t.x - a1 * t.y; v[1] = a1 * t.x + a0 * t.y;
@@ -665,9 +666,12 @@ __device__ __forceinline__ TileCtx tile_ctx(const GemmArgs& p, int h, int total)
 
 // LIFE (experiments, variant 9): s_memtime stamps of every tile {loop top, first K tile landed, loop end, next tile's DMA issued,
 // stores issued} + HW_ID / XCC_ID behind the C matrix (scripts/gemm_wg_life.py)
-template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool KEXT = false, bool LIFE = false>
+// BM2 = 192 (round 3): the same kernel on a 192-row tile (each wave group owns 96 rows = 6 fragment rows).  M = 6144 (the LM at
+// B = 32) is 32 x 192: N = 2048 gives 256 tiles = ONE per CU and N = 4096 gives 512 = two full rounds, where 256-row tiles leave
+// a quarter of the chip idle (192 of 256 CUs; 1.5 rounds).
+template <int BN2, int ACT, bool OUT_BF16, bool HAS_RES, bool KEXT = false, bool LIFE = false, int BM2 = 256>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
-  constexpr int BM2 = 256;
+  constexpr int MI = BM2 / 32;                      // 16-row fragment rows per wave (two wave groups split the tile's rows)
   constexpr int NT = BN2 / 64;
   constexpr int NA = BM2 / 64, NB = BN2 / 64;
   constexpr int A_BYTES = BM2 * 128, STAGE = (BM2 + BN2) * 128;
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   // wave-uniform LDS byte address of this wave's 1-KB DMA window in stage 0
   const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + wave * 1024);
   const int swz = l15 >> 1;
-  const int a_rd = (wm * 128 + l15) * 128;
+  const int a_rd = (wm * (BM2 / 2) + l15) * 128;
   const int b_rd = A_BYTES + (wn * (BN2 / 4) + l15) * 128;
   const int koff0 = ((0 + g) ^ swz) << 4;
   const int koff1 = ((4 + g) ^ swz) << 4;
@@ -754,9 +758,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   first_dma(cur);
 
   for (;;) {
-    f32x4 acc[8][NT];
+    f32x4 acc[MI][NT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -771,14 +775,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       const bool more = kt + 1 < cur.ke;
       const char* S = smem + cs * STAGE;
       const unsigned nxt = lds_w + (cs ^ 1) * STAGE;
-      bf16x8 af[8], bfr[NT];
+      bf16x8 af[MI], bfr[NT];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ko = kk ? koff1 : koff0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8*)(S + b_rd + j * 2048 + ko);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(S + a_rd + i * 2048 + ko);
         if (kk == 0) {
           if (more) {
             ext_switch(cur, kt + 1);
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
@@ -828,8 +832,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       const bool wide = epilogue_wide_ok(p);
       {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int ml = cur.m0 + e_wm * 128 + i * 16 + e_l15;
+        for (int i = 0; i < MI; ++i) {
+          const int ml = cur.m0 + e_wm * (BM2 / 2) + i * 16 + e_l15;
           if (ml >= cur.Mact) continue;
           const int m = cur.rbase + ml;
           const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
@@ -1492,7 +1496,7 @@ std::vector<ProfRec> g_prof;
 static int pick_variant(int M, int N, int K, int splits) {
   const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
   const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 11) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
+  if (forced >= 0 && forced <= 12) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
@@ -1512,6 +1516,12 @@ static int pick_variant(int M, int N, int K, int splits) {
     static const int mink = [] { const char* v = getenv("TA355_V5_MINK"); return v && *v ? atoi(v) : 2048; }();
     if (r10 > 0.0 && K / splits >= mink && t < best_t) { best_t = t; best = 10; }
   }
+  {                                                  // 12 = 192x256 ping-pong, persistent (v4 with BM2 = 192)
+    static const double r12 = [] { const char* v = getenv("TA355_RATE_192x256"); return v && *v ? atof(v) : TA355_RATE_192x256_PP; }();
+    const long tiles = (long)ta_cdiv(M, 192) * ta_cdiv(N, 256) * splits;
+    const double t = (double)((tiles + 255) / 256) * 192.0 * 256.0 / r12;
+    if (r12 > 0.0 && t < best_t) { best_t = t; best = 12; }
+  }
   // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
   static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
   if (ring && (best == 3 || best == 4)) best += 3;
@@ -1523,15 +1533,16 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   int variant = pick_variant(a.M, a.N, a.K, a.splits);
   const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
   if ((variant == 10 || variant == 11) && (a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 / v6: no gather, plain W only
+  if (variant == 12 && (a.a_idx || a.A2 || a_far)) variant = 3;                                // the 192-row tile exists in the persistent form only
   if (variant == 10 && ACT == 0) {                  // TA355_GEMM_M32=1 (experiment): plain linears on the 32x32x16 form of the same tile (v6)
     const char* e = getenv("TA355_GEMM_M32");
     if (e && *e == '1') variant = 11;
   }
   if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
   if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
-  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11) ? 192 : 256));
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12) ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
-  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6) ? 256 : 128);
+  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
@@ -1576,6 +1587,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96>), dim3(grid), dim3(256), 0, st, a);
   else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
+  else if (variant == 12) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES, false, false, 192>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3 && persist) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
@@ -1684,7 +1696,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = o.lda2;
   a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
   a.res_bf16 = resb != nullptr;
-  a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows;
+  a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows; a.rope_cols = o.rope_cols > 0 ? o.rope_cols : N;
   a.w_blocked = o.w_blocked ? 1 : 0;
   a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
   a.dbg = 0; a.grp_n = 0; a.grp_w_stride = 0;
@@ -1694,7 +1706,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     if (!o.lnf_stats || !o.lnf_c1 || !(row_ok || col_ok) || splits > 1 || seg || a_idx) return TA_ERR_ARG;
   }
   if (a.w_blocked && ((N & 63) || xA2 || krange || a_idx)) return TA_ERR_ARG;
-  if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64))) return TA_ERR_ARG;
+  if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64) || o.rope_cols < 0 || (o.rope_cols % 64))) return TA_ERR_ARG;
   if (resb && splits > 1) return TA_ERR_ARG;
   if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;
   if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
@@ -1750,7 +1762,7 @@ extern "C" int ta_gemm_bf16_nt_grouped(const void* A, const void* W, void* C, in
   a.a_plain = 1; a.c_plain = 1;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = nullptr; a.W2 = nullptr; a.K2 = 0; a.lda2 = 0; a.sw_gu = nullptr; a.sw_dgu = nullptr; a.res_bf16 = 0;
-  a.rope_tab = nullptr; a.rope_rows = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
+  a.rope_tab = nullptr; a.rope_rows = 0; a.rope_cols = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
   a.grp_n = n_groups; a.grp_w_stride = w_stride;
   a.splits = krange ? n_groups : 1;           // K-slice form: z = group, slabs c_stride apart
   a.slab_stride = krange ? c_stride : (long)M * N;

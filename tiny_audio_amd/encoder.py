@@ -64,9 +64,11 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         b["norm_b"] = _t(g("norm.bias"), dev, F32)
         cos, sin = self._rope_tables()
         b["rope_cos"], b["rope_sin"] = _t(cos, dev, F32), _t(sin, dev, F32)
+        self._q_masters = {}
         for i in range(L):
             p = f"layers.{i}."
             a = p + "self_attn."
+            self._q_masters[i] = g(a + "q_proj.weight").detach().to(torch.float32).cpu()      # consumed by _derive_fused_qkv
             b[p + "wqkv"] = _t(torch.cat([g(a + "q_proj.weight"), g(a + "k_proj.weight"), g(a + "v_proj.weight")], 0), dev, BF16)
             b[p + "bqkv"] = _t(torch.cat([g(a + "q_proj.bias"), torch.zeros(H), g(a + "v_proj.bias")], 0), dev, F32)
             b[p + "wo"] = _t(g(a + "o_proj.weight"), dev, BF16)
@@ -122,10 +124,18 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         rows = (torch.arange(nh, device=dev)[:, None] * hd + d_of_p[None, :]).reshape(-1)
         rows = torch.cat([rows, H + rows])
         b["rope_il"] = torch.stack([b["rope_cos"], b["rope_sin"]], dim=-1).contiguous()   # [max_pos, 16, 2]
+        # ta_enc_layer.wqkv_fa: softmax scale and log2(e) folded into the q rows, so that ta_attention_enc_fwd exponentiates
+        # q.k directly in base 2.  From the fp32 masters when load_state_dict_hf kept them (one rounding to bf16, like the
+        # reference's own cast), else from the bf16 image.
+        qs = (hd ** -0.5) * math.log2(math.e)
+        masters = getattr(self, "_q_masters", None) or {}
         for i in range(c.num_hidden_layers):
             q = f"layers.{i}."
             b[q + "wqk_il"] = b[q + "wqkv"][rows].contiguous()
             b[q + "bqk_il"] = b[q + "bqkv"][rows].contiguous()
+            wq32 = masters[i].to(dev) if i in masters else b[q + "wqkv"][:H].float()
+            b[q + "wqkv_fa"] = torch.cat([(wq32[rows[:H]] * qs).to(BF16), b[q + "wqkv"][rows[H:]], b[q + "wqkv"][2 * H:]], 0).contiguous()
+            b[q + "bqkv_fa"] = torch.cat([b[q + "bqkv"][rows[:H]] * qs, torch.zeros(H, device=dev), b[q + "bqkv"][2 * H:]], 0).contiguous()
             b[q + "bo_fold"] = (b[q + "bo"] + b[q + "wo"].float() @ b[q + "bqkv"][2 * H:]).contiguous()
             if os.environ.get("TA355_ENC_LN_FOLD") != "1":      # experiment (measured slower): images only on request
                 continue
@@ -147,6 +157,7 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         L = c.num_hidden_layers
         if c.hidden_size // c.num_attention_heads == 64:
             self._derive_fused_qkv()
+        self._q_masters = None
         arr = (_lib.EncLayer * L)()
         for i in range(L):
             p = f"layers.{i}."

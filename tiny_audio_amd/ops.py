@@ -49,6 +49,7 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
         if rope is not None:
             _req(rope[0], F32)
             opts.rope_tab, opts.rope_rows = ptr(rope[0]), int(rope[1])
+            opts.rope_cols = int(rope[2]) if len(rope) > 2 else 0       # rope on columns [0, rope_cols) only (0 = all)
         if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
             _req(residual_bf16, BF16)
             opts.residual_bf16 = ptr(residual_bf16)
@@ -183,6 +184,16 @@ def attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, causal, scale, kmask=
                                  ptr(delta), ptr(kmask), ptr(dQ), ptr(dK), ptr(dV), B, Hq, Hkv, L, Lp, hd, int(causal),
                                  scale, stream()), "ta_attention_bwd")
     return dQ, dK, dV
+
+
+def attention_enc_fwd(qkv, B, heads, S):
+    """GLM-ASR encoder attention straight from the q|k|v GEMM output: qkv bf16 [B*S, 3*heads*64] (q pre-scaled by
+    head_dim^-0.5 * log2 e) -> bf16 [B*S, heads*64] = softmax_base2(q k^T) v, non-causal, no mask."""
+    _req(qkv, BF16)
+    assert qkv.shape == (B * S, 3 * heads * 64)
+    out = torch.empty((B * S, heads * 64), device=qkv.device, dtype=BF16)
+    check(lib().ta_attention_enc_fwd(ptr(qkv), ptr(out), B, heads, S, stream()), "ta_attention_enc_fwd")
+    return out
 
 
 def attention_fwd_qkv(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, scale, eps=1e-6, kmask=None, pos=None):
