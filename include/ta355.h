@@ -276,6 +276,13 @@ int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out, hipStream
 /* HF greedy bookkeeping for step t = *step_dev (TF:generation/utils.py _sample): finished clips emit pad_id, a clip
  * finishes on any eos id; writes out_seq[b, t], next_ids[b]; advances pos / *slot_dev / kmask for the next decode step
  * (not on t == 0, whose token comes from the prompt pass); *step_dev += 1; *n_unfinished = clips still running. */
+/* The reference's non-default greedy settings (tiny_audio/asr_config.py:84-86,155-160; TF:generation/logits_process.py
+ * RepetitionPenaltyLogitsProcessor + NoRepeatNGramLogitsProcessor) on the step's logits [B, ld] f32 (V valid columns) BEFORE
+ * ta_argmax_f32.  The processors see prompt_ids [B, L] i64 followed by the first *step_dev tokens of out_seq [B, max_new]
+ * (the reference passes input_ids to generate for exactly this: tiny_audio/asr_modeling.py:625-633).  repetition_penalty 1.0 and
+ * no_repeat_ngram_size 0 make it a no-op; L + max_new <= 8192. */
+int ta_logits_process(float* logits, long ld, int V, const long* prompt_ids, int L, const long* out_seq, int max_new,
+                      const int* step_dev, int B, float repetition_penalty, int no_repeat_ngram_size, hipStream_t st);
 int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad_id, int* finished, long* next_ids,
                       long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax, int B,
                       int* n_unfinished, hipStream_t st);

@@ -39,7 +39,30 @@ def prompt_embeds(batch, W, cfg):
     return masked_scatter_rows(emb, is_audio, gather_audio_embeds(y, counts))
 
 
-def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False):
+def apply_logits_processors(scores, seq, repetition_penalty=1.0, no_repeat_ngram_size=0):
+    """TF:generation/logits_process.py on one step's scores [B, V] given the sequences so far ``seq`` [B, n] (the prompt ids
+    followed by the generated tokens: the reference hands input_ids to generate for this, tiny_audio/asr_modeling.py:625-633).
+    RepetitionPenaltyLogitsProcessor.__call__: score = gather(scores, seq); score = where(score < 0, score * p, score / p);
+    scatter back.  NoRepeatNGramLogitsProcessor.__call__ (_calc_banned_ngram_tokens): if n + 1 >= ngram, every token that
+    followed an earlier occurrence of the last ngram-1 tokens is set to -inf."""
+    scores = scores.copy()
+    B, n = seq.shape
+    if repetition_penalty != 1.0:
+        for b in range(B):
+            sc = scores[b, seq[b]]
+            scores[b, seq[b]] = np.where(sc < 0, sc * np.float32(repetition_penalty), sc / np.float32(repetition_penalty))
+    g = int(no_repeat_ngram_size)
+    if g > 0 and n + 1 >= g:
+        for b in range(B):
+            prefix = tuple(seq[b, n - (g - 1):]) if g > 1 else ()
+            for i in range(n - g + 1):
+                if tuple(seq[b, i:i + g - 1]) == prefix:
+                    scores[b, seq[b, i + g - 1]] = -np.inf
+    return scores
+
+
+def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False, repetition_penalty=1.0,
+                    no_repeat_ngram_size=0):
     """-> generated token ids [B, n_new] (prompt stripped), n_new <= max_new_tokens.  The prompt must be unpadded
     (attention_mask all ones), which is what ASRModel.generate builds.  ``return_margins`` also returns the
     top-1 minus top-2 logit gap of every decision (how robust the argmax is to bf16 rounding)."""
@@ -54,6 +77,9 @@ def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, ret
         logits, _ = qwen3.lm_forward(x, np.ones(x.shape[:2], np.int64), W["lm"], cfg["lm"], keep_cache=False,
                                      lora=W.get("lora"), lora_scale=cfg.get("lora_scale", 0.0))
         last = logits[:, -1].astype(np.float32)
+        if repetition_penalty != 1.0 or no_repeat_ngram_size > 0:
+            seq = np.concatenate([np.asarray(batch["input_ids"], np.int64)] + [o[:, None] for o in out], axis=1)
+            last = apply_logits_processors(last, seq, repetition_penalty, no_repeat_ngram_size)
         nxt = last.argmax(-1)
         srt = np.sort(last, axis=-1)
         margins.append(srt[:, -1] - srt[:, -2])

@@ -451,6 +451,31 @@ def gen_generate():
     print("generate:", a_out.tolist(), eos, b_out.tolist())
 
 
+def gen_generate_penalties():
+    """The same reduced model through the reference's ASRModel.generate with its two non-default knobs
+    (tiny_audio/asr_config.py:84-86): repetition_penalty = 1.3 and no_repeat_ngram_size = 2 -- separately and together -- plus a
+    run whose plain greedy output repeats a token (a sharpened lm_head row), so that the processors visibly change the tokens."""
+    from transformers import WhisperFeatureExtractor
+    from tests.golden.recipe import gen_waves, gen_prompt, gen_lm_weights
+    E, D, H = SMALL["enc"]["hidden"], SMALL["lm"]["hidden"], SMALL["proj_hidden"]
+    fe = WhisperFeatureExtractor(feature_size=128); fe.padding = False
+    a = fe(gen_waves(), sampling_rate=16000, padding="longest", return_attention_mask=True, return_tensors="np")
+    feats, amask = a["input_features"].astype(np.float32), a["attention_mask"].astype(np.int64)
+    n_audio = int(((amask.sum(-1)[0] - 1) // 2 + 1 - 4) // 4 + 1)
+    ids = gen_prompt(n_audio)
+    model = build_asr("mlp", OW.init_mlp_projector(E, D, H), lm_weights=gen_lm_weights())
+    model.eval()
+    kw = dict(input_ids=t(ids), input_features=t(feats), audio_attention_mask=t(amask), attention_mask=torch.ones_like(t(ids)))
+    model.generation_config.eos_token_id = [SMALL["eos_id"], SMALL["pad_id"]]
+    model.generation_config.pad_token_id = SMALL["pad_id"]
+    out = {}
+    for name, g in (("plain", {}), ("rep", dict(repetition_penalty=1.3)), ("ngram", dict(no_repeat_ngram_size=2)),
+                    ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2)), ("rep_strong", dict(repetition_penalty=5.0))):
+        out["tokens_" + name] = model.generate(**kw, max_new_tokens=16, **g).numpy()
+    save("generate_penalties_small.npz", input_features=feats, audio_attention_mask=amask, input_ids=ids, n_audio=np.array(n_audio), **out)
+    print("generate penalties:", {k: v.tolist() for k, v in out.items()})
+
+
 # ----------------------------------------------------------------------------- 6c. checkpoint written by the reference (section 8(f) rank 3)
 def gen_ckpt():
     """What ASRModel.save_pretrained stores for the trainable part: state_dict() -> model.safetensors (HF writes it with
@@ -505,7 +530,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "train_moe", "fullft", "generate", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "train_moe", "fullft", "generate", "generate_penalties", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "train_moe": gen_train_moe, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "train_moe": gen_train_moe, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "generate_penalties": gen_generate_penalties, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

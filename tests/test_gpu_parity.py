@@ -489,7 +489,7 @@ def test_mosa_projector_true_width():
 
 
 # ============================================================================ greedy generation (section 8(f) rank 1)
-def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12):
+def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12, **processors):
     """Greedy parity that is robust to bf16 near-ties: feed the HIP path's OWN tokens to the fp32 oracle and require
     every decision to be the oracle's argmax or within `tol` logits of it (bf16 logits carry ~0.03 of rounding);
     pad-after-EOS and the stopping rule are checked exactly."""
@@ -503,6 +503,9 @@ def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.1
         assert unfinished.any(), "generation continued after every clip had finished"
         logits, _ = OQ.lm_forward(x, np.ones(x.shape[:2], np.int64), W["lm"], cfg["lm"], keep_cache=False)
         last = logits[:, -1]
+        if processors:
+            seq = np.concatenate([np.asarray(batch["input_ids"], np.int64), tokens[:, :t]], axis=1)
+            last = OG.apply_logits_processors(last.astype(np.float32), seq, **processors)
         for b in range(B):
             if not unfinished[b]:
                 assert tokens[b, t] == pad_id
@@ -547,6 +550,64 @@ def test_generate_vs_golden_and_oracle(golden):
         m.generate(**kw, num_beams=4)
     with pytest.raises(ValueError):
         m.generate(input_ids=kw["input_ids"], input_features=kw["input_features"])
+
+
+def test_generate_with_repetition_penalty_and_no_repeat_ngram(golden):
+    """ta_logits_process in the decode loop (inside the captured hipGraph from step 2 on): every HIP decision is the fp32
+    oracle's processed argmax (or within the bf16 near-tie tolerance of it) on the HIP path's own prefix; no bigram repeats
+    under no_repeat_ngram_size = 2; and the reference's tokens are reproduced wherever its margins are decisive."""
+    g = golden("generate_penalties_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    wE, wL, wP = OW.init_encoder(S["enc"], 0), R.gen_lm_weights(), OW.init_mlp_projector(E, D, H)
+    m = build_model(S["enc"], S["lm"], H, wE, wL, wP, audio_token_id=S["audio_token_id"], pad_token_id=S["pad_id"],
+                    eos_token_id=S["eos_id"])
+    kw = dict(input_ids=torch.from_numpy(g["input_ids"]), input_features=torch.from_numpy(g["input_features"]),
+              audio_attention_mask=torch.from_numpy(g["audio_attention_mask"]),
+              attention_mask=torch.ones(g["input_ids"].shape, dtype=torch.int64))
+    W = dict(encoder=wE, lm=wL, projector=wP)
+    cfg = dict(enc=S["enc"], lm=S["lm"], projector_type="mlp", k=S["k"], audio_token_id=S["audio_token_id"])
+    batch = dict(input_ids=g["input_ids"], input_features=g["input_features"])
+    L = g["input_ids"].shape[1]
+    for name, opts in (("rep", dict(repetition_penalty=1.3)), ("ngram", dict(no_repeat_ngram_size=2)),
+                       ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2))):
+        out = m.generate(**kw, max_new_tokens=16, **opts).cpu().numpy()
+        assert out.shape == (2, 16)
+        exact = _check_greedy_against_oracle(out, batch, W, cfg, (S["eos_id"], S["pad_id"]), S["pad_id"], **opts)
+        assert exact >= 26, (name, exact)                      # of 32 decisions
+        assert (out == g["tokens_" + name]).mean() > 0.5 and (out[:, :5] == g["tokens_" + name][:, :5]).all(), name
+        if "no_repeat_ngram_size" in opts:
+            for row in out:
+                seq = list(g["input_ids"][0]) + list(row)
+                big = list(zip(seq[L - 1:-1], seq[L:]))
+                assert len(set(big)) == len(big)
+    m.config.repetition_penalty = 1.3                            # the setting may also come from the config (asr_config.py:155-160)
+    out_cfg = m.generate(**kw, max_new_tokens=16).cpu().numpy()
+    assert np.array_equal(out_cfg, m.generate(**kw, max_new_tokens=16, repetition_penalty=1.3).cpu().numpy())
+
+
+def test_logits_process_kernel_vs_oracle():
+    """ta_logits_process alone, exact: random logits and sequences with repeated ids, every (penalty, n-gram) combination,
+    step counter read from device memory."""
+    from oracle import generate as OG
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.ops import ptr, stream
+    rng = np.random.RandomState(3)
+    B, V, Vp, L, max_new = 3, 200, 256, 9, 12
+    for step in (0, 1, 5, 12):
+        for pen, ng in ((1.0, 2), (1.7, 0), (1.7, 3), (0.6, 1), (1.2, 2)):
+            logits = rng.standard_normal((B, Vp)).astype(np.float32) * 3
+            prompt = rng.randint(0, 12, (B, L)).astype(np.int64)           # few distinct ids: many repeated n-grams
+            gen = rng.randint(0, 12, (B, max_new)).astype(np.int64)
+            seq = np.concatenate([prompt, gen[:, :step]], 1)
+            ref = OG.apply_logits_processors(logits[:, :V], seq, pen, ng)
+            lg = torch.from_numpy(logits).to(DEV)
+            pr, gn = torch.from_numpy(prompt).to(DEV), torch.from_numpy(gen).to(DEV)
+            st = torch.tensor([step], dtype=torch.int32, device=DEV)
+            _lib.check(_lib.lib().ta_logits_process(ptr(lg), Vp, V, ptr(pr), L, ptr(gn), max_new, ptr(st), B, pen, ng, stream()), "lp")
+            got = lg.cpu().numpy()
+            np.testing.assert_array_equal(got[:, :V], ref, err_msg=f"step {step} penalty {pen} ngram {ng}")
+            np.testing.assert_array_equal(got[:, V:], logits[:, V:])
 
 
 def test_generate_true_width_ragged_prompts_and_cache_consistency():

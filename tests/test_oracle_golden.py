@@ -213,6 +213,27 @@ def test_greedy_generate(golden):
     assert b.shape[1] == 11 and (b[0, 7:] == S["pad_id"]).all()          # clip 0 finished first and is padded
 
 
+def test_greedy_generate_with_logits_processors(golden):
+    """The reference's two non-default generation knobs (tiny_audio/asr_config.py:84-86 -> HF RepetitionPenaltyLogitsProcessor /
+    NoRepeatNGramLogitsProcessor over prompt ids + generated tokens): token-exact against the reference's own generate."""
+    from oracle import generate as OG
+    g = golden("generate_penalties_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    W = dict(encoder=OW.init_encoder(S["enc"], 0), lm=R.gen_lm_weights(), projector=OW.init_mlp_projector(E, D, H))
+    cfg = dict(enc=S["enc"], lm=S["lm"], projector_type="mlp", k=S["k"], audio_token_id=S["audio_token_id"])
+    batch = dict(input_ids=g["input_ids"], input_features=g["input_features"], attention_mask=np.ones_like(g["input_ids"]))
+    kw = dict(max_new_tokens=16, eos_ids=(S["eos_id"], S["pad_id"]), pad_id=S["pad_id"])
+    for name, opts in (("plain", {}), ("rep", dict(repetition_penalty=1.3)), ("ngram", dict(no_repeat_ngram_size=2)),
+                       ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2)), ("rep_strong", dict(repetition_penalty=5.0))):
+        np.testing.assert_array_equal(OG.greedy_generate(batch, W, cfg, **kw, **opts), g["tokens_" + name], err_msg=name)
+    assert not np.array_equal(g["tokens_plain"], g["tokens_rep"]) and not np.array_equal(g["tokens_plain"], g["tokens_ngram"])
+    for row in g["tokens_ngram"]:                            # the property itself: no bigram occurs twice in prompt + output
+        seq = list(g["input_ids"][0]) + list(row)
+        big = list(zip(seq[len(g["input_ids"][0]) - 1:-1], seq[len(g["input_ids"][0]):]))
+        assert len(set(big)) == len(big)
+
+
 # ----------------------------------------------------------------------------- whole model
 def _asr_setup(golden, ptype):
     g = golden("asr_small.npz")

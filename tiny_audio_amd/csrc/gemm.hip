@@ -77,7 +77,7 @@ struct GemmArgs {
 #define TA355_RATE_256x256_PP 1.40  /* per unit tile area vs the 128x128 kernel, fitted on profiles/r01_f_gemm_variants.txt (lm_qkv 56 vs 62 us, sq8192 1330 vs 1050 TF/s) */
 #define TA355_RATE_96x128 0.93      /* 3x4 instead of 4x4 MFMAs per fragment set; estimate, to be refitted */
 #define TA355_RATE_192x128 1.1      /* v5 (one 192x128 tile per CU), cold operands, profiles/r02_gemm_v5_ab_cold.txt: 1.05-1.15 in one round (lm o / down / dX: 43.5 / 58.5 / 61.7 / 97.2 us vs 49.4 / 68.4 / 74.3 / 120.2 for 96x128), 0.9-1.03 over several rounds; in the step 1.0 / 1.1 / 1.25 are equal for Qwen3-0.6B and 1.1 is 1 ms better than 1.0 for the 1.7B widths (2-round N = 2048 shapes); 0 = never chosen */
-#define TA355_RATE_192x256_PP 1.30  /* round 3: v4 on a 192-row tile (variant 12), see pick_variant */
+#define TA355_RATE_192x256_PP 1.15  /* round 3: v4 on a 192-row tile (variant 12).  Cold, M = 6144 (profiles/r03_b_gemm_lm_cold.txt): d(attn-out) N = 2048 36.3 us vs 42.7 (256x256) / 39.4 (v5); q|k|v N = 4096 794 vs 764 TF/s; gate|up N = 6144 95.9 us vs 80.6 for 256x320 -- the rate must keep 3 rounds of 192x256 ABOVE 2 rounds of 256x320 there (r < 1.278) and below 256x256 for N = 2048 / 4096 (r > 1.05); at 1.30 the step LOST 0.2 ms (gate|up moved) */
 #define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
@@ -1539,7 +1539,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     if (e && *e == '1') variant = 11;
   }
   if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
-  if (a.w_blocked && variant >= 6) return TA_ERR_ARG;         // the ring kernel stages plain [N, K] weights only
+  if (a.w_blocked && variant >= 6 && variant != 12) return TA_ERR_ARG;         // the ring kernel (and v5 / v6) stage plain [N, K] weights only
   const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12) ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
   const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12) ? 256 : 128);

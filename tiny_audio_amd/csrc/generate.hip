@@ -148,6 +148,50 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
   }
 }
 
+// HF logits processors of the reference's generation settings (tiny_audio/asr_config.py:84-86,155-160, forwarded to
+// language_model.generate at tiny_audio/asr_modeling.py:627-633 together with input_ids, so the processors see the PROMPT
+// ids followed by the generated tokens), applied to the f32 logits of the step before the argmax:
+//   RepetitionPenaltyLogitsProcessor (TF:generation/logits_process.py): every token id of the sequence so far gets
+//       score < 0 ? score * penalty : score / penalty -- once, however often it occurs (gather, then scatter);
+//   NoRepeatNGramLogitsProcessor(n): with the last n-1 tokens as the prefix, every token that followed an earlier occurrence
+//       of that prefix is banned (-inf); nothing is banned while the sequence is shorter than n-1 tokens.
+// One workgroup per clip.  The sequence length comes from *step_p in device memory (prompt length + tokens generated so
+// far), so the launch arguments never change and the step stays hipGraph-capturable.
+#define LP_MAXSEQ 8192
+__global__ __launch_bounds__(1024) void logits_process_kernel(float* __restrict__ logits, long ld, int V, const long* __restrict__ prompt,
+                                                              int L, const long* __restrict__ out_seq, int max_new,
+                                                              const int* __restrict__ step_p, float penalty, int ngram) {
+  __shared__ float val[LP_MAXSEQ];
+  const int b = blockIdx.x, t = *step_p, n = L + (t < max_new ? t : max_new);
+  float* row = logits + (long)b * ld;
+  const long* pr = prompt + (long)b * L;
+  const long* gen = out_seq + (long)b * max_new;
+  auto tok = [&](int i) -> long { return i < L ? pr[i] : gen[i - L]; };
+  if (penalty != 1.0f) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {              // gather the ORIGINAL scores first ...
+      const long id = tok(i);
+      float sc = 0.f;
+      if (id >= 0 && id < V) { sc = row[id]; sc = sc < 0.f ? sc * penalty : sc / penalty; }
+      val[i] = sc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {              // ... then scatter: a repeated id is penalised once
+      const long id = tok(i);
+      if (id >= 0 && id < V) row[id] = val[i];
+    }
+    __syncthreads();
+  }
+  if (ngram > 0 && n + 1 >= ngram) {
+    const int pre = ngram - 1;                                        // prefix = tokens n-pre .. n-1
+    for (int i = threadIdx.x; i + pre < n; i += blockDim.x) {        // the n-gram starting at i ends at i + pre <= n - 1
+      bool same = true;
+      for (int j = 0; j < pre; ++j) same &= tok(i + j) == tok(n - pre + j);
+      const long id = tok(i + pre);
+      if (same && id >= 0 && id < V) row[id] = -INFINITY;
+    }
+  }
+}
+
 // HF greedy bookkeeping (TF:generation/utils.py _sample): finished clips emit pad; a clip finishes when it emits an
 // eos id; record the token, make it the next input, advance its position, open the next cache slot in the key mask.
 __global__ void greedy_advance_kernel(const long* __restrict__ amax, const long* __restrict__ eos, int n_eos, long pad_id,
@@ -351,6 +395,16 @@ extern "C" int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out
   if (rows <= 0) return TA_OK;
   if (n <= 0) return TA_ERR_ARG;
   TA_LAUNCH(argmax_rows_kernel, dim3(rows), dim3(1024), 0, st, x, ld, n, out);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+extern "C" int ta_logits_process(float* logits, long ld, int V, const long* prompt_ids, int L, const long* out_seq, int max_new,
+                                 const int* step_dev, int B, float repetition_penalty, int no_repeat_ngram_size, hipStream_t st) {
+  if (B <= 0 || (repetition_penalty == 1.0f && no_repeat_ngram_size <= 0)) return TA_OK;
+  if (L + max_new > LP_MAXSEQ || repetition_penalty <= 0.f || no_repeat_ngram_size < 0) return TA_ERR_ARG;
+  TA_LAUNCH(logits_process_kernel, dim3(B), dim3(1024), 0, st, logits, ld, V, prompt_ids, L, out_seq, max_new, step_dev,
+            repetition_penalty, no_repeat_ngram_size);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

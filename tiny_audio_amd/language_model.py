@@ -475,17 +475,18 @@ class Qwen3MI355X(torch.nn.Module):
     # ------------------------------------------------------------------ greedy decoding
     @torch.no_grad()
     def greedy_decode(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
-                      sync_every=8, use_graph=True):
+                      sync_every=8, use_graph=True, repetition_penalty=1.0, no_repeat_ngram_size=0):
         """-> int64 [B, n_new]; see ``greedy_decode_iter`` (this drains it, polling the device every ``sync_every``
         steps only)."""
         out = None
         for out in self.greedy_decode_iter(input_ids, src_row, audio, attention_mask, max_new_tokens, eos_ids, pad_id,
-                                           sync_every, use_graph, per_token=False):
+                                           sync_every, use_graph, per_token=False, repetition_penalty=repetition_penalty,
+                                           no_repeat_ngram_size=no_repeat_ngram_size):
             pass
         return out
 
     def greedy_decode_iter(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
-                           sync_every=8, use_graph=True, per_token=True):
+                           sync_every=8, use_graph=True, per_token=True, repetition_penalty=1.0, no_repeat_ngram_size=0):
         """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
         config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
         emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
@@ -539,7 +540,12 @@ class Qwen3MI355X(torch.nn.Module):
         ids = input_ids.to(device=dev, dtype=i64).contiguous()
         a = None if audio is None else audio.detach().to(F32).contiguous()
 
+        rep, ngram = float(repetition_penalty), int(no_repeat_ngram_size)
+
         def advance():
+            if rep != 1.0 or ngram > 0:            # HF logits processors over prompt ids + generated tokens (device-side, graph-safe)
+                _lib.check(L_.ta_logits_process(ptr(logits), self.vocab_pad, c.vocab_size, ptr(ids), L, ptr(out_seq), max_new,
+                                                ptr(step_dev), B, rep, ngram, stream()), "ta_logits_process")
             _lib.check(L_.ta_argmax_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, ptr(amax), stream()), "ta_argmax_f32")
             _lib.check(L_.ta_greedy_advance(ptr(amax), ptr(eos), n_eos, int(pad_id), ptr(finished), ptr(next_ids), ptr(out_seq),
                                             max_new, ptr(step_dev), ptr(slot_dev), ptr(pos), ptr(kmask), Lmax, B, ptr(alive),
