@@ -58,6 +58,28 @@ def test_gemm_epilogues():
     assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=BF16), torch.nn.functional.gelu(ref)) < 1.5e-2
 
 
+@pytest.mark.parametrize("variant", ["3", "4", "12"])
+def test_gemm_gelu_chord_table(variant, monkeypatch):
+    """The persistent ping-pong kernel evaluates erf-GELU through the 1024-chord table of csrc/gelu_lut.h staged in LDS
+    (round 3): f32 output against torch's exact GELU, |error| <= 2.5e-5 + fp32 accumulation noise; TA355_GELU_LUT=0 (the
+    arithmetic form) gives the same values to that tolerance; inputs far outside the table's range take the end chords."""
+    monkeypatch.setenv("TA355_GEMM_VARIANT", variant)
+    M, N, K = 700, 640, 256
+    A, W = rnd(M, K, seed=3, dtype=BF16), rnd(N, K, seed=4, scale=2.5 / math.sqrt(K), dtype=BF16)
+    bias = rnd(N, seed=5)
+    bias[:8] = torch.tensor([-30.0, 30.0, -9.0, 9.0, -8.0, 8.0, 1e4, -1e4], device=DEV)        # beyond [-8, 8): GELU -> 0 resp. x
+    pre = A.float() @ W.float().T + bias
+    ref = torch.nn.functional.gelu(pre)
+    out = ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=F32)
+    assert float((out - ref).abs()[:, 8:].max()) < 1e-4, float((out - ref).abs()[:, 8:].max())
+    assert relerr(out[:, :8], ref[:, :8]) < 1e-5
+    monkeypatch.setenv("TA355_GELU_LUT", "0")
+    out0 = ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=F32)
+    assert float((out0 - ref).abs()[:, 8:].max()) < 1e-4 and not torch.equal(out0, out)
+    monkeypatch.delenv("TA355_GELU_LUT")
+    assert relerr(ops.gemm_nt(A, W, bias=bias, act=1, out_dtype=BF16), ref) < 1.5e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 64, 256), (1000, 1024, 1024), (6144, 4096, 1024), (4100, 1024, 3072)])
 @pytest.mark.parametrize("variant", [None, "0", "1", "3", "4", "10", "11", "12"])
 def test_gemm_k_extension(M, N, K, variant, monkeypatch):

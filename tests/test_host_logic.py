@@ -544,6 +544,14 @@ def test_causal_lm_output_is_model_output_shaped():
         o3.hidden_states
 
 
+def test_hf_label_names_are_just_labels():
+    """HF Trainer derives label_names from the forward signature (every parameter whose name contains "label"); a second such
+    parameter made Trainer.predict treat the batches as unlabelled (round 3: label_meta now travels through **kwargs)."""
+    from transformers.utils.generic import find_labels
+    from tiny_audio_amd.asr_modeling import ASRModel
+    assert find_labels(ASRModel) == ["labels"]
+
+
 def test_register_module_handles_survive_deepcopy():
     """A deep copy carries the original's handle attribute; it must get its own handle instead of rebinding the original's."""
     import copy

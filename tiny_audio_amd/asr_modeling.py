@@ -220,13 +220,15 @@ class ASRModel(nn.Module):
     def forward(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, audio_token_counts: Optional[torch.Tensor] = None,
-                num_items_in_batch=None, return_logits: bool = True, frame_keep=None, label_meta=None, after_encoder=None,
+                num_items_in_batch=None, return_logits: bool = True, frame_keep=None, after_encoder=None,
                 **kwargs):
         """Training/eval forward (tiny_audio/asr_modeling.py:481-533).
 
         ``num_items_in_batch``: as in HF Trainer -- loss = sum(nll) / num_items_in_batch (default: the number of
         label tokens in this batch, i.e. the mean).  ``return_logits=False`` skips materialising the [B, L, V]
-        logits (the HF Trainer discards them on the training path).  ``label_meta=(rows, targets, n)`` lets a
+        logits (the HF Trainer discards them on the training path).  ``label_meta=(rows, targets, n)`` (through ``**kwargs``:
+        a NAMED parameter containing "label" would enter HF Trainer's ``label_names`` -- find_labels scans the signature -- and
+        Trainer.predict would then treat every batch as unlabelled) lets a
         collator that already knows the label positions on the host avoid one device->host sync.
         """
         dev = self.device_
@@ -248,6 +250,7 @@ class ASRModel(nn.Module):
         kmask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int32).contiguous()
         n_lab, rows, targets = 0, None, None
         if labels is not None:
+            label_meta = kwargs.pop("label_meta", None)
             if label_meta is not None:
                 rows, targets, n_lab = label_meta
             else:

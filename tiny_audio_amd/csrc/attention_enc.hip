@@ -10,7 +10,7 @@
 //   * the softmax runs in base 2 on PRE-SCALED scores: head_dim^-0.5 * log2(e) is folded into the q rows of the weight image,
 //     and the running maximum enters the QK^T MFMAs as their C operand (s' = k.q - m), so the per-score VALU work is
 //     1 v_exp + 1/2 v_max3 + 1/2 v_cvt_pk -- no multiply-subtract pass, no accumulator zeroing.  O and l are rescaled only when
-//     a tile raises some row's maximum (s' > 0); the row sums ride on an all-ones MFMA block.
+//     a tile raises some row's maximum by more than 2^8 (deferred rescale); the row sums ride on an all-ones MFMA block.
 //   * the output tile is staged through LDS and stored as whole 128-byte rows.
 // Per 64-key x 32-query tile and wave: 36 MFMAs (16 QK^T, 16 PV, 4 row sums), 32 v_exp, 16 v_max3, 16 v_cvt_pk, 8 ds_read_b128,
 // 16 ds_read_b64_tr_b16.
@@ -24,6 +24,7 @@ constexpr int HD = 64;                 // head dim
 constexpr int KT = 64;                 // keys per tile
 constexpr int TILE = KT * HD * 2;      // 8 KB: one K or V tile, rows of 128 B
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 8.0f;
 
 // K rows: 16-B chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128 fragments (the GEMM's scheme).
 // V rows: chunk index XOR 2 * ((row >> 1) & 3): the transposing read of one 16-lane group covers 4 rows x 32 B, two groups
@@ -178,8 +179,13 @@ __global__ __launch_bounds__(256) void attn_enc_fwd_kernel(const bf16_t* __restr
       mx = max3(mx, s[sub][3][1], s[sub][3][2]);
       mx = fmaxf(mx, s[sub][3][3]);
       mx = group_max(mx);
-      // s' > 0 somewhere: that row's maximum moved.  Tile 0 always takes this path (m starts at 0, not at the first maximum).
-      if (t == 0 || __any(mx > 0.f)) {
+      // Deferred rescale: m is the maximum as of the last rescale, not the running maximum -- it moves only when some row of the
+      // wave exceeds it by more than RESCALE_THR (base-2 units: P <= 2^8 in between; bf16 keeps its relative precision, the f32
+      // accumulators have the headroom, and O / l are built from the SAME rounded P, so the normalisation stays consistent).
+      // An exact running maximum moves for SOME of a wave's 16 rows in almost every tile -- 1 - (t / (t + 1))^16 on exchangeable
+      // scores -- so "rescale when the maximum moved" ran its 45 extra VALU per sub-tile nearly always (PMC: 225 VALU per 36
+      // MFMAs).  Tile 0 always takes the path (m starts at 0, not at the first maximum).
+      if (t == 0 || __any(mx > RESCALE_THR)) {
         const float d = t == 0 ? mx : fmaxf(mx, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll

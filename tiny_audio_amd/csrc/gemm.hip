@@ -81,6 +81,7 @@ struct GemmArgs {
 #define TA355_RATE_256x320_PP 1.42  /* enc qkv 140 vs 147 us (256x256), fc2 1190 vs 870 TF/s, lm gate|up 73 vs 86 us, lm dact 39 vs 55 us */
 #endif
 #define TILE_BYTES (BM * BK * 2)   // 16 KiB
+#include "gelu_lut.h"
 
 // the same DMA in its scalar-base form: address = 64-bit uniform base (SGPR pair) + 32-bit per-lane byte offset; `lds` is the
 // wave-uniform LDS byte address (the hardware adds lane * 16).  Inline assembly: the builtin keeps 64-bit per-lane pointers.
@@ -104,9 +105,18 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // the bf16 epilogue cost 14.5 us per round of 256 tiles vs 7.6 us of HBM time), so adjacent fragments are first
 // exchanged between lane rows with v_permlane16_swap: afterwards lane g holds 8 consecutive columns
 // (16 * (j + (g & 1)) + 8 * (g >> 1) ...) and one store covers 64 contiguous bytes per row.
+// erf-GELU through the chord table of gelu_lut.h staged in LDS (`lut`): 3 VALU + 1 ds_read_b64 + 1 FMA per element instead of the
+// 13 VALU + v_rcp + v_exp of gelu_erf_fast.  Round 3: in the encoder's fc1 (M = 16000, N = 5120, K = 1280) the arithmetic form
+// cost ~25 k of the ~94 k cycles a CU spends per 256x320 tile -- un-overlapped VALU time in the epilogue.  |error| <= 2.5e-5.
+__device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
+  float t = fmaf(x, GELU_LUT_SCALE, GELU_LUT_BIAS);
+  t = __builtin_amdgcn_fmed3f(t, 0.f, (float)(GELU_LUT_N - 1));
+  const float2 e = lut[(int)t];
+  return fmaf(e.x, x, e.y);
+}
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
-                                               int m, const float* bias) {
+                                               int m, const float* bias, const float2* lut = nullptr) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
@@ -137,7 +147,8 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
       if (BASE == 1) {
-        v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]);
+        if (lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
+        else { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]); }
       }
       if (BASE == 2) {
         const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
@@ -820,6 +831,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     }
     if (nx.ok) first_dma(nx);
     if (LIFE) lf[3] = __builtin_amdgcn_s_memtime();
+    // GELU epilogues: the chord table (8 KB) goes into stage 1 -- free until the next tile's second K tile is staged, which
+    // happens after this epilogue -- one 16-B piece per thread; TA355_GELU_LUT=0 (p.dbg bit 3) keeps the arithmetic form
+    constexpr bool GELU = ACT == 1 || ACT == 3;
+    const float2* lut = nullptr;
+    if (GELU && !(p.dbg & 8)) {
+      static_assert(GELU_LUT_N * 8 == 512 * 16, "one uint4 per thread");
+      *(uint4*)(smem + STAGE + tid * 16) = ((const uint4*)kGeluLut)[tid];
+      __syncthreads();
+      lut = (const float2*)(smem + STAGE);
+    }
 
     // ---- epilogue of `cur`.  Its index arithmetic starts from an opaque copy of the thread index: otherwise the compiler
     // hoists those loop-invariant values out of the tile loop and carries them, spilled, across the main loop.
@@ -837,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
           if (ml >= cur.Mact) continue;
           const int m = cur.rbase + ml;
           const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-          epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, cur.n0 + e_wn * (BN2 / 4), e_g, wide, m, cur.biasp);
+          epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, cur.n0 + e_wn * (BN2 / 4), e_g, wide, m, cur.biasp, lut);
         }
       }
     }
@@ -1549,10 +1570,17 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   {
     const char* gm = getenv("TA355_GROUP_M");             // experiments: tile-order group height
     a.group_m = gm && *gm ? atoi(gm) : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD
+    // 12 column tiles of 320 (the encoder's q | k | v GEMM, 3 rounds): groups of 16 row tiles instead of 4 -- an XCD's round is then
+    // 16 row tiles x 2 column tiles.  Cold operands (profiles/r03_c_gemm_enc_groupm_cold.txt): 146.3 us against 153.9 (g = 8:
+    // 148.1); N = 5120 / 1280 shapes are flat in g.  TA355_GROUP_M_AUTO=0 keeps 4 everywhere.
+    static const bool gauto = [] { const char* v = getenv("TA355_GROUP_M_AUTO"); return !(v && *v == '0'); }();
+    if (!(gm && *gm) && gauto && variant == 4 && a.tiles_n == 12 && a.tiles_m >= 32) a.group_m = 16;
     const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
     a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
     const char* d = getenv("TA355_GEMM_DEBUG");           // experiments: 1 = no epilogue stores, 2 = one K tile only
     a.dbg = d && *d ? atoi(d) : 0;
+    const char* gl = getenv("TA355_GELU_LUT");            // 0 = arithmetic erf-GELU in the ping-pong kernel's epilogue (A/B, tests)
+    if (gl && *gl == '0') a.dbg |= 8;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
   // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
