@@ -843,6 +843,31 @@ __device__ __forceinline__ void qkv_post_bwd_tile(const char* st, const QkvPostB
   }
 }
 
+// ---- round 3: global -> LDS DMA staging of [64][128] row tiles for the backward (double-buffered LDS, no staging registers).
+// Inline assembly: behind the builtin the compiler drains vmcnt in front of every later transposing LDS read (it tracks the DMA as
+// an LDS store that may alias them), which would wait for the NEXT tile right after issuing it.  Every wait for these loads is the
+// explicit s_waitcnt vmcnt(0) at the top of an iteration.  `lds` = wave-uniform LDS byte address, the hardware adds lane * 16.
+__device__ __forceinline__ void dma16_asm(const void* g, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
+}
+// rows row0 .. row0 + 63 (clamped to nrows - 1) of a [.., 128] bf16 matrix with `row_stride` elements per row -> the RowTile<128>
+// image at `lds_tile`: one wave instruction covers 4 rows x 256 B, wave w of 4 moves row blocks w, w + 4, w + 8, w + 12; the XOR
+// swizzle of the image is applied to the SOURCE chunk (the LDS side of the DMA is lane-linear).
+__device__ __forceinline__ void dma_rowtile128(const bf16_t* base, long row_stride, int row0, int nrows, unsigned lds_tile, int wave,
+                                               int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int blk = wave + 4 * i, r = blk * 4 + (lane >> 4);
+    int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; if (gr < 0) gr = 0;
+    const int c = (lane & 15) ^ RowTile<128>::swz(r);
+    dma16_asm(base + (long)gr * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + blk * 1024));   // (wave-uniform by construction)
+  }
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p);
+}
+constexpr int BWD_BUF = 2 * 64 * 128 * 2 + 512;      // one staging buffer of the backward: two row tiles + 128 floats / ints
+
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
 template <int HD, bool CAUSAL>
@@ -852,9 +877,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
                                                  const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                  const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
                                                  int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F) {
-  char* Ks = smem;
-  char* Vs = Ks + RowTile<HD>::BYTES;
-  int* Ms = (int*)(Vs + RowTile<HD>::BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int nq = (L + 63) / 64, grp = Hq / Hkv;
   int group, member;
@@ -882,14 +904,27 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
   for (int i = 0; i < HD / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int ntiles = (L + KV_TILE - 1) / KV_TILE;
   if (CAUSAL) { const int lim = qt + 1; if (lim < ntiles) ntiles = lim; }
+  // Round 3: K / V tiles by DMA into a double buffer, the next tile issued before this tile's arithmetic (the kernel runs at
+  // 2 waves per SIMD -- 216 VGPRs -- and load -> store -> barrier -> compute exposed the full fetch latency in every iteration)
+  static_assert(HD == 128, "the DMA staging of the backward is written for head_dim 128");
+  const unsigned lds0 = lds_addr_of(smem);
+  int pm = 0;
+  auto issue = [&](int t) {
+    const unsigned dst = lds0 + (t & 1) * BWD_BUF;
+    dma_rowtile128(Kb, HD, t * KV_TILE, L, dst, wave, lane);
+    dma_rowtile128(Vb, HD, t * KV_TILE, L, dst + RowTile<HD>::BYTES, wave, lane);
+    if (tid < 64) { const int kk = t * KV_TILE + tid; pm = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
+  };
+  if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * KV_TILE;
-    {
-      RowStage<HD> a; a.load(Kb, HD, key0, L, tid); a.store(Ks, tid);
-      RowStage<HD> c; c.load(Vb, HD, key0, L, tid); c.store(Vs, tid);
-      if (tid < 64) { const int kk = key0 + tid; Ms[tid] = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
-    }
-    __syncthreads();
+    char* Ks = smem + (t & 1) * BWD_BUF;
+    char* Vs = Ks + RowTile<HD>::BYTES;
+    int* Ms = (int*)(Vs + RowTile<HD>::BYTES);
+    if (tid < 64) Ms[tid] = pm;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // tile t has landed; every wave is done with tile t - 1 (the other buffer)
+    if (t + 1 < ntiles) issue(t + 1);
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -924,8 +959,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
         dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq[dt], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
+  __syncthreads();                                     // the tiles are free for the fused epilogue's image
   if (F.qkv0) {
     if constexpr (HD == 128) {
       qkv_stage_f32(smem, dq, wave, l15, g);                 // the last loop iteration ended with a barrier: the tiles are free
@@ -956,10 +991,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
                                                   const int* __restrict__ kmask, bf16_t* __restrict__ dK,
                                                   bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
                                                   float scale, const QkvPostBwd& F) {
-  char* Qs = smem;
-  char* dOs = Qs + RowTile<HD>::BYTES;
-  float* Ls = (float*)(dOs + RowTile<HD>::BYTES);    // [64] lse * log2e
-  float* Ds = Ls + 64;                               // [64] delta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int grp = Hq / Hkv;
   int group, kt_idx;
@@ -982,23 +1013,37 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   for (int i = 0; i < HD / 16; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   const int nq = (L + 63) / 64;
   const int qt_begin = CAUSAL ? kt_idx : 0;
+  // Round 3: Q / dO tiles by DMA into a double buffer; the (head, query tile) pairs of this key tile form ONE sequence of
+  // iterations, the next one's tiles are in flight while this one computes
+  static_assert(HD == 128, "the DMA staging of the backward is written for head_dim 128");
+  const unsigned lds0 = lds_addr_of(smem);
+  float pl = 1.0e30f, pd = 0.f;
+  int it = 0;
+  auto issue = [&](int hh, int qt, int buf) {
+    const int h = hk * grp + hh, q0 = qt * 64;
+    const unsigned dst = lds0 + buf * BWD_BUF;
+    dma_rowtile128(Q + ((long)(b * Hq + h) * L) * HD, HD, q0, L, dst, wave, lane);
+    dma_rowtile128(dO + (long)b * L * dO_stride + (long)h * HD, dO_stride, q0, L, dst + RowTile<HD>::BYTES, wave, lane);
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      const bool v = qq < L;
+      pl = v ? LSE[(long)(b * Hq + h) * L + qq] * LOG2E : 1.0e30f;
+      pd = v ? Delta[(long)(b * Hq + h) * L + qq] : 0.f;
+    }
+  };
+  if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
   for (int hh = 0; hh < grp; ++hh) {
-    const int h = hk * grp + hh;
-    const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
-    const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;
-    for (int qt = qt_begin; qt < nq; ++qt) {
+    for (int qt = qt_begin; qt < nq; ++qt, ++it) {
       const int q0 = qt * 64;
-      {
-        RowStage<HD> a; a.load(Qb, HD, q0, L, tid); a.store(Qs, tid);
-        RowStage<HD> c; c.load(dOb, dO_stride, q0, L, tid); c.store(dOs, tid);
-        if (tid < 64) {
-          const int qq = q0 + tid;
-          const bool v = qq < L;
-          Ls[tid] = v ? LSE[(long)(b * Hq + h) * L + qq] * LOG2E : 1.0e30f;
-          Ds[tid] = v ? Delta[(long)(b * Hq + h) * L + qq] : 0.f;
-        }
-      }
+      char* Qs = smem + (it & 1) * BWD_BUF;
+      char* dOs = Qs + RowTile<HD>::BYTES;
+      float* Ls = (float*)(dOs + RowTile<HD>::BYTES);  // [64] lse * log2e
+      float* Ds = Ls + 64;                             // [64] delta
+      if (tid < 64) { Ls[tid] = pl; Ds[tid] = pd; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
+      else if (hh + 1 < grp) issue(hh + 1, qt_begin, (it + 1) & 1);
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int qs = 0; qs < 4; ++qs) {
@@ -1039,9 +1084,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
           dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(read_colfrag_tr<HD>(Qs, dt, l15, c0, c1), dsb, dk[dt], 0, 0, 0);
         }
       }
-      __syncthreads();
     }
   }
+  __syncthreads();                                     // the tiles are free for the fused epilogue's image
   if (F.qkv0) {
     if constexpr (HD == 128) {
       qkv_stage_f32(smem, dk, wave, l15, g);
@@ -1071,7 +1116,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
 // are independent (both only read Q, K, V, dO), so a single grid lets the dQ workgroups fill the CUs while the longer
 // dK / dV ones drain, without a second stream or a kernel boundary in between.  The heavier dK / dV blocks go first.
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
                                                        const bf16_t* __restrict__ K, const bf16_t* __restrict__ KT,
                                                        const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, long dO_stride,
                                                        const bf16_t* __restrict__ dOT, const float* __restrict__ LSE,
@@ -1160,7 +1205,7 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
   // K^T / Q^T / dO^T fragments are read transposed out of the row tiles; the fused epilogue re-uses the space for a [64][128] f32 image
-  const size_t lds_kv = (2 * RowTile<HD>::BYTES + 128 * 4 > 64 * (size_t)QP_PITCH) ? 2 * RowTile<HD>::BYTES + 128 * 4 : 64 * (size_t)QP_PITCH;
+  const size_t lds_kv = (2 * (size_t)BWD_BUF > 64 * (size_t)QP_PITCH) ? 2 * (size_t)BWD_BUF : 64 * (size_t)QP_PITCH;      // two staging buffers
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);

@@ -206,6 +206,21 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     }
   }
 }
+// Every tile variant evaluates GELU through the same chord table (a GEMM's result must not depend on the tile the launch-time
+// model picks: the B = 32 step and the same clips at B = 4 run different variants and are compared in the tests).  `smem` must be
+// free: every wave past its last LDS read of the main loop.
+template <int ACT, int NTHREADS>
+__device__ __forceinline__ const float2* stage_gelu_lut(char* smem, const GemmArgs& p, int tid, bool barrier_first) {
+  if constexpr (ACT == 1 || ACT == 3) {
+    if (!(p.dbg & 8)) {
+      if (barrier_first) __syncthreads();
+      for (int i = tid; i < GELU_LUT_N * 8 / 16; i += NTHREADS) ((uint4*)smem)[i] = ((const uint4*)kGeluLut)[i];
+      __syncthreads();
+      return (const float2*)smem;
+    }
+  }
+  return nullptr;
+}
 __device__ __forceinline__ bool epilogue_wide_ok(const GemmArgs& p) { return p.wide != 0; }
 
 
@@ -359,13 +374,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   char* Cb = (char*)p.C;
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
+  const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, false);       // the K loop ended with a barrier
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int ml = m0 + wm * WR + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp);
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp, lut);
   }
 }
 
@@ -600,13 +616,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   char* Cb = (char*)p.C;
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
+  const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int ml = m0 + wm * 128 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp, lut);
   }
   if (life) {                                   // behind the C matrix: [workgroup][wave group] x {5 stamps, HW_ID, XCC_ID, tile}
     lf[3] = __builtin_amdgcn_s_memtime();
@@ -1039,13 +1056,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
     return;
   }
   const bool wide = epilogue_wide_ok(p);
+  const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int ml = m0 + wm * 128 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp);
+    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp, lut);
   }
 }
 
@@ -1261,13 +1279,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
       for (int e = 0; e < 4; ++e) acc[i][e] = (f32x4){acc32[i][4 * e], acc32[i][4 * e + 1], acc32[i][4 * e + 2], acc32[i][4 * e + 3]};
   }
   const bool wide = epilogue_wide_ok(p);
+  const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, true);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int ml = m0 + wm * 96 + i * 16 + l15;
     if (ml >= Mact) continue;
     const int m = rbase + ml;
     const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp);
+    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp, lut);
   }
 }
 
@@ -1572,8 +1591,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.group_m = gm && *gm ? atoi(gm) : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD
     // 12 column tiles of 320 (the encoder's q | k | v GEMM, 3 rounds): groups of 16 row tiles instead of 4 -- an XCD's round is then
     // 16 row tiles x 2 column tiles.  Cold operands (profiles/r03_c_gemm_enc_groupm_cold.txt): 146.3 us against 153.9 (g = 8:
-    // 148.1); N = 5120 / 1280 shapes are flat in g.  TA355_GROUP_M_AUTO=0 keeps 4 everywhere.
-    static const bool gauto = [] { const char* v = getenv("TA355_GROUP_M_AUTO"); return !(v && *v == '0'); }();
+    // 148.1); N = 5120 / 1280 shapes are flat in g.  Experiment only (TA355_GROUP_M_AUTO=1): no gain in the step.
+    static const bool gauto = [] { const char* v = getenv("TA355_GROUP_M_AUTO"); return v && *v == '1'; }();   // opt-in: in the STEP it measured 42.85 vs 42.79 ms (profiles/r03_d_ab_groupm.txt)
     if (!(gm && *gm) && gauto && variant == 4 && a.tiles_n == 12 && a.tiles_m >= 32) a.group_m = 16;
     const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
     a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
