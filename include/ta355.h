@@ -37,9 +37,15 @@ int ta_version(void); /* ABI version, currently 2 (round 3: ta_gemm_opts.rope_co
  * wav [B, Ls] f32 zero-padded to the longest clip, lens [B] true sample counts.
  * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once (dft is read only by the
  *      exact-DFT variant, TA355_LOGMEL_DFT=1; the default is a 16 x 25 mixed-radix FFT with compiled-in twiddles).
- * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.  clip_max_ws: int[B + 2 * n_mels] scratch. */
+ * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.
+ * clip_ws: int[2 * B] scratch (per-clip maxima and arrival counters; no initial contents required).
+ * mel_ranges: int[2 * n_mels] {first, end} frequency bin of every mel filter, from ta_logmel_mel_ranges -- a function of the
+ *      filter bank alone, computed once when the tables are uploaded (ABI 1 recomputed it per call into the scratch).
+ * The features are written in ONE pass: a clip's workgroups rendezvous on its arrival counter before applying the (max - 8)
+ * floor (clips longer than ~40 s fall back to a second pass). */
+int ta_logmel_mel_ranges(const float* melfb, int n_mels, int* mel_ranges, hipStream_t st);
 int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
-                  const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st);
+                  const float* melfb, int n_mels, float* feats, int* mask, int* clip_ws, const int* mel_ranges, hipStream_t st);
 
 /* ---- frozen GLM-ASR encoder: replaces model.audio_tower(input_features=...).last_hidden_state
  *      (tiny_audio/asr_modeling.py:448-450; TF:models/glmasr/modeling_glmasr.py:313-327). */

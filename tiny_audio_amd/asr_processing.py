@@ -67,6 +67,7 @@ class LogMelFeatureExtractor:
         self._dft = torch.from_numpy(dft).to(self.device)
         self._win = torch.from_numpy(win).to(self.device)
         self._mel = torch.from_numpy(slaney_mel_filters(feature_size)).to(self.device)
+        self._mel_ranges = None                                  # {first, end} bin per filter: computed once (ta_logmel_mel_ranges)
 
     def extract(self, wav: torch.Tensor, lens: torch.Tensor):
         """wav [B, Ls] f32 (zero padded, device), lens [B] int64 -> (features [B, n_mels, T], mask [B, T] int32);
@@ -79,9 +80,14 @@ class LogMelFeatureExtractor:
         T = Ls // HOP
         feats = torch.empty((B, self.feature_size, T), device=self.device, dtype=F32)
         mask = torch.empty((B, T), device=self.device, dtype=torch.int32)
-        cm = torch.empty(B + 2 * self.feature_size, device=self.device, dtype=torch.int32)     # clip maxima + mel bin ranges
+        if self._mel_ranges is None:
+            self._mel_ranges = torch.empty(2 * self.feature_size, device=self.device, dtype=torch.int32)
+            _lib.check(_lib.lib().ta_logmel_mel_ranges(ptr(self._mel), self.feature_size, ptr(self._mel_ranges), stream()),
+                       "ta_logmel_mel_ranges")
+        cm = torch.empty(2 * B, device=self.device, dtype=torch.int32)                         # clip maxima + arrival counters
         _lib.check(_lib.lib().ta_logmel_f32(ptr(wav), ptr(lens), B, Ls, ptr(self._dft), ptr(self._win), ptr(self._mel),
-                                            self.feature_size, ptr(feats), ptr(mask), ptr(cm), stream()), "ta_logmel_f32")
+                                            self.feature_size, ptr(feats), ptr(mask), ptr(cm), ptr(self._mel_ranges), stream()),
+                   "ta_logmel_f32")
         return feats, mask
 
     def __call__(self, raw_speech, sampling_rate=None, padding="longest", return_attention_mask=True,

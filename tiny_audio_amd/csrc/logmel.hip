@@ -217,7 +217,8 @@ template <int LFT, int LF_G>
 __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict__ wav, int Ls, const float* __restrict__ dft,
                                                          const float* __restrict__ window, const float* __restrict__ melfb,
                                                          int n_mels, float* __restrict__ out, int* __restrict__ clip_max, int T, int dbg,
-                                                         const int* __restrict__ mrange_g) {
+                                                         const int* __restrict__ mrange_g, int* __restrict__ arrived,
+                                                         const long* __restrict__ lens, int* __restrict__ mask) {
   constexpr int LF_SPAN = (LFT - 1) * HOP + NFFT, LF_SCR = LF_G * NFFT * 2, LF_MELS = LFT + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* span = lds;                              // [LF_SPAN]            (later: melbuf [n_mels][LF_MELS])
@@ -347,9 +348,28 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
   __syncthreads();
   if (dbg & 4) ts[4] = __builtin_amdgcn_s_memtime();
+  // Single pass (round 3, `arrived` != NULL): the tile stays in LDS until every workgroup of the clip has contributed its
+  // maximum -- an arrival counter per clip, released after this workgroup's atomicMax, polled by one lane -- and is written ONCE
+  // with the (max - 8) floor and the (x + 4) / 4 map applied: no second kernel re-reading and re-writing the 512 KB per clip.
+  // The workgroups of a clip have consecutive ids, so they are resident together (the host falls back to the two-pass form when
+  // a clip has more workgroups than a quarter of the resident slots).
+  float floorv = -INFINITY, add = 0.f, mul = 1.f;
+  if (arrived) {
+    float& fl_s = *(float*)(mrange + 2 * n_mels);             // one float behind the mel ranges (sized by the host)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(arrived + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const int need = gridDim.x;
+      while (__hip_atomic_load(arrived + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+      fl_s = ord2f(__hip_atomic_load(clip_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - 8.0f;
+    }
+    __syncthreads();
+    floorv = fl_s; add = 4.0f; mul = 0.25f;
+    if (mask && blockIdx.x == 0)
+      for (int t = tid; t < T; t += 256) mask[(long)b * T + t] = ((long)t * HOP < lens[b]) ? 1 : 0;
+  }
   for (int i = tid; i < n_mels * LFT; i += 256) {                 // one mel row = LFT consecutive frames per store
     const int r = i / LFT, f = i - r * LFT;
-    if (t0 + f < T) out[((long)b * n_mels + r) * T + t0 + f] = melbuf[r * LF_MELS + f];
+    if (t0 + f < T) out[((long)b * n_mels + r) * T + t0 + f] = (fmaxf(melbuf[r * LF_MELS + f], floorv) + add) * mul;
   }
   if (dbg & 4) {                                                  // experiment: phase stamps of workgroup (5, 3) into the output
     __syncthreads();
@@ -359,14 +379,9 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   }
 }
 
-// block n_mels: clip maxima := -inf.  block m < n_mels: {first, end} bin of mel filter m (its non-zero taps) -> mrange[2m..]:
-// the FFT kernel applies every filter over its own ~4 (low) to ~13 (high) bins instead of all 201.
-__global__ __launch_bounds__(256) void logmel_init_kernel(int* clip_max, int B, const float* __restrict__ melfb, int n_mels,
-                                                          int* __restrict__ mrange) {
-  if ((int)blockIdx.x == n_mels) {
-    for (int i = threadIdx.x; i < B; i += blockDim.x) clip_max[i] = f2ord(-INFINITY);
-    return;
-  }
+// {first, end} bin of every mel filter (its non-zero taps): the FFT kernel applies a filter over its own ~4 (low) to ~13 (high) bins
+// instead of all 201.  Depends on the filter bank only: computed ONCE at table upload (ta_logmel_mel_ranges).
+__global__ __launch_bounds__(256) void logmel_ranges_kernel(const float* __restrict__ melfb, int n_mels, int* __restrict__ mrange) {
   __shared__ int lo_s, hi_s;
   if (threadIdx.x == 0) { lo_s = NBIN; hi_s = 0; }
   __syncthreads();
@@ -374,6 +389,10 @@ __global__ __launch_bounds__(256) void logmel_init_kernel(int* clip_max, int B, 
   if (k < NBIN && melfb[k * n_mels + m] != 0.f) { atomicMin(&lo_s, k); atomicMax(&hi_s, k + 1); }
   __syncthreads();
   if (threadIdx.x == 0) { mrange[2 * m] = lo_s; mrange[2 * m + 1] = hi_s; }
+}
+// per call: clip maxima := -inf, arrival counters := 0
+__global__ void logmel_init_kernel(int* clip_max, int B) {
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { clip_max[i] = f2ord(-INFINITY); clip_max[B + i] = 0; }
 }
 
 // x = (max(x, clipmax - 8) + 4) / 4 in place; also the frame mask [B, T]: 1 iff t*160 < len[b]
@@ -389,38 +408,57 @@ __global__ void logmel_finalize_kernel(float* __restrict__ out, const int* __res
     for (int t = threadIdx.x; t < T; t += blockDim.x) mask[(long)b * T + t] = ((long)t * HOP < lens[b]) ? 1 : 0;
 }
 
+extern "C" int ta_logmel_mel_ranges(const float* melfb, int n_mels, int* mel_ranges, hipStream_t st) {
+  if (!melfb || !mel_ranges || n_mels <= 0) return TA_ERR_ARG;
+  TA_LAUNCH(logmel_ranges_kernel, dim3(n_mels), dim3(256), 0, st, melfb, n_mels, mel_ranges);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
 // wav f32 [B, Ls] (zero-padded to the longest clip), lens int64 [B] -> feats f32 [B, n_mels, T], mask i32 [B, T],
-// T = Ls / 160.  clip_max_ws: int[B + 2 * n_mels] workspace (clip maxima, then the bin range of every mel filter).
+// T = Ls / 160.  clip_ws: int[2 * B] scratch (clip maxima, arrival counters: no initial contents required);
+// mel_ranges: int[2 * n_mels] from ta_logmel_mel_ranges (computed once per filter bank).
 extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
-                             const float* melfb, int n_mels, float* feats, int* mask, int* clip_max_ws, hipStream_t st) {
+                             const float* melfb, int n_mels, float* feats, int* mask, int* clip_ws, const int* mel_ranges,
+                             hipStream_t st) {
   if (B <= 0) return TA_OK;
   const int T = Ls / HOP;
-  if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256)) return TA_ERR_ARG;
-  int* mrange_ws = clip_max_ws + B;                 // [2 * n_mels] behind the clip maxima
-  TA_LAUNCH(logmel_init_kernel, dim3(n_mels + 1), dim3(256), 0, st, clip_max_ws, B, melfb, n_mels, mrange_ws);
+  if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256) || !clip_ws || !mel_ranges) return TA_ERR_ARG;
+  TA_LAUNCH(logmel_init_kernel, dim3(1), dim3(256), 0, st, clip_ws, B);
   // TA355_LOGMEL_DFT=1: the exact-f32 DFT-as-GEMM form (bit-for-bit a scalar fmaf chain) instead of the mixed-radix FFT
   static const bool use_dft = [] { const char* e = getenv("TA355_LOGMEL_DFT"); return e && *e == '1'; }();
+  bool two_pass = true;
   if (use_dft) {
     TA_LAUNCH(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
-              feats, clip_max_ws, T);
+              feats, clip_ws, T);
   } else {
     static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
     static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
-    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4; };
+    static const bool onepass_off = [] { const char* e = getenv("TA355_LOGMEL_ONEPASS"); return e && *e == '0'; }();
+    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 16; };
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
       attr = true;
     }
+    static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     // the mel stage works on groups of 16 frames per thread: LFT / (256 / n_mels) >= 16 holds for <32, 2> only at n_mels = 128
-    if (big || n_mels != 128)
-      TA_LAUNCH((logmel_fft_kernel<64, 4>), dim3(ta_cdiv(T, 64), B), dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_max_ws, T, dbg, mrange_ws);
+    const bool wide = big || n_mels != 128;
+    const int nblk = ta_cdiv(T, wide ? 64 : 32), resident = ncu * (wide ? 1 : 2);
+    // single pass needs every workgroup of a clip resident at once (they wait for one another): consecutive ids make that so
+    // as long as a clip is a small part of the resident set; very long clips (> ~40 s at 256 CUs) keep the two-pass form
+    two_pass = onepass_off || dbg != 0 || nblk * 4 > resident;
+    int* arrived = two_pass ? nullptr : clip_ws + B;
+    if (wide)
+      TA_LAUNCH((logmel_fft_kernel<64, 4>), dim3(nblk, B), dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask);
     else
-      TA_LAUNCH((logmel_fft_kernel<32, 2>), dim3(ta_cdiv(T, 32), B), dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_max_ws, T, dbg, mrange_ws);
+      TA_LAUNCH((logmel_fft_kernel<32, 2>), dim3(nblk, B), dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask);
   }
-  int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
-  TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_max_ws, lens, mask, n_mels, T);
+  if (two_pass) {
+    int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
+    TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_ws, lens, mask, n_mels, T);
+  }
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
