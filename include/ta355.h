@@ -41,8 +41,8 @@ int ta_version(void); /* ABI version, currently 2 (round 3: ta_gemm_opts.rope_co
  * clip_ws: int[2 * B] scratch (per-clip maxima and arrival counters; no initial contents required).
  * mel_ranges: int[2 * n_mels] {first, end} frequency bin of every mel filter, from ta_logmel_mel_ranges -- a function of the
  *      filter bank alone, computed once when the tables are uploaded (ABI 1 recomputed it per call into the scratch).
- * The features are written in ONE pass: a clip's workgroups rendezvous on its arrival counter before applying the (max - 8)
- * floor (clips longer than ~40 s fall back to a second pass). */
+ * (The arrival counters serve the opt-in single-pass form, TA355_LOGMEL_ONEPASS=1: a clip's workgroups rendezvous before applying
+ * the (max - 8) floor and write the features once.  It measured slower than the default second pass over the 512 KB per clip.) */
 int ta_logmel_mel_ranges(const float* melfb, int n_mels, int* mel_ranges, hipStream_t st);
 int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
                   const float* melfb, int n_mels, float* feats, int* mask, int* clip_ws, const int* mel_ranges, hipStream_t st);

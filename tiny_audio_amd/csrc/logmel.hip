@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
   __syncthreads();
   if (dbg & 4) ts[4] = __builtin_amdgcn_s_memtime();
-  // Single pass (round 3, `arrived` != NULL): the tile stays in LDS until every workgroup of the clip has contributed its
+  // Single pass (round 3 experiment, `arrived` != NULL, opt-in: it measured slower): the tile stays in LDS until every workgroup of the clip has contributed its
   // maximum -- an arrival counter per clip, released after this workgroup's atomicMax, polled by one lane -- and is written ONCE
   // with the (max - 8) floor and the (x + 4) / 4 map applied: no second kernel re-reading and re-writing the 512 KB per clip.
   // The workgroups of a clip have consecutive ids, so they are resident together (the host falls back to the two-pass form when
@@ -434,7 +434,10 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
   } else {
     static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
     static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
-    static const bool onepass_off = [] { const char* e = getenv("TA355_LOGMEL_ONEPASS"); return e && *e == '0'; }();
+    // TA355_LOGMEL_ONEPASS=1 (experiment; measured SLOWER, profiles/r03_f_logmel_onepass.txt: 113.7 us against 80.9 for 32 clips):
+    // the clip's workgroups rendezvous on an arrival counter and write the tile once from LDS instead of the second pass -- but a
+    // workgroup then holds its CU slot until the slowest of its clip's 32 arrives, and the second wave of clips starts that much later
+    static const bool onepass_off = [] { const char* e = getenv("TA355_LOGMEL_ONEPASS"); return !(e && *e == '1'); }();
     auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 16; };
     static bool attr = false;
     if (!attr) {
