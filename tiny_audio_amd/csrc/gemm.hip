@@ -48,7 +48,6 @@ struct GemmArgs {
   // columns of every head hold the 16 rotation pairs INTERLEAVED (pair i = columns 2i, 2i+1), so both members of a pair
   // sit in one lane; rope_tab [rope_rows][16][2] = (cos, sin) of pair i at position (logical row % rope_rows)
   const float* rope_tab; int rope_rows; int rope_cols;   // rope on columns [0, rope_cols)
-  int res_narrow;      // experiment (TA355_RES_WIDE=0): the bf16 residual in the accumulator layout instead of the store layout
   int group_m;         // tile-order group height (L2 reuse of W panels inside a group of M-tiles)
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
   int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
@@ -106,9 +105,6 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // the bf16 epilogue cost 14.5 us per round of 256 tiles vs 7.6 us of HBM time), so adjacent fragments are first
 // exchanged between lane rows with v_permlane16_swap: afterwards lane g holds 8 consecutive columns
 // (16 * (j + (g & 1)) + 8 * (g >> 1) ...) and one store covers 64 contiguous bytes per row.
-__device__ __forceinline__ unsigned add2bf(unsigned a, unsigned b) {      // two packed bf16 + two packed bf16, f32 adds, RNE
-  return pack2bf(__uint_as_float(a << 16) + __uint_as_float(b << 16), __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u));
-}
 // erf-GELU through the chord table of gelu_lut.h staged in LDS (`lut`): 3 VALU + 1 ds_read_b64 + 1 FMA per element instead of the
 // 13 VALU + v_rcp + v_exp of gelu_erf_fast.  Round 3: in the encoder's fc1 (M = 16000, N = 5120, K = 1280) the arithmetic form
 // cost ~25 k of the ~94 k cycles a CU spends per 256x320 tile -- un-overlapped VALU time in the epilogue.  |error| <= 2.5e-5.
@@ -165,13 +161,11 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       }
       if (HAS_RES) {
         if (p.res_bf16) {
-          // bf16 residual on the wide store path: added AFTER the lane exchange below, 16 B per lane (round 3); here only for the
-          // narrow path and the unpaired last fragment
-          if (!(OUT_BF16 && wide && !SWIGLU) || (j == NT - 1 && (NT & 1)) || p.res_narrow) {
-            const uint2 r = *(const uint2*)((const bf16_t*)p.res + roff + n);
-            v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
-            v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
-          }
+          // (Round 3: reading the residual in the STORE layout instead -- 16 B per lane after the lane exchange, bf16 + bf16 adds --
+          // measured 0.19 ms per step SLOWER, profiles/r03_g_ab_res_wide.txt, and made the rounding depend on the tile width; removed.)
+          const uint2 r = *(const uint2*)((const bf16_t*)p.res + roff + n);
+          v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+          v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
         } else {
           const float4 r = *(const float4*)(p.res + roff + n);
           v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
@@ -210,19 +204,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
       const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
       const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
-      if (col < p.N) {
-        uint4 y = make_uint4(a[0], b[0], a[1], b[1]);
-        if (HAS_RES && p.res_bf16 && !p.res_narrow) {
-          // The bf16 residual stream (x += A W^T + b of the frozen models): read here, in the store layout -- 8 consecutive columns
-          // = 16 B per lane, 64 contiguous bytes per row -- instead of 8 B per lane in the accumulator layout (16 rows x 32 B per
-          // load instruction: the request pattern the store-rate probe measured at half the 64-B rate; o_proj spent ~14 of its 73 us
-          // on it).  The sum is bf16(x + bf16(A W^T + b)): the two roundings of the reference's bf16 modules
-          // (TF:models/glmasr/modeling_glmasr.py:249-270, TF:models/qwen3/modeling_qwen3.py:283-324 with model_dtype bfloat16).
-          const uint4 r = *(const uint4*)((const bf16_t*)p.res + roff + col);
-          y.x = add2bf(y.x, r.x); y.y = add2bf(y.y, r.y); y.z = add2bf(y.z, r.z); y.w = add2bf(y.w, r.w);
-        }
-        *(uint4*)(Cb + (roff + col) * 2) = y;
-      }
+      if (col < p.N) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
     }
   }
 }
@@ -1620,8 +1602,6 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.dbg = d && *d ? atoi(d) : 0;
     const char* gl = getenv("TA355_GELU_LUT");            // 0 = arithmetic erf-GELU in the ping-pong kernel's epilogue (A/B, tests)
     if (gl && *gl == '0') a.dbg |= 8;
-    const char* rw = getenv("TA355_RES_WIDE");            // 0 = bf16 residual read 8 B per lane in the accumulator layout (A/B)
-    if (rw && *rw == '0') a.res_narrow = 1;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
   // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
@@ -1768,7 +1748,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows; a.rope_cols = o.rope_cols > 0 ? o.rope_cols : N;
   a.w_blocked = o.w_blocked ? 1 : 0;
   a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
-  a.dbg = 0; a.grp_n = 0; a.grp_w_stride = 0; a.res_narrow = 0;
+  a.dbg = 0; a.grp_n = 0; a.grp_w_stride = 0;
   if (a.lnf_mode) {
     const bool row_ok = a.lnf_mode == 1 && act != 0;
     const bool col_ok = a.lnf_mode == 2 && act == 0 && out_bf16 && !residual && (N % 4) == 0;
@@ -1831,7 +1811,7 @@ extern "C" int ta_gemm_bf16_nt_grouped(const void* A, const void* W, void* C, in
   a.a_plain = 1; a.c_plain = 1;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = nullptr; a.W2 = nullptr; a.K2 = 0; a.lda2 = 0; a.sw_gu = nullptr; a.sw_dgu = nullptr; a.res_bf16 = 0;
-  a.rope_tab = nullptr; a.rope_rows = 0; a.rope_cols = 0; a.res_narrow = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
+  a.rope_tab = nullptr; a.rope_rows = 0; a.rope_cols = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
   a.grp_n = n_groups; a.grp_w_stride = w_stride;
   a.splits = krange ? n_groups : 1;           // K-slice form: z = group, slabs c_stride apart
   a.slab_stride = krange ? c_stride : (long)M * N;
