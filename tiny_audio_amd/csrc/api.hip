@@ -627,8 +627,14 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1) -> int {
     RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, st));
-    RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
-    RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
+    static const bool dual = [] { const char* e = getenv("TA355_LORA_TN_DUAL"); return !(e && *e == '0'); }();
+    if (dual) {                                        // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
+      RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, s.dyB, members * r, dla, 1, in, w->lora_scale,
+                              0, 0, 0, M, st));
+    } else {
+      RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
+      RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
+    }
     kx = opts_kext(s.dyB, g.at);
     return TA_OK;
   };

@@ -61,14 +61,13 @@ __device__ __forceinline__ lbf16x4 tr_read(const bf16_t* p) {
 }
 typedef __attribute__((ext_vector_type(4))) float lf32x4;
 
-__global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
-                                                           int R, float* __restrict__ out, long so_c, long so_j, int M,
-                                                           float post, int r, int b0, int b1, int rows_per_chunk) {
-  __shared__ __attribute__((aligned(16))) bf16_t sx[32 * 256];
-  __shared__ __attribute__((aligned(16))) bf16_t sy[32 * 64];
+struct LoraTnArgs { const bf16_t* X; int Cn; const bf16_t* Y; int R; float* out; long so_c, so_j; float post; int r, b0, b1, rows, gx, gy; };
+__device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
+                                             int R, float* __restrict__ out, long so_c, long so_j, int M, float post, int r, int b0,
+                                             int b1, int rows_per_chunk, int bx, int by) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-  const int c0 = blockIdx.x * 256;
-  const int m_begin = blockIdx.y * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
+  const int c0 = bx * 256;
+  const int m_begin = by * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
   const int jblocks = R > 16 ? 2 : 1;
   lf32x4 acc[2][4];
 #pragma unroll
@@ -151,6 +150,27 @@ __global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restr
         }
       }
   }
+}
+
+__global__ __launch_bounds__(256) void lora_tn_mfma_kernel(const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
+                                                           int R, float* __restrict__ out, long so_c, long so_j, int M,
+                                                           float post, int r, int b0, int b1, int rows_per_chunk) {
+  __shared__ __attribute__((aligned(16))) bf16_t sx[32 * 256];
+  __shared__ __attribute__((aligned(16))) bf16_t sy[32 * 64];
+  lora_tn_body(sx, sy, X, Cn, Y, R, out, so_c, so_j, M, post, r, b0, b1, rows_per_chunk, blockIdx.x, blockIdx.y);
+}
+// Two TN products in ONE launch (round 3): the adapter gradients dB = dY^T xa and dA = s (dY B)^T x of a group are independent,
+// each alone is a 13-14 us launch that fills the chip badly (dA of the q|k|v group: 192 workgroups), and stage 2 issues 112 such
+// pairs per step.  Workgroups [0, n0) run problem 0, the rest problem 1.
+__global__ __launch_bounds__(256) void lora_tn_dual_kernel(const LoraTnArgs p0, const LoraTnArgs p1, int M) {
+  __shared__ __attribute__((aligned(16))) bf16_t sx[32 * 256];
+  __shared__ __attribute__((aligned(16))) bf16_t sy[32 * 64];
+  const int n0 = p0.gx * p0.gy;
+  int b = blockIdx.x;
+  const bool second = b >= n0;
+  const LoraTnArgs& p = second ? p1 : p0;
+  if (second) b -= n0;
+  lora_tn_body(sx, sy, p.X, p.Cn, p.Y, p.R, p.out, p.so_c, p.so_j, M, p.post, p.r, p.b0, p.b1, p.rows, b % p.gx, b / p.gx);
 }
 
 // out[M, 64] (bf16) = X[M, K] W[64, K]^T : the rank-space projections xa = x (sAcat)^T and dyB = dy Bext.
@@ -247,21 +267,37 @@ int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
+// rows per workgroup: every workgroup ends with 256 x R float atomics, so fewer, longer row chunks are better as long
+// as ~512 workgroups remain (Cn = 6144: 288 rows -> 22 x 24 workgroups and 2.1 M atomics instead of 4.7 M)
+static int lora_tn_rows(int M, int Cn) {
+  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
+  int rows = 128;
+  const long want = (long)M * ta_cdiv(Cn, 256) / 512;
+  if (want > rows) rows = (int)((want + 31) / 32 * 32);
+  if (rows_env > 0) rows = rows_env;
+  return rows;
+}
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
                         int r, int b0, int b1, hipStream_t st) {
   if (R > 32 || R <= 0 || ldy != 64 || Cn % 8) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  // rows per workgroup: every workgroup ends with 256 x R float atomics, so fewer, longer row chunks are better as long
-  // as ~512 workgroups remain (Cn = 6144: 288 rows -> 22 x 24 workgroups and 2.1 M atomics instead of 4.7 M)
-  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
-  int rows = 128;
-  {
-    const long want = (long)M * ta_cdiv(Cn, 256) / 512;
-    if (want > rows) rows = (int)((want + 31) / 32 * 32);
-    if (rows_env > 0) rows = rows_env;
-  }
+  const int rows = lora_tn_rows(M, Cn);
   TA_LAUNCH(lora_tn_mfma_kernel, dim3(ta_cdiv(Cn, 256), ta_cdiv(M, rows)), dim3(256), 0, st, (const bf16_t*)X, Cn, (const bf16_t*)Y,
             R, out, so_c, so_j, M, post, r, b0, b1, rows);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+// both adapter gradients of one group in one launch: problem 0 = (X0, Y0, ...), problem 1 likewise (same M)
+int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float* out0, long so_c0, long so_j0, float post0, int r0,
+                         int b00, int b10, const void* X1, int Cn1, const void* Y1, int R1, float* out1, long so_c1, long so_j1,
+                         float post1, int r1, int b01, int b11, int M, hipStream_t st) {
+  if (R0 > 32 || R0 <= 0 || R1 > 32 || R1 <= 0 || (Cn0 % 8) || (Cn1 % 8)) return TA_ERR_ARG;
+  if (M <= 0) return TA_OK;
+  LoraTnArgs p0 = {(const bf16_t*)X0, Cn0, (const bf16_t*)Y0, R0, out0, so_c0, so_j0, post0, r0, b00, b10, lora_tn_rows(M, Cn0), 0, 0};
+  LoraTnArgs p1 = {(const bf16_t*)X1, Cn1, (const bf16_t*)Y1, R1, out1, so_c1, so_j1, post1, r1, b01, b11, lora_tn_rows(M, Cn1), 0, 0};
+  p0.gx = ta_cdiv(Cn0, 256); p0.gy = ta_cdiv(M, p0.rows);
+  p1.gx = ta_cdiv(Cn1, 256); p1.gy = ta_cdiv(M, p1.rows);
+  TA_LAUNCH(lora_tn_dual_kernel, dim3(p0.gx * p0.gy + p1.gx * p1.gy), dim3(256), 0, st, p0, p1, M);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
