@@ -114,62 +114,86 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
   const float2 e = lut[(int)t];
   return fmaf(e.x, x, e.y);
 }
+// Round 3: the epilogue's loads are BATCHED.  The ISA of the r02 epilogue had an `s_waitcnt vmcnt(0)` behind every single load --
+// bias, residual, rope table, each behind its own per-fragment bounds branch -- i.e. up to 80 serialised memory round trips per
+// wave and tile; o_proj spent 35 of its 73 us outside the main loop.  Now (i) every load of a strip is unconditional (clamped
+// column, the value is simply not used out of range) and sits in one gather phase in front of the arithmetic, (ii) the bias of
+// the lane's NT column groups rides in the same batch (L1 hits; keeping it in registers across the strips spilled), and (iii) the
+// bf16 residual of strip i + 1 is requested before strip i is stored (EpiPre, filled by epilogue_tile): the residual stream aliases C, so the compiler may not hoist those loads itself.
+template <int NT> struct EpiPre { uint2 r[NT]; };
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
-                                               int m, const float* bias, const float2* lut = nullptr) {
+                                               int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
+                                               bool pre_r = false) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
   constexpr bool LNF_ROW = ACT == 3 || ACT == 4, LNF_COL = ACT == 5;
   constexpr bool SWIGLU = ACT == 6;                 // fused SwiGLU backward (ta_gemm_opts.swiglu_*), its own instantiation too
   constexpr int BASE = ACT == 3 ? 1 : (ACT == 4 ? 2 : ((ACT == 5 || ACT == 6) ? 0 : ACT));
+  // ---- gather phase: every load of the strip, unconditional (column clamped into the matrix)
+  float4 bq[NT], rt[NT], rf[NT], lc[NT], ls0[NT], ls1[NT];
+  uint2 rb[NT];
+  float2 lst = make_float2(1.f, 0.f); float lcm = 0.f;
+  if (LNF_ROW) lst = ((const float2*)p.lnf_stats)[m];
+  if (LNF_COL) lcm = p.lnf_c1[m];
+  const long rope_row = BASE == 2 ? (long)(m % p.rope_rows) * 16 : 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = nb + j * 16 + g * 4;
+    const int nn = n < p.N ? n : p.N - 4;          // (tiles are column-aligned to 4; out-of-range values are never stored)
+    if (LNF_ROW) lc[j] = *(const float4*)(p.lnf_c1 + nn);
+    if (LNF_COL) { ls0[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn); ls1[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn + 4); }
+    if (bias) bq[j] = *(const float4*)(bias + nn);
+    if (BASE == 2) {
+      const int pc = nn & 63;
+      rt[j] = *(const float4*)(p.rope_tab + (rope_row + (pc < 32 ? (pc >> 1) : 0)) * 2);   // c0 s0 c1 s1
+    }
+    if (HAS_RES) {
+      if (p.res_bf16) rb[j] = pre_r ? pre->r[j] : *(const uint2*)((const bf16_t*)p.res + roff + nn);
+      else rf[j] = *(const float4*)(p.res + roff + nn);
+    }
+  }
   uint2 o[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = nb + j * 16 + g * 4;
     const bool in = n < p.N;
     f32x4 v = acc[j];
-    if (in) {
-      if (LNF_ROW) {
-        const float2 st = ((const float2*)p.lnf_stats)[m];
-        const float4 c = *(const float4*)(p.lnf_c1 + n);
-        v[0] = v[0] * st.x + st.y * c.x; v[1] = v[1] * st.x + st.y * c.y;
-        v[2] = v[2] * st.x + st.y * c.z; v[3] = v[3] * st.x + st.y * c.w;
+    if (LNF_ROW) {
+      const float4 c = lc[j];
+      v[0] = v[0] * lst.x + lst.y * c.x; v[1] = v[1] * lst.x + lst.y * c.y;
+      v[2] = v[2] * lst.x + lst.y * c.z; v[3] = v[3] * lst.x + lst.y * c.w;
+    }
+    if (LNF_COL) {
+      const float4 s0 = ls0[j], s1 = ls1[j];
+      v[0] = v[0] * s0.x + s0.y * lcm; v[1] = v[1] * s0.z + s0.w * lcm;
+      v[2] = v[2] * s1.x + s1.y * lcm; v[3] = v[3] * s1.z + s1.w * lcm;
+    }
+    if (bias) { v[0] += bq[j].x; v[1] += bq[j].y; v[2] += bq[j].z; v[3] += bq[j].w; }
+    if (BASE == 1) {
+      if (lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
+      else { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]); }
+    }
+    if (BASE == 2) {
+      const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
+      if (pc < 32 && n < p.rope_cols) {
+        const float4 t = rt[j];
+        const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        v[0] = a0 * t.x - a1 * t.y; v[1] = a1 * t.x + a0 * t.y;
+        v[2] = a2 * t.z - a3 * t.w; v[3] = a3 * t.z + a2 * t.w;
       }
-      if (LNF_COL) {
-        const float4 s0 = *(const float4*)(p.lnf_stats + 2 * (long)n), s1 = *(const float4*)(p.lnf_stats + 2 * (long)n + 4);
-        const float c = p.lnf_c1[m];
-        v[0] = v[0] * s0.x + s0.y * c; v[1] = v[1] * s0.z + s0.w * c;
-        v[2] = v[2] * s1.x + s1.y * c; v[3] = v[3] * s1.z + s1.w * c;
-      }
-      if (bias) {
-        const float4 b = *(const float4*)(bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (BASE == 1) {
-        if (lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
-        else { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]); }
-      }
-      if (BASE == 2) {
-        const int pc = n & 63;                                   // column inside the head; the lane holds pairs pc/2, pc/2+1
-        if (pc < 32 && n < p.rope_cols) {
-          const float4 t = *(const float4*)(p.rope_tab + ((long)(m % p.rope_rows) * 16 + (pc >> 1)) * 2);   // c0 s0 c1 s1
-          const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-          v[0] = a0 * t.x - a1 * t.y; v[1] = a1 * t.x + a0 * t.y;
-          v[2] = a2 * t.z - a3 * t.w; v[3] = a3 * t.z + a2 * t.w;
-        }
-      }
-      if (HAS_RES) {
-        if (p.res_bf16) {
-          // (Round 3: reading the residual in the STORE layout instead -- 16 B per lane after the lane exchange, bf16 + bf16 adds --
-          // measured 0.19 ms per step SLOWER, profiles/r03_g_ab_res_wide.txt, and made the rounding depend on the tile width; removed.)
-          const uint2 r = *(const uint2*)((const bf16_t*)p.res + roff + n);
-          v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
-          v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
-        } else {
-          const float4 r = *(const float4*)(p.res + roff + n);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        }
+    }
+    if (HAS_RES) {
+      if (p.res_bf16) {
+        // (Round 3: reading the residual in the STORE layout instead -- 16 B per lane after the lane exchange, bf16 + bf16 adds --
+        // measured 0.19 ms per step SLOWER, profiles/r03_g_ab_res_wide.txt, and made the rounding depend on the tile width; removed.)
+        const uint2 r = rb[j];
+        v[0] += bf2f((bf16_t)(r.x & 0xffff)); v[1] += bf2f((bf16_t)(r.x >> 16));
+        v[2] += bf2f((bf16_t)(r.y & 0xffff)); v[3] += bf2f((bf16_t)(r.y >> 16));
+      } else {
+        const float4 r = rf[j];
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
     }
     if (SWIGLU) {
@@ -205,6 +229,45 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
       const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
       if (col < p.N) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
+    }
+  }
+}
+// The strips of one wave's part of a tile: rows ml0 + 16 i (i < MI); the bf16 residual is requested one strip ahead.
+// AHEAD = false (the 8-wave kernels at 256 VGPRs: the second residual strip in flight spilled into the main loop): each strip
+// gathers its own loads -- still ONE round trip per strip instead of one per fragment and operand.
+template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool AHEAD = false>
+__device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int Mact, int rbase, int nb,
+                                              int g, bool wide, const float* bias, const float2* lut) {
+  auto row_off = [&](int m) -> long {
+    return p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+  };
+  EpiPre<NT> pre;
+  int ncl[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = nb + j * 16 + g * 4;
+    ncl[j] = n < p.N ? n : p.N - 4;
+  }
+  const bool pre_r = AHEAD && HAS_RES && p.res_bf16;
+  uint2 nxt[NT];
+  auto fetch = [&](int i, uint2* dst) {                        // residual of strip i (rows past the tile's end: the last valid row)
+    int ml = ml0 + i * 16; if (ml >= Mact) ml = Mact - 1;
+    const long ro = row_off(rbase + ml);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) dst[j] = *(const uint2*)((const bf16_t*)p.res + ro + ncl[j]);
+  };
+  if (pre_r) fetch(0, pre.r);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    if (pre_r && i + 1 < MI) fetch(i + 1, nxt);
+    const int ml = ml0 + i * 16;
+    if (ml < Mact) {
+      const int m = rbase + ml;
+      epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, &pre, pre_r);
+    }
+    if (pre_r && i + 1 < MI) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) pre.r[j] = nxt[j];
     }
   }
 }
@@ -377,14 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, false);       // the K loop ended with a barrier
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int ml = m0 + wm * WR + i * 16 + l15;
-    if (ml >= Mact) continue;
-    const int m = rbase + ml;
-    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp, lut);
-  }
+  epilogue_tile<MI, 4, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * WR + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);
 }
 
 // ============================================================================ v2: 256-row tiles, 8 waves, 1 WG / CU
@@ -619,14 +675,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ml = m0 + wm * 128 + i * 16 + l15;
-    if (ml >= Mact) continue;
-    const int m = rbase + ml;
-    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp, lut);
-  }
+  epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
   if (life) {                                   // behind the C matrix: [workgroup][wave group] x {5 stamps, HW_ID, XCC_ID, tile}
     lf[3] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -870,16 +919,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       char* Cb = (char*)p.C;
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
-      {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int ml = cur.m0 + e_wm * (BM2 / 2) + i * 16 + e_l15;
-          if (ml >= cur.Mact) continue;
-          const int m = cur.rbase + ml;
-          const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-          epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, cur.n0 + e_wn * (BN2 / 4), e_g, wide, m, cur.biasp, lut);
-        }
-      }
+      epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, cur.m0 + e_wm * (BM2 / 2) + e_l15, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
+                                                     wide, cur.biasp, lut);
     }
     if (LIFE) {
       lf[4] = __builtin_amdgcn_s_memtime();
@@ -1059,14 +1100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
   }
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ml = m0 + wm * 128 + i * 16 + l15;
-    if (ml >= Mact) continue;
-    const int m = rbase + ml;
-    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * (BN2 / 4), g, wide, m, biasp, lut);
-  }
+  epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
 }
 
 // out[i] = (add ? add[i] : 0) + sum_z slab[z][i]  (f32 and/or bf16 out; add may alias out); n4 = count / 4
@@ -1282,14 +1316,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   }
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, true);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int ml = m0 + wm * 96 + i * 16 + l15;
-    if (ml >= Mact) continue;
-    const int m = rbase + ml;
-    const long roff = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
-    epilogue_strip<4, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, roff, n0 + wn * 64, g, wide, m, biasp, lut);
-  }
+  epilogue_tile<6, 4, ACT, OUT_BF16, HAS_RES, true>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);   // one wave per SIMD: registers to spare
 }
 
 // ============================================================================ v6: v5 on v_mfma_f32_32x32x16_bf16
