@@ -516,6 +516,31 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
   }   // pass
 }
 
+// ---- round 3: global -> LDS DMA staging of [64][128] row tiles for the backward (double-buffered LDS, no staging registers).
+// Inline assembly: behind the builtin the compiler drains vmcnt in front of every later transposing LDS read (it tracks the DMA as
+// an LDS store that may alias them), which would wait for the NEXT tile right after issuing it.  Every wait for these loads is the
+// explicit s_waitcnt vmcnt(0) at the top of an iteration.  `lds` = wave-uniform LDS byte address, the hardware adds lane * 16.
+__device__ __forceinline__ void dma16_asm(const void* g, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
+}
+// rows row0 .. row0 + 63 (clamped to nrows - 1) of a [.., 128] bf16 matrix with `row_stride` elements per row -> the RowTile<128>
+// image at `lds_tile`: one wave instruction covers 4 rows x 256 B, wave w of 4 moves row blocks w, w + 4, w + 8, w + 12; the XOR
+// swizzle of the image is applied to the SOURCE chunk (the LDS side of the DMA is lane-linear).
+__device__ __forceinline__ void dma_rowtile128(const bf16_t* base, long row_stride, int row0, int nrows, unsigned lds_tile, int wave,
+                                               int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int blk = wave + 4 * i, r = blk * 4 + (lane >> 4);
+    int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; if (gr < 0) gr = 0;
+    const int c = (lane & 15) ^ RowTile<128>::swz(r);
+    dma16_asm(base + (long)gr * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + blk * 1024));   // (wave-uniform by construction)
+  }
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p);
+}
+constexpr int BWD_BUF = 2 * 64 * 128 * 2 + 512;      // one staging buffer of the backward: two row tiles + 128 floats / ints
+
 // ============================================================================ forward, short sequences, straight from the q|k|v GEMM output
 // attn_fwd_gqa_kernel with ta_lm_qkv_post_fwd folded in: one workgroup = one (clip, kv head) reads the PRE-norm q | k | v rows of its
 // GQA group from the token-major GEMM output, applies the per-head RMSNorm (q_norm / k_norm) and RoPE while staging
@@ -546,32 +571,54 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   const long ld = (long)(Hq + 2 * Hkv) * HD;
   const float sl2 = scale * LOG2E;
   const int ntiles = (L + KV_TILE - 1) / KV_TILE;
-  // ---- stage K and V once: all global loads first, then the per-row work (PER chunks of K and of V per thread)
+  // ---- stage K and V once (round 3): the PRE-norm K rows and the V rows travel global -> LDS by DMA straight into the swizzled
+  // row tiles (no staging registers: the r02 form held 64 VGPRs of chunks across the whole pass and spilled), K is then
+  // normalised and rotated IN PLACE in LDS, with the cos / sin rows of the next pass requested while the current one is
+  // computed.  (The r02 form also sat behind an s_waitcnt per 16-B load: each load lived under its own bounds branch.)
   constexpr int PER = (MAXT * 64 * (HD / 8) + NT_ - 1) / NT_;
-  uint4 kreg[PER], vreg[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
-    if (t < ntiles) {
-      const int r = w / (HD / 8), c = w % (HD / 8);
+  {
+    const unsigned ldsK = lds_addr_of(Ks), ldsV = lds_addr_of(Vs);
+    const bf16_t* kbase = qkv0 + (long)b * L * ld + (long)(Hq + hk) * HD;
+    const bf16_t* vbase = kbase + (long)Hkv * HD;
+    // 16 row blocks of 4 rows per tile, MAXT tiles; wave w moves blocks w, w + NW, ... (a block = one 1-KB DMA instruction)
+    for (int blk = wave; blk < ntiles * 16; blk += NW) {
+      const int t = blk >> 4, rb4 = (blk & 15) * 4, r = rb4 + (lane >> 4);
       int gr = t * KV_TILE + r; if (gr > L - 1) gr = L - 1;
-      const bf16_t* row = qkv0 + ((long)b * L + gr) * ld;
-      kreg[i] = *(const uint4*)(row + (long)(Hq + hk) * HD + c * 8);
-      vreg[i] = *(const uint4*)(row + (long)(Hq + Hkv + hk) * HD + c * 8);
+      const int c = (lane & 15) ^ RowTile<HD>::swz(r);
+      const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(t * RowTile<HD>::BYTES + rb4 * 256));
+      dma16_asm(kbase + (long)gr * ld + c * 8, ldsK + off);
+      dma16_asm(vbase + (long)gr * ld + c * 8, ldsV + off);
     }
   }
   {
     const int c = tid & 15;                           // NT_ is a multiple of 16: a thread keeps its chunk column in every pass
     const float4 wa = *(const float4*)(kn_w + c * 8), wb = *(const float4*)(kn_w + c * 8 + 4);
     const float wk[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+    float4 cc[2][4];                                  // cos | sin rows of the current and the next pass
+    auto rope_rows = [&](int i, float4* dst) {
+      const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+      const int krow = t * KV_TILE + w / (HD / 8), gr = krow > L - 1 ? L - 1 : krow;
+      const int pp = pos ? pos[(long)b * L + gr] : gr;
+      const float* cp = cosT + (long)pp * 64 + (c & 7) * 8;
+      const float* sp = sinT + (long)pp * 64 + (c & 7) * 8;
+      dst[0] = *(const float4*)cp; dst[1] = *(const float4*)(cp + 4); dst[2] = *(const float4*)sp; dst[3] = *(const float4*)(sp + 4);
+    };
+    rope_rows(0, cc[0]);
+    for (int i = tid; i < ntiles * 64; i += NT_) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA instructions (and the loads above) have landed
+    __syncthreads();                                  // ... everyone's
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
+      if (i + 1 < PER) rope_rows(i + 1, cc[(i + 1) & 1]);
       if (t < ntiles) {                               // whole 16-lane rows take the same branch
         const int r = w / (HD / 8);
         const int krow = t * KV_TILE + r, gr = krow > L - 1 ? L - 1 : krow;
         const long tok = (long)b * L + gr;
-        const uint32_t u[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+        char* kp = Ks + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c);
+        const uint4 kin = *(const uint4*)kp;
+        const uint4 vin = *(const uint4*)(Vs + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c));
+        const uint32_t u[4] = {kin.x, kin.y, kin.z, kin.w};
         float x[8], ss = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { x[2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); x[2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
@@ -579,10 +626,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
         for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
         ss = row_sum16(ss);
         const float rr = rsqrtf(ss / (float)HD + eps);
-        const int p = pos ? pos[tok] : gr;
-        const float4 c0 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8), c1 = *(const float4*)(cosT + (long)p * 64 + (c & 7) * 8 + 4);
-        const float4 s0 = *(const float4*)(sinT + (long)p * 64 + (c & 7) * 8), s1 = *(const float4*)(sinT + (long)p * 64 + (c & 7) * 8 + 4);
-        const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float4* q4 = cc[i & 1];
+        const float cs[8] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w};
+        const float sn[8] = {q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
         float y[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -591,17 +637,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
           y[e] = c < 8 ? n * cs[e] - np * sn[e] : n * cs[e] + np * sn[e];
         }
         const uint4 kv = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
-        *(uint4*)(Ks + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c)) = kv;
-        *(uint4*)(Vs + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c)) = vreg[i];
+        *(uint4*)kp = kv;                             // in place: this thread is the only reader and writer of its chunk
         if (krow < L) {
           *(uint4*)(Ko + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = kv;
-          *(uint4*)(Vo + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = vreg[i];
+          *(uint4*)(Vo + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = vin;
           if (c == 0) rk[tok * Hkv + hk] = rr;
         }
       }
     }
   }
-  for (int i = tid; i < ntiles * 64; i += NT_) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
   __syncthreads();
   const bf16x8 ones = (bf16x8){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 zeros = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -612,16 +656,28 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   const int h = hk * grp + chunk / cph;
   const int q0 = (chunk % cph) * 16 * QSUB;
   bf16x8 qf[QSUB][HD / 32];
+  // (Round 3: the loads of a query sub-tile -- its 4 row chunks and the cos / sin rows of both dim halves -- are issued as ONE batch;
+  // the r02 form waited for the row, then per dim half for eight dependent table loads.)
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
     const int qrow = q0 + sub * 16 + l15, qr = qrow > L - 1 ? L - 1 : qrow;
     const long tok = (long)b * L + qr;
     const bf16_t* src = qkv0 + tok * ld + (long)h * HD;
+    const int p = pos ? pos[tok] : qr;
+    uint4 raw[HD / 32];
+    float4 tc[2][2], ts[2][2];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) raw[ks] = *(const uint4*)(src + ks * 32 + g * 8);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      tc[ks][0] = *(const float4*)(cosT + (long)p * 64 + d0); tc[ks][1] = *(const float4*)(cosT + (long)p * 64 + d0 + 4);
+      ts[ks][0] = *(const float4*)(sinT + (long)p * 64 + d0); ts[ks][1] = *(const float4*)(sinT + (long)p * 64 + d0 + 4);
+    }
     float x[HD / 32][8], ss = 0.f;
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) {
-      const uint4 v = *(const uint4*)(src + ks * 32 + g * 8);
-      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t u[4] = {raw[ks].x, raw[ks].y, raw[ks].z, raw[ks].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) { x[ks][2 * k] = bf2f((bf16_t)(u[k] & 0xffff)); x[ks][2 * k + 1] = bf2f((bf16_t)(u[k] >> 16)); }
 #pragma unroll
@@ -629,12 +685,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
     }
     ss = group_sum(ss);
     const float rr = rsqrtf(ss / (float)HD + eps);
-    const int p = pos ? pos[tok] : qr;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                   // dims d = ks * 32 + g * 8 + e < 64 and their partners d + 64 (fragment ks + 2)
       const int d0 = ks * 32 + g * 8;
-      const float4 c0 = *(const float4*)(cosT + (long)p * 64 + d0), c1 = *(const float4*)(cosT + (long)p * 64 + d0 + 4);
-      const float4 s0 = *(const float4*)(sinT + (long)p * 64 + d0), s1 = *(const float4*)(sinT + (long)p * 64 + d0 + 4);
+      const float4 c0 = tc[ks][0], c1 = tc[ks][1], s0 = ts[ks][0], s1 = ts[ks][1];
       const float4 wa = *(const float4*)(qn_w + d0), wb = *(const float4*)(qn_w + d0 + 4);
       const float4 wc = *(const float4*)(qn_w + 64 + d0), wd = *(const float4*)(qn_w + 64 + d0 + 4);
       const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -843,30 +897,6 @@ __device__ __forceinline__ void qkv_post_bwd_tile(const char* st, const QkvPostB
   }
 }
 
-// ---- round 3: global -> LDS DMA staging of [64][128] row tiles for the backward (double-buffered LDS, no staging registers).
-// Inline assembly: behind the builtin the compiler drains vmcnt in front of every later transposing LDS read (it tracks the DMA as
-// an LDS store that may alias them), which would wait for the NEXT tile right after issuing it.  Every wait for these loads is the
-// explicit s_waitcnt vmcnt(0) at the top of an iteration.  `lds` = wave-uniform LDS byte address, the hardware adds lane * 16.
-__device__ __forceinline__ void dma16_asm(const void* g, unsigned lds) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(g) : "memory");
-}
-// rows row0 .. row0 + 63 (clamped to nrows - 1) of a [.., 128] bf16 matrix with `row_stride` elements per row -> the RowTile<128>
-// image at `lds_tile`: one wave instruction covers 4 rows x 256 B, wave w of 4 moves row blocks w, w + 4, w + 8, w + 12; the XOR
-// swizzle of the image is applied to the SOURCE chunk (the LDS side of the DMA is lane-linear).
-__device__ __forceinline__ void dma_rowtile128(const bf16_t* base, long row_stride, int row0, int nrows, unsigned lds_tile, int wave,
-                                               int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int blk = wave + 4 * i, r = blk * 4 + (lane >> 4);
-    int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; if (gr < 0) gr = 0;
-    const int c = (lane & 15) ^ RowTile<128>::swz(r);
-    dma16_asm(base + (long)gr * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + blk * 1024));   // (wave-uniform by construction)
-  }
-}
-__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
-  return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p);
-}
-constexpr int BWD_BUF = 2 * 64 * 128 * 2 + 512;      // one staging buffer of the backward: two row tiles + 128 floats / ints
 
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
