@@ -73,48 +73,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // bf16 -> bf16 LayerNorm with 16-byte accesses: HALF a wave per row (32 lanes x NCH chunks of 8 columns, H = 256 * NCH),
 // two rows per wave, eight per workgroup.  The encoder's two LayerNorms per layer read and write the bf16 residual stream
 // (82 MB per call at B = 32): halving the number of memory instructions per byte is what this variant is for.
-template <int NCH>
+// Round 3: a half wave walks ROWS rows and keeps its gamma / beta columns in registers.  With one row per half wave every
+// lane re-read 8 x NCH floats of gamma and of beta per row from L1 -- 4x the bytes of the row itself (20 KB of L1 reads per
+// 2.5-KB row at H = 1280: ~8 of the kernel's 16 us at 64 B/clk/CU); the next row's chunks are requested before the current
+// row's arithmetic.
+template <int NCH, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ b, bf16_t* __restrict__ y,
                                                                const float* __restrict__ rowscale, int M, float eps) {
   constexpr int H = NCH * 256;
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (row >= M) return;
   const int l = threadIdx.x & 31;
-  const uint4* xr = (const uint4*)(x + (long)row * H);
-  float v[NCH][8];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const uint4 u = xr[l + i * 32];
-    const uint32_t q[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[i][2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[i][2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); s += v[i][2 * j] + v[i][2 * j + 1]; }
-  }
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);          // lanes 0-31 / 32-63 reduce separately
-  const float mean = s / (float)H;
-  float q2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q2 += d * d; }
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
-  const float rstd = rsqrtf(q2 / (float)H + eps);
-  const float rs = rowscale ? rowscale[row] : 1.0f;
-  uint4* yr = (uint4*)(y + (long)row * H);
+  const int row0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * ROWS;
+  if (row0 >= M) return;
+  float ww[NCH][8], bb[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (l + i * 32) * 8;
     const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + c + 4);
     const float4 b0 = *(const float4*)(b + c), b1 = *(const float4*)(b + c + 4);
-    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float o[8];
+    ww[i][0] = w0.x; ww[i][1] = w0.y; ww[i][2] = w0.z; ww[i][3] = w0.w; ww[i][4] = w1.x; ww[i][5] = w1.y; ww[i][6] = w1.z; ww[i][7] = w1.w;
+    bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+  }
+  uint4 nx[NCH];
+  {
+    const uint4* xr = (const uint4*)(x + (long)row0 * H);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = ((v[i][j] - mean) * rstd * ww[j] + bb[j]) * rs;
-    yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    for (int i = 0; i < NCH; ++i) nx[i] = xr[l + i * 32];
+  }
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;                               // (uniform per half wave: the shuffles below stay inside it)
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const uint32_t q[4] = {nx[i].x, nx[i].y, nx[i].z, nx[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[i][2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); s += v[i][2 * j] + v[i][2 * j + 1]; }
+    }
+    if (rr + 1 < ROWS && row + 1 < M) {
+      const uint4* xr = (const uint4*)(x + (long)(row + 1) * H);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) nx[i] = xr[l + i * 32];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);          // lanes 0-31 / 32-63 reduce separately
+    const float mean = s / (float)H;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q2 += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+    const float rstd = rsqrtf(q2 / (float)H + eps);
+    const float rs = rowscale ? rowscale[row] : 1.0f;
+    uint4* yr = (uint4*)(y + (long)row * H);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = ((v[i][j] - mean) * rstd * ww[i][j] + bb[i][j]) * rs;
+      yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    }
   }
 }
 
@@ -295,9 +317,14 @@ extern "C" int ta_layernorm_bf16(const void* x_bf16, const float* w, const float
   // bf16 -> bf16 only, H a multiple of 256 up to 2048: the 16-byte half-wave-per-row variant (TA355_LN_WIDE=0: the generic one)
   static const bool ln_wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
   if (ln_wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
-    dim3 g8(ta_cdiv(M, 8));
+    // rows per half wave: 4 once that still leaves >= 2 workgroups per CU (M = 16000 at B = 32: 500), else 1; TA355_LN_ROWS=1|2|4
+    static const int rows_env = [] { const char* e = getenv("TA355_LN_ROWS"); return e && *e ? atoi(e) : 0; }();
+    const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M >= 8 * 4 * 512 ? 4 : (M >= 8 * 2 * 512 ? 2 : 1));
+    dim3 g8(ta_cdiv(M, 8 * rows));
     switch (H / 256) {
-#define LNW(N) case N: TA_LAUNCH((layernorm_bf16x8_kernel<N>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); break;
+#define LNW(N) case N: if (rows == 4) TA_LAUNCH((layernorm_bf16x8_kernel<N, 4>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
+               else if (rows == 2) TA_LAUNCH((layernorm_bf16x8_kernel<N, 2>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
+               else TA_LAUNCH((layernorm_bf16x8_kernel<N, 1>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); break;
       LNW(1) LNW(2) LNW(3) LNW(4) LNW(5) LNW(6) LNW(7) LNW(8)
 #undef LNW
     }
