@@ -233,41 +233,58 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
   }
 }
 // The strips of one wave's part of a tile: rows ml0 + 16 i (i < MI); the bf16 residual is requested one strip ahead.
-// AHEAD = false (the 8-wave kernels at 256 VGPRs: the second residual strip in flight spilled into the main loop): each strip
-// gathers its own loads -- still ONE round trip per strip instead of one per fragment and operand.
-template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool AHEAD = false>
+// AHEAD: how the bf16 residual (which aliases C, so the compiler cannot move its loads over the stores) is requested.
+//   0  every strip gathers its own loads: ONE round trip per strip (instead of one per fragment and operand in r02)
+//   1  strips in PAIRS: the residual of strips i and i + 1 in one batch (4 round trips per 8 strips; +NT registers)
+//   2  one strip ahead (the one-wave-per-SIMD kernel: registers to spare; in the 8-wave kernels at 256 VGPRs this form spilled
+//      into the main loop)
+template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0>
 __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int Mact, int rbase, int nb,
                                               int g, bool wide, const float* bias, const float2* lut) {
   auto row_off = [&](int m) -> long {
     return p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
   };
-  EpiPre<NT> pre;
   int ncl[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = nb + j * 16 + g * 4;
     ncl[j] = n < p.N ? n : p.N - 4;
   }
-  const bool pre_r = AHEAD && HAS_RES && p.res_bf16;
-  uint2 nxt[NT];
+  const bool pre_r = AHEAD > 0 && HAS_RES && p.res_bf16;
   auto fetch = [&](int i, uint2* dst) {                        // residual of strip i (rows past the tile's end: the last valid row)
     int ml = ml0 + i * 16; if (ml >= Mact) ml = Mact - 1;
     const long ro = row_off(rbase + ml);
 #pragma unroll
     for (int j = 0; j < NT; ++j) dst[j] = *(const uint2*)((const bf16_t*)p.res + ro + ncl[j]);
   };
-  if (pre_r) fetch(0, pre.r);
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    if (pre_r && i + 1 < MI) fetch(i + 1, nxt);
+  auto strip = [&](int i, const EpiPre<NT>* pre) {
     const int ml = ml0 + i * 16;
     if (ml < Mact) {
       const int m = rbase + ml;
-      epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, &pre, pre_r);
+      epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r);
     }
-    if (pre_r && i + 1 < MI) {
+  };
+  if constexpr (AHEAD == 1) {
+    static_assert(MI % 2 == 0, "pairs of strips");
 #pragma unroll
-      for (int j = 0; j < NT; ++j) pre.r[j] = nxt[j];
+    for (int i = 0; i < MI; i += 2) {
+      EpiPre<NT> p0, p1;
+      if (pre_r) { fetch(i, p0.r); fetch(i + 1, p1.r); }
+      strip(i, &p0);
+      strip(i + 1, &p1);
+    }
+  } else {
+    EpiPre<NT> pre;
+    uint2 nxt[NT];
+    if (pre_r) fetch(0, pre.r);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (pre_r && i + 1 < MI) fetch(i + 1, nxt);
+      strip(i, &pre);
+      if (pre_r && i + 1 < MI) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) pre.r[j] = nxt[j];
+      }
     }
   }
 }
@@ -919,7 +936,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       char* Cb = (char*)p.C;
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
-      epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, cur.m0 + e_wm * (BM2 / 2) + e_l15, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
+      epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, (BM2 == 192 ? 1 : 0)>(acc, p, Cb, cur.m0 + e_wm * (BM2 / 2) + e_l15, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
                                                      wide, cur.biasp, lut);
     }
     if (LIFE) {
@@ -1316,7 +1333,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   }
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, true);
-  epilogue_tile<6, 4, ACT, OUT_BF16, HAS_RES, true>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);   // one wave per SIMD: registers to spare
+  epilogue_tile<6, 4, ACT, OUT_BF16, HAS_RES, 2>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);   // one wave per SIMD: registers to spare
 }
 
 // ============================================================================ v6: v5 on v_mfma_f32_32x32x16_bf16

@@ -317,9 +317,10 @@ extern "C" int ta_layernorm_bf16(const void* x_bf16, const float* w, const float
   // bf16 -> bf16 only, H a multiple of 256 up to 2048: the 16-byte half-wave-per-row variant (TA355_LN_WIDE=0: the generic one)
   static const bool ln_wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
   if (ln_wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
-    // rows per half wave: 4 once that still leaves >= 2 workgroups per CU (M = 16000 at B = 32: 500), else 1; TA355_LN_ROWS=1|2|4
+    // rows per half wave: 4 once that still leaves >= 1 workgroup per CU (M = 16000 at B = 32: 500 workgroups; measured 41.62 /
+    // 41.63 / 41.88 ms per step at 4 / 2 / 1, profiles/r03_k_ab_ln_rows.txt), 2 from 4096 rows, else 1; TA355_LN_ROWS=1|2|4
     static const int rows_env = [] { const char* e = getenv("TA355_LN_ROWS"); return e && *e ? atoi(e) : 0; }();
-    const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M >= 8 * 4 * 512 ? 4 : (M >= 8 * 2 * 512 ? 2 : 1));
+    const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M >= 8 * 4 * 256 ? 4 : (M >= 8 * 2 * 256 ? 2 : 1));
     dim3 g8(ta_cdiv(M, 8 * rows));
     switch (H / 256) {
 #define LNW(N) case N: if (rows == 4) TA_LAUNCH((layernorm_bf16x8_kernel<N, 4>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
