@@ -120,11 +120,16 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 // column, the value is simply not used out of range) and sits in one gather phase in front of the arithmetic, (ii) the bias of
 // the lane's NT column groups rides in the same batch (L1 hits; keeping it in registers across the strips spilled), and (iii) the
 // bf16 residual of strip i + 1 is requested before strip i is stored (EpiPre, filled by epilogue_tile): the residual stream aliases C, so the compiler may not hoist those loads itself.
+// (iv) ELS (the persistent ping-pong kernel): the tile's bias row and its rows of the rope table were DMA'd into the idle LDS
+// stage during the LAST K tile of the main loop (EPI_LDS_* below), so the strip reads them with ds_read_b128 and -- with the bf16
+// residual taken as the accumulators' start value -- the encoder's epilogues wait for no global load at all.
+#define EPI_LDS_BIAS 0        /* float[BN2]: the tile's bias columns (clamped into the matrix) */
+#define EPI_LDS_TAB 2048      /* GELU: the chord table (8 KB); rope: BM2 rows x 128 B, 16-B chunk c of local row r at slot c ^ (r & 7) */
 template <int NT> struct EpiPre { uint2 r[NT]; };
-template <int NT, int ACT, bool OUT_BF16, bool HAS_RES>
+template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
                                                int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
-                                               bool pre_r = false) {
+                                               bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
@@ -144,10 +149,11 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     const int nn = n < p.N ? n : p.N - 4;          // (tiles are column-aligned to 4; out-of-range values are never stored)
     if (LNF_ROW) lc[j] = *(const float4*)(p.lnf_c1 + nn);
     if (LNF_COL) { ls0[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn); ls1[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn + 4); }
-    if (bias) bq[j] = *(const float4*)(bias + nn);
+    if (bias) bq[j] = ELS ? *(const float4*)(els + EPI_LDS_BIAS + (nn - ecol0) * 4) : *(const float4*)(bias + nn);
     if (BASE == 2) {
       const int pc = nn & 63;
-      rt[j] = *(const float4*)(p.rope_tab + (rope_row + (pc < 32 ? (pc >> 1) : 0)) * 2);   // c0 s0 c1 s1
+      if (ELS) rt[j] = *(const float4*)(els + EPI_LDS_TAB + erow * 128 + ((((pc < 32 ? pc : 0) >> 2) ^ (erow & 7)) << 4));
+      else rt[j] = *(const float4*)(p.rope_tab + (rope_row + (pc < 32 ? (pc >> 1) : 0)) * 2);   // c0 s0 c1 s1
     }
     if (HAS_RES) {
       if (p.res_bf16) rb[j] = pre_r ? pre->r[j] : *(const uint2*)((const bf16_t*)p.res + roff + nn);
@@ -238,9 +244,10 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 //   1  strips in PAIRS: the residual of strips i and i + 1 in one batch (4 round trips per 8 strips; +NT registers)
 //   2  one strip ahead (the one-wave-per-SIMD kernel: registers to spare; in the 8-wave kernels at 256 VGPRs this form spilled
 //      into the main loop)
-template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0>
+template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0, bool ELS = false>
 __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int Mact, int rbase, int nb,
-                                              int g, bool wide, const float* bias, const float2* lut) {
+                                              int g, bool wide, const float* bias, const float2* lut, const char* els = nullptr,
+                                              int ecol0 = 0, int erow0 = 0) {
   auto row_off = [&](int m) -> long {
     return p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
   };
@@ -261,7 +268,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
     const int ml = ml0 + i * 16;
     if (ml < Mact) {
       const int m = rbase + ml;
-      epilogue_strip<NT, ACT, OUT_BF16, HAS_RES>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r);
+      epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r, els, ecol0, erow0 + i * 16);
     }
   };
   if constexpr (AHEAD == 1) {
@@ -287,6 +294,50 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
       }
     }
   }
+}
+// A plain bf16 residual (ACT 0: x += A W^T + b, the encoder's o_proj / fc2 and the LM's o / down products) is the START VALUE of
+// the accumulators in EVERY tile variant, not an addend of the epilogue: the sum is then fl(..fl(fl(r + a0 w0) + a1 w1)..) + b
+// whatever tile the launch-time model picks (the B = 32 step and the same clips at B = 4 run different variants and are compared
+// in the tests), and the kernels' epilogues have no residual load left to wait for.  Loads in batches of <= 4 strips.
+// TA355_GEMM_RES_INIT=0 (p.dbg bit 4): the r02 form, residual added in the epilogue.
+template <int ACT, bool OUT_BF16, bool HAS_RES>
+__device__ __forceinline__ bool residual_is_start(const GemmArgs& p) {
+  return HAS_RES && ACT == 0 && OUT_BF16 && p.res_bf16 && p.splits == 1 && !(p.dbg & 16);
+}
+template <int MI, int NT>
+__device__ __forceinline__ void residual_start(f32x4 (*acc)[NT], const GemmArgs& p, int ml0, int Mact, int rbase, int nb, int g) {
+  int ncl[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { const int n = nb + j * 16 + g * 4; ncl[j] = n < p.N ? n : p.N - 4; }
+  constexpr int HB = MI > 4 ? (MI + 1) / 2 : MI;
+#pragma unroll
+  for (int i0 = 0; i0 < MI; i0 += HB) {
+    uint2 t[HB][NT];
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+      if (i0 + i < MI) {
+        const int m = rbase + min(ml0 + (i0 + i) * 16, Mact - 1);
+        const long ro = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) t[i][j] = *(const uint2*)((const bf16_t*)p.res + ro + ncl[j]);
+      }
+#pragma unroll
+    for (int i = 0; i < HB; ++i)
+      if (i0 + i < MI) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const uint2 r = t[i][j];
+          acc[i0 + i][j] = (f32x4){bf2f((bf16_t)(r.x & 0xffff)), bf2f((bf16_t)(r.x >> 16)), bf2f((bf16_t)(r.y & 0xffff)), bf2f((bf16_t)(r.y >> 16))};
+        }
+      }
+  }
+}
+template <int MI, int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (*acc)[NT]) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 // Every tile variant evaluates GELU through the same chord table (a GEMM's result must not depend on the tile the launch-time
 // model picks: the B = 32 step and the same clips at B = 4 run different variants and are compared in the tests).  `smem` must be
@@ -399,10 +450,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int koff1 = ((4 + g) ^ swz) << 4;
 
   f32x4 acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool res_init = residual_is_start<ACT, OUT_BF16, HAS_RES>(p);
+  if (res_init) residual_start<MI, 4>(acc, p, m0 + wm * WR + l15, Mact, rbase, n0 + wn * 64, g);
+  else zero_acc<MI, 4>(acc);
 
   int next_tile = kt_begin;
   auto stage = [&](int buf) {
@@ -457,7 +507,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, false);       // the K loop ended with a barrier
-  epilogue_tile<MI, 4, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * WR + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);
+  if (res_init) epilogue_tile<MI, 4, ACT, OUT_BF16, false>(acc, p, Cb, m0 + wm * WR + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);
+  else epilogue_tile<MI, 4, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * WR + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);
 }
 
 // ============================================================================ v2: 256-row tiles, 8 waves, 1 WG / CU
@@ -555,10 +606,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   const int koff1 = ((4 + g) ^ swz) << 4;
 
   f32x4 acc[8][NT];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool res_init = residual_is_start<ACT, OUT_BF16, HAS_RES>(p);
+  if (res_init) residual_start<8, NT>(acc, p, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g);
+  else zero_acc<8, NT>(acc);
 
   auto dma_a = [&](char* base, int i) { glds16(a_src[i], base + i * 8192); a_src[i] += BK * 2; };
   auto dma_w = [&](char* base, int i) { glds16(w_src[i], base + A_BYTES + i * 8192); w_src[i] += w_step; };
@@ -692,7 +742,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs p) {
   if (p.splits > 1) Cb += (long)z * p.slab_stride * 4;
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
-  epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
+  if (res_init) epilogue_tile<8, NT, ACT, OUT_BF16, false>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
+  else epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
   if (life) {                                   // behind the C matrix: [workgroup][wave group] x {5 stamps, HW_ID, XCC_ID, tile}
     lf[3] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -756,6 +807,10 @@ __device__ __forceinline__ TileCtx tile_ctx(const GemmArgs& p, int h, int total)
   if (p.dbg & 2) c.ke = min(c.ke, c.kb + 1);
   c.Mact = p.M; c.rbase = 0;
   if (segp) { c.rbase = segp[0]; c.Mact = segp[1]; if (c.m0 >= c.Mact) return c; }
+  // wave-uniform by construction; values that came through a vector load (segment / K-range tables) are marked as such, so the K
+  // loop's control and the stage parity derived from it stay in SGPRs
+  c.kb = __builtin_amdgcn_readfirstlane(c.kb); c.ke = __builtin_amdgcn_readfirstlane(c.ke);
+  c.rbase = __builtin_amdgcn_readfirstlane(c.rbase); c.Mact = __builtin_amdgcn_readfirstlane(c.Mact);
   c.ok = 1;
   return c;
 }
@@ -793,6 +848,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   const int koff0 = ((0 + g) ^ swz) << 4;
   const int koff1 = ((4 + g) ^ swz) << 4;
   const int lag = __builtin_amdgcn_readfirstlane(wm);
+  // The thread index, re-derived where the code around the main loop needs it (wave number from an SGPR + v_mbcnt): index
+  // arithmetic that started from threadIdx.x was hoisted out of the tile loop and carried, spilled, across the main loop.
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  auto fresh_tid = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return wave_s * 64 + l;
+  };
 
   auto dma_tile = [&](unsigned base) {                          // one K tile of both operands; the bases step to the next one
     const char* ab = uniform_ptr(a_base);
@@ -817,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
         w_off[i] = (unsigned)(((long)(min(c.n0 + i * 64 + lr, p.N - 1) - c.n0) * p.K2 + clog * 8) * 2);
     }
   };
-  auto first_dma = [&](const TileCtx& c) {                      // sources of tile c + its first K tile into stage 0
+  auto first_dma = [&](const TileCtx& c, int st) {              // sources of tile c + its first K tile into stage st
     if (p.a_plain) {
 #pragma unroll
       for (int i = 0; i < NA; ++i)
@@ -840,10 +903,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     w_base = (const char*)c.Wp + (p.w_blocked ? (((long)(c.n0 >> 6) * nkt) << 13) + (long)c.kb * 8192 : ((long)c.n0 * p.K + (long)c.kb * BK) * 2);
     if (c.kb < c.ke) {
       ext_switch(c, c.kb);
-      dma_tile(lds_w);
+      dma_tile(lds_w + st * STAGE);
+    }
+  };
+  // The epilogue's constants of tile c into the stage whose wave window starts at `base` (see EPI_LDS_*): issued where the main
+  // loop's LAST K tile would request its successor, waited for by that K tile's own vmcnt(0) + barriers.
+  constexpr bool GELU = ACT == 1 || ACT == 3;
+  constexpr bool ROPE = ACT == 2 || ACT == 4;
+  auto dma_epi = [&](const TileCtx& c, unsigned base) {
+    const int te = fresh_tid();                                 // (keeps this address arithmetic out of the K loop's live ranges)
+    if (c.biasp && te < BN2 / 4) {
+      const int n = c.n0 + te * 4;
+      glds16_s(uniform_ptr((const char*)c.biasp), (unsigned)((n < p.N ? n : p.N - 4) * 4), base + EPI_LDS_BIAS);
+    }
+    if (GELU && !(p.dbg & 8)) {
+      static_assert(GELU_LUT_N * 8 == 512 * 16, "one 16-B piece per thread");
+      glds16_s(uniform_ptr((const char*)kGeluLut), (unsigned)(te * 16), base + EPI_LDS_TAB);
+    }
+    if (ROPE) {
+      const char* rb = uniform_ptr((const char*)p.rope_tab);
+#pragma unroll
+      for (int i = 0; i < BM2 * 128 / 8192; ++i) {
+        const int q = i * 512 + te, r = q >> 3, cch = q & 7;
+        const int m = c.rbase + min(c.m0 + r, c.Mact - 1);
+        glds16_s(rb, (unsigned)(((m % p.rope_rows) * 32 + ((cch ^ (r & 7)) << 2)) * 4), base + EPI_LDS_TAB + i * 8192);
+      }
     }
   };
 
+  const bool res_init = residual_is_start<ACT, OUT_BF16, HAS_RES>(p);
   int h = blockIdx.x;
   TileCtx cur = tile_ctx<BM2, BN2, KEXT>(p, h, total);
   while (!cur.ok) {                                              // surplus tiles of a grouped launch
@@ -851,14 +939,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     if (h >= total) return;
     cur = tile_ctx<BM2, BN2, KEXT>(p, h, total);
   }
-  first_dma(cur);
+  int ph = 0;                                                    // the stage that receives the tile's first K tile
+  first_dma(cur, ph);
 
   for (;;) {
     f32x4 acc[MI][NT];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the residual's loads (residual_start) go out here, behind the first K tile's DMA and in front of the wait that tile needs anyway
+    if (res_init) {
+      const int te = fresh_tid();
+      residual_start<MI, NT>(acc, p, cur.m0 + (te >> 8) * (BM2 / 2) + (te & 15), cur.Mact, cur.rbase, cur.n0 + ((te >> 6) & 3) * (BN2 / 4), (te >> 4) & 3);
+    } else {
+      zero_acc<MI, NT>(acc);
+    }
 
     unsigned long long lf[5] = {0, 0, 0, 0, 0};
     if (LIFE) lf[0] = __builtin_amdgcn_s_memtime();
@@ -867,7 +959,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     if (LIFE) lf[1] = __builtin_amdgcn_s_memtime();                                             // first K tile landed; every wave is past the previous epilogue's LDS reads
     if (lag) __builtin_amdgcn_s_barrier();
     for (int kt = cur.kb; kt < cur.ke; ++kt) {
-      const int cs = (kt - cur.kb) & 1;
+      const int cs = ((kt - cur.kb) & 1) ^ ph;
       const bool more = kt + 1 < cur.ke;
       const char* S = smem + cs * STAGE;
       const unsigned nxt = lds_w + (cs ^ 1) * STAGE;
@@ -883,6 +975,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
           if (more) {
             ext_switch(cur, kt + 1);
             dma_tile(nxt);
+          } else {
+            dma_epi(cur, nxt);
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
@@ -914,30 +1008,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       if (nx.ok) break;
       hn += gridDim.x;
     }
-    if (nx.ok) first_dma(nx);
-    if (LIFE) lf[3] = __builtin_amdgcn_s_memtime();
-    // GELU epilogues: the chord table (8 KB) goes into stage 1 -- free until the next tile's second K tile is staged, which
-    // happens after this epilogue -- one 16-B piece per thread; TA355_GELU_LUT=0 (p.dbg bit 3) keeps the arithmetic form
-    constexpr bool GELU = ACT == 1 || ACT == 3;
-    const float2* lut = nullptr;
-    if (GELU && !(p.dbg & 8)) {
-      static_assert(GELU_LUT_N * 8 == 512 * 16, "one uint4 per thread");
-      *(uint4*)(smem + STAGE + tid * 16) = ((const uint4*)kGeluLut)[tid];
+    // the last K tile sat in stage `last`: free now, it takes the next tile's first K tile; the other one holds the epilogue's
+    // constants until the next tile's SECOND K tile is requested (behind the next loop-top barrier, i.e. after this epilogue)
+    const int nK = cur.ke - cur.kb;
+    const int last = __builtin_amdgcn_readfirstlane(nK > 0 ? (((nK - 1) & 1) ^ ph) : ph);
+    const char* els = smem + (last ^ 1) * STAGE;
+    if (nK <= 0) {                                               // (an empty K range: nothing was staged on the way)
+      dma_epi(cur, lds_w + (last ^ 1) * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      lut = (const float2*)(smem + STAGE);
     }
+    if (nx.ok) first_dma(nx, last);
+    if (LIFE) lf[3] = __builtin_amdgcn_s_memtime();
+    const float2* lut = (GELU && !(p.dbg & 8)) ? (const float2*)(els + EPI_LDS_TAB) : nullptr;   // (TA355_GELU_LUT=0: the arithmetic form)
 
     // ---- epilogue of `cur`.  Its index arithmetic starts from an opaque copy of the thread index: otherwise the compiler
     // hoists those loop-invariant values out of the tile loop and carries them, spilled, across the main loop.
     if (!(p.dbg & 1)) {
-      int te = tid;
-      asm volatile("" : "+v"(te));
+      const int te = fresh_tid();
       const int e_l15 = te & 15, e_g = (te >> 4) & 3, e_wn = (te >> 6) & 3, e_wm = te >> 8;
       char* Cb = (char*)p.C;
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
-      epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, (BM2 == 192 ? 1 : 0)>(acc, p, Cb, cur.m0 + e_wm * (BM2 / 2) + e_l15, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
-                                                     wide, cur.biasp, lut);
+      const int erow0 = e_wm * (BM2 / 2) + e_l15;
+      if (res_init)
+        epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, true>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
+                                                             wide, cur.biasp, lut, els, cur.n0, erow0);
+      else
+        epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, (BM2 == 192 ? 1 : 0), true>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase,
+                                                                                  cur.n0 + e_wn * (BN2 / 4), e_g, wide, cur.biasp, lut, els, cur.n0, erow0);
     }
     if (LIFE) {
       lf[4] = __builtin_amdgcn_s_memtime();
@@ -950,7 +1049,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       }
     }
     if (!nx.ok) return;
-    cur = nx; h = hn;
+    cur = nx; h = hn; ph = last;
   }
 }
 
@@ -1045,10 +1144,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
   const int b_rd = A_BYTES + (wn * (BN2 / 4)) * 64 + rd;
 
   f32x4 acc[8][NT];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool res_init = residual_is_start<ACT, OUT_BF16, HAS_RES>(p);
+  if (res_init) residual_start<8, NT>(acc, p, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g);
+  else zero_acc<8, NT>(acc);
 
   const int nh = 2 * (kt_end - kt_begin);
   const int ext_at = KEXT ? 2 * (nkt - kt_begin) : -1;      // first half-tile of the K extension
@@ -1117,7 +1215,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs p) {
   }
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 512>(smem, p, tid, false);       // both wave groups are past their last LDS read
-  epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
+  if (res_init) epilogue_tile<8, NT, ACT, OUT_BF16, false>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
+  else epilogue_tile<8, NT, ACT, OUT_BF16, HAS_RES>(acc, p, Cb, m0 + wm * 128 + l15, Mact, rbase, n0 + wn * (BN2 / 4), g, wide, biasp, lut);
 }
 
 // out[i] = (add ? add[i] : 0) + sum_z slab[z][i]  (f32 and/or bf16 out; add may alias out); n4 = count / 4
@@ -1222,10 +1321,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   const int koff1 = ((4 + g) ^ swz) << 4;
 
   f32x4 acc[6][4];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool res_init = residual_is_start<ACT, OUT_BF16, HAS_RES>(p);
+  if (res_init) residual_start<6, 4>(acc, p, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g);
+  else zero_acc<6, 4>(acc);
   typedef __attribute__((ext_vector_type(16))) float f32x16;
   f32x16 acc32[6];                                    // EXP == 5 (timing only): the same tile as 6 blocks of 32x32, 12 MFMAs per half-step
   if (EXP == 5) {
@@ -1333,7 +1431,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v5(GemmArgs p) {
   }
   const bool wide = epilogue_wide_ok(p);
   const float2* lut = stage_gelu_lut<ACT, 256>(smem, p, tid, true);
-  epilogue_tile<6, 4, ACT, OUT_BF16, HAS_RES, 2>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);   // one wave per SIMD: registers to spare
+  if (res_init) epilogue_tile<6, 4, ACT, OUT_BF16, false>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);
+  else epilogue_tile<6, 4, ACT, OUT_BF16, HAS_RES, 2>(acc, p, Cb, m0 + wm * 96 + l15, Mact, rbase, n0 + wn * 64, g, wide, biasp, lut);   // one wave per SIMD: registers to spare
 }
 
 // ============================================================================ v6: v5 on v_mfma_f32_32x32x16_bf16
@@ -1646,6 +1745,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     a.dbg = d && *d ? atoi(d) : 0;
     const char* gl = getenv("TA355_GELU_LUT");            // 0 = arithmetic erf-GELU in the ping-pong kernel's epilogue (A/B, tests)
     if (gl && *gl == '0') a.dbg |= 8;
+    const char* ri = getenv("TA355_GEMM_RES_INIT");       // 0 = the ping-pong kernel adds a bf16 residual in its epilogue (A/B)
+    if (ri && *ri == '0') a.dbg |= 16;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
   // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
