@@ -957,6 +957,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share of the first K tile (and its last stores)
     __syncthreads();
     if (LIFE) lf[1] = __builtin_amdgcn_s_memtime();                                             // first K tile landed; every wave is past the previous epilogue's LDS reads
+    // which tile comes next is scalar work (two divisions, the grouped launches' table look-ups): done HERE, where it shares the
+    // issue slots with the main loop's first MFMAs, instead of between the main loop and the epilogue (~1 k cycles per tile)
+    int hn = h + gridDim.x;
+    TileCtx nx; nx.ok = 0;
+    while (hn < total) {
+      nx = tile_ctx<BM2, BN2, KEXT>(p, hn, total);
+      if (nx.ok) break;
+      hn += gridDim.x;
+    }
     if (lag) __builtin_amdgcn_s_barrier();
     for (int kt = cur.kb; kt < cur.ke; ++kt) {
       const int cs = ((kt - cur.kb) & 1) ^ ph;
@@ -1000,14 +1009,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     if (!lag) __builtin_amdgcn_s_barrier();                      // both groups are past their last LDS read: both stages are free
 
     if (LIFE) lf[2] = __builtin_amdgcn_s_memtime();
-    // ---- the next tile of this workgroup: its first K tile travels while the epilogue runs
-    int hn = h + gridDim.x;
-    TileCtx nx; nx.ok = 0;
-    while (hn < total) {
-      nx = tile_ctx<BM2, BN2, KEXT>(p, hn, total);
-      if (nx.ok) break;
-      hn += gridDim.x;
-    }
+    // ---- the next tile of this workgroup (found before the main loop): its first K tile travels while the epilogue runs
     // the last K tile sat in stage `last`: free now, it takes the next tile's first K tile; the other one holds the epilogue's
     // constants until the next tile's SECOND K tile is requested (behind the next loop-top barrier, i.e. after this epilogue)
     const int nK = cur.ke - cur.kb;
