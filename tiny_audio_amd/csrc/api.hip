@@ -384,8 +384,8 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
   if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
   // y = x W^T + xa Bext^T with xa = x (s Acat)^T: one skinny GEMM for xa, then the frozen GEMM runs one extra K-tile
   ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen GEMM (consumed and cleared by it)
-  auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa) -> int {
-    RC(ta_i_lora_skinny_nt(x, in, g.a, xa, M, st));
+  auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa, int members) -> int {
+    RC(ta_i_lora_skinny_nt(x, in, g.a, xa, M, members * r, st));
     kx = opts_kext(xa, g.b);
     return TA_OK;
   };
@@ -453,7 +453,7 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
       return gemm_opt(A, Wm, out, M, d.D, K, nullptr, res, 0, 0, o, st);
     };
     RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
-    if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv));
+    if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv, 3));
     RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging (TA355_ATTN_FWD_FUSED=0: two kernels)
     static const bool fuse_fwd = [] { const char* e = getenv("TA355_ATTN_FWD_FUSED"); return !(e && *e == '0'); }();
@@ -471,15 +471,15 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
         return TA_ERR_LAUNCH;
     }
     if (!fused_fwd) RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
-    if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o));
+    if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o, 1));
     RC(res_gemm(p.ao, Lw.wo, p.x1, d.nq * d.hd, p.x_in));
     bf16_t* xn2 = keep ? p.xn2_s : s.xn;
     bf16_t* act = keep ? p.act_s : s.act;
     RC(norm(p.x1, Lw.ln_post_w, xn2, p.r_post));
-    if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu));
+    if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu, 2));
     RC(gemm_opt(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_swiglu_fwd(p.gu, act, M, d.F, st));
-    if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d));
+    if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d, 1));
     RC(res_gemm(act, Lw.wd, x_next, d.F, p.x1));
   }
   return TA_OK;
@@ -626,7 +626,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen dX GEMM
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1) -> int {
-    RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, st));
+    RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, members * r, st));
     static const bool dual = [] { const char* e = getenv("TA355_LORA_TN_DUAL"); return !(e && *e == '0'); }();
     if (dual) {                                        // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
       RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, s.dyB, members * r, dla, 1, in, w->lora_scale,

@@ -1720,7 +1720,10 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   int variant = pick_variant(a.M, a.N, a.K, a.splits);
   const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
   if ((variant == 10 || variant == 11) && (a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 / v6: no gather, plain W only
-  if (variant == 12 && (a.a_idx || a.A2 || a_far)) variant = 3;                                // the 192-row tile exists in the persistent form only
+  {
+    static const bool pk12 = [] { const char* e = getenv("TA355_GEMM_PERSIST_KEXT"); return e && *e == '1'; }();
+    if (variant == 12 && (a.a_idx || a_far || (a.A2 && !pk12))) variant = 3;                  // the 192-row tile exists in the persistent form only
+  }
   if (variant == 10 && ACT == 0) {                  // TA355_GEMM_M32=1 (experiment): plain linears on the 32x32x16 form of the same tile (v6)
     const char* e = getenv("TA355_GEMM_M32");
     if (e && *e == '1') variant = 11;
@@ -1757,6 +1760,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
   if (a_far) persist = false;
+  // round 3: the K extension on the persistent kernel re-measured (TA355_GEMM_PERSIST_KEXT=1; default: v2 as in round 2).  With the
+  // tile context marked wave-uniform the pointer switch no longer spills in the tile loop, but the launches are SLOWER (gate|up +
+  // d(act) 91.8 against 61.6 us, LoRA step 47.4 against 46.05 ms: profiles/r03_p_ab_lora.txt)
+  static const bool pk_env = [] { const char* e = getenv("TA355_GEMM_PERSIST_KEXT"); return e && *e == '1'; }();
+  const bool persist_kext = pk_env && a.A2 && !a.a_idx && !a_far && (variant == 3 || variant == 4 || variant == 12);
   const int pgrid = grid < ncu ? grid : ncu;
   ProfRec r;
   if (g_prof_on) {
@@ -1769,6 +1777,9 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 128, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 1) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 12) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES, true, false, 192>), dim3(pgrid), dim3(512), 0, st, a);
+      else if (variant == 3 && persist_kext) TA_LAUNCH((gemm_nt_kernel_v4<256, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
+      else if (variant == 4 && persist_kext) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES, true>), dim3(pgrid), dim3(512), 0, st, a);
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 10) TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES, 0, true>), dim3(grid), dim3(256), 0, st, a);

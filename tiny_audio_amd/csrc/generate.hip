@@ -362,7 +362,7 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
                     const LoraImg* g) -> int {
     const bf16_t *a2 = nullptr, *w2 = nullptr;
     if (g) {
-      RC(ta_i_lora_skinny_nt(x, K, g->a, s.xa, B, st));
+      RC(ta_i_lora_skinny_nt(x, K, g->a, s.xa, B, 64, st));   // (decode: M = batch rows; the full 64-wide image)
       a2 = s.xa; w2 = g->b;
     }
     if (small) return linear_small_m(x, (const bf16_t*)Wm, y, B, N, K, res, out_bf16, a2, w2, st);

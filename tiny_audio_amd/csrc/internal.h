@@ -19,4 +19,4 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
 int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float* out0, long so_c0, long so_j0, float post0, int r0,
                          int b00, int b10, const void* X1, int Cn1, const void* Y1, int R1, float* out1, long so_c1, long so_j1,
                          float post1, int r1, int b01, int b11, int M, hipStream_t st);   // two TN products, one launch
-int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T
+int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, int R, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T; rows >= R of W are zero

@@ -180,17 +180,22 @@ __global__ __launch_bounds__(256) void lora_tn_dual_kernel(const LoraTnArgs p0, 
 // The kernel is a stream over X (HBM) with W (<= 768 KB) resident in L2; two k-steps are kept in flight per wave so
 // that ~32 KB of X loads are outstanding per CU.
 constexpr int SK_WAVES = 8;
+// NCB (round 3): only the first NCB 16-column blocks of W hold an adapter (24 / 8 / 16 / 8 of the 64 rows for the q|k|v, o,
+// gate|up and down groups: NCB = 2, 1, 1, 1); the rest of the 64-wide image is zero by construction and is written as zeros
+// without being fetched or multiplied.  The W fragments (re-read from L2 by every workgroup) were 4 KB per k-step and wave
+// against 2 KB of X: the kernel ran at half the HBM rate on L2 traffic it did not need.
+template <int NCB>
 __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf16_t* __restrict__ X, int K,
                                                                        const bf16_t* __restrict__ W,
                                                                        bf16_t* __restrict__ out, int M) {
-  __shared__ float red[SK_WAVES][32][65];
+  __shared__ float red[SK_WAVES][32][NCB * 16 + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 32;
-  lf32x4 acc[2][4];
+  lf32x4 acc[2][NCB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NCB; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
   const int ra = min(m0 + i, M - 1), rb = min(m0 + 16 + i, M - 1);       // clamped rows are never stored
   const bf16_t* xa = X + (long)ra * K + g * 8;
   const bf16_t* xb = X + (long)rb * K + g * 8;
@@ -205,14 +210,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
   const int rot = ns ? (int)((blockIdx.x * 7u) % (unsigned)ns) : 0;
   auto kof = [&](int sidx) { int q = sidx + rot; if (q >= ns) q -= ns; return (wave + SK_WAVES * q) * 32; };
   constexpr int PF = 3;
-  lbf16x8 xr[PF][2], wr[PF][4];
+  lbf16x8 xr[PF][2], wr[PF][NCB];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < ns) {
       const int kp = kof(p);
       xr[p][0] = *(const lbf16x8*)(xa + kp); xr[p][1] = *(const lbf16x8*)(xb + kp);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kp >> 5) * 64 + cb * 16) * 32);
+      for (int cb = 0; cb < NCB; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kp >> 5) * 64 + cb * 16) * 32);
     }
   for (int s0 = 0; s0 < ns; s0 += PF) {
 #pragma unroll
@@ -220,17 +225,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
       const int sc = s0 + p;
       if (sc < ns) {                                 // wave-uniform
         const lbf16x8 a0 = xr[p][0], a1 = xr[p][1];
-        lbf16x8 b[4];
+        lbf16x8 b[NCB];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = wr[p][cb];
+        for (int cb = 0; cb < NCB; ++cb) b[cb] = wr[p][cb];
         if (sc + PF < ns) {                          // refill this ring slot
           const int kf = kof(sc + PF);
           xr[p][0] = *(const lbf16x8*)(xa + kf); xr[p][1] = *(const lbf16x8*)(xb + kf);
 #pragma unroll
-          for (int cb = 0; cb < 4; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kf >> 5) * 64 + cb * 16) * 32);
+          for (int cb = 0; cb < NCB; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kf >> 5) * 64 + cb * 16) * 32);
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
           acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[cb], acc[0][cb], 0, 0, 0);
           acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[1][cb], 0, 0, 0);
         }
@@ -240,15 +245,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
 #pragma unroll
   for (int rbk = 0; rbk < 2; ++rbk)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[wave][rbk * 16 + g * 4 + q][cb * 16 + i] = acc[rbk][cb][q];
   __syncthreads();
   for (int e = tid; e < 32 * 64; e += SK_WAVES * 64) {
     const int row = e >> 6, col = e & 63;
     float v = 0.f;
+    if (col < NCB * 16) {
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][col];
+      for (int w = 0; w < SK_WAVES; ++w) v += red[w][row][col];
+    }
     if (m0 + row < M) out[(long)(m0 + row) * 64 + col] = f2bf(v);
   }
 }
@@ -301,10 +308,17 @@ int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float*
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
-int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, hipStream_t st) {
-  if (K % 32 || K <= 0) return TA_ERR_ARG;
+// R = rows of W that can be non-zero (members * rank of the group; 64 = all)
+int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, int R, hipStream_t st) {
+  if (K % 32 || K <= 0 || R <= 0 || R > 64) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  TA_LAUNCH(lora_skinny_nt_kernel, dim3(ta_cdiv(M, 32)), dim3(SK_WAVES * 64), 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  static const bool full = [] { const char* e = getenv("TA355_LORA_NT_FULL"); return e && *e == '1'; }();   // A/B: all 64 columns
+  const int ncb = full ? 4 : (R + 15) / 16;
+  const dim3 grid(ta_cdiv(M, 32)), blk(SK_WAVES * 64);
+  if (ncb == 1) TA_LAUNCH((lora_skinny_nt_kernel<1>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  else if (ncb == 2) TA_LAUNCH((lora_skinny_nt_kernel<2>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  else if (ncb == 3) TA_LAUNCH((lora_skinny_nt_kernel<3>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  else TA_LAUNCH((lora_skinny_nt_kernel<4>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
