@@ -833,8 +833,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   const int total = p.tiles_m * p.tiles_n * p.splits;
   const int nkt = p.K / BK;
 
-  const int lr = tid >> 3;
-  const int clog = (tid & 7) ^ ((lr >> 1) & 7);
   // DMA sources: a uniform base pointer that walks along K (scalar adds) + one 32-bit byte offset per 16-B chunk
   // (operands < 4 GB, checked by the host): half the registers of per-chunk pointers and no vector adds in the main loop
   const char* a_base; const char* w_base;
@@ -870,6 +868,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   // whatever the operand's size; only A under a non-identity row map is addressed from the start of A (host: < 4 GB, no gather).
   auto ext_switch = [&](const TileCtx& c, int tile) {            // call before staging K-tile `tile` of tile context c
     if (KEXT && tile == nkt) {
+      // (thread index re-derived here: from threadIdx.x these nine offsets are loop-invariant, were hoisted out of the tile loop and
+      // pushed the regular ones into scratch -- reloaded between the DMA issues of every K tile, each reload behind a vmcnt(0))
+      const int te = fresh_tid(), lr = te >> 3, clog = (te & 7) ^ ((lr >> 1) & 7);
       a_base = (const char*)(p.A2 + (long)(c.rbase + c.m0) * p.lda2);
       w_base = (const char*)(p.W2 + (long)c.n0 * p.K2);
 #pragma unroll
@@ -881,6 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     }
   };
   auto first_dma = [&](const TileCtx& c, int st) {              // sources of tile c + its first K tile into stage st
+    const int te = fresh_tid(), lr = te >> 3, clog = (te & 7) ^ ((lr >> 1) & 7);
     if (p.a_plain) {
 #pragma unroll
       for (int i = 0; i < NA; ++i)
