@@ -1762,9 +1762,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
   { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
   if (a_far) persist = false;
-  // round 3: the K extension on the persistent kernel re-measured (TA355_GEMM_PERSIST_KEXT=1; default: v2 as in round 2).  With the
-  // tile context marked wave-uniform the pointer switch no longer spills in the tile loop, but the launches are SLOWER (gate|up +
-  // d(act) 91.8 against 61.6 us, LoRA step 47.4 against 46.05 ms: profiles/r03_p_ab_lora.txt)
+  // round 3: the K extension on the persistent kernel re-measured (TA355_GEMM_PERSIST_KEXT=1; default: v2 as in round 2).  First
+  // attempt: 91.8 against 61.6 us per launch (profiles/r03_p_ab_lora.txt) -- the extension's nine DMA offsets, loop-invariant from
+  // threadIdx.x, had been hoisted out of the tile loop and pushed the regular offsets into scratch, reloaded behind a vmcnt(0)
+  // between the DMA issues of every K tile.  With the offsets derived from a fresh thread index at the switch: no scratch, and the
+  // LoRA step is the same on both kernels (45.45 ms each, profiles/r03_r_ab_lora_persist_kext.txt)
   static const bool pk_env = [] { const char* e = getenv("TA355_GEMM_PERSIST_KEXT"); return e && *e == '1'; }();
   const bool persist_kext = pk_env && a.A2 && !a.a_idx && !a_far && (variant == 3 || variant == 4 || variant == 12);
   const int pgrid = grid < ncu ? grid : ncu;
