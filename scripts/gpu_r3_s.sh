@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 3, visit s: LM attention backward -- LSE / Delta of the next tile loaded raw (no arithmetic behind the DMA issues); A/B vs the library of visit r
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd $REPO
+export PYTHONUNBUFFERED=1
+timeout 900 python -m pytest tests -m gpu -q -x -k "attention or attn or lm_ or language or b32 or smoke or full_depth" 2>&1 | tail -4 | tee $OUT/r3s_pytest.log
+for i in 1 2 3; do
+  for lib in libta355_prev.so libta355.so; do
+    TA355_LIB=$REPO/tiny_audio_amd/$lib python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-logits-full --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['ms_per_step'], d['value'])"
+  done
+done | tee $OUT/r3s_ab_attn_bwd.txt
+cd /tmp && export TMPDIR=/tmp
+P=$OUT/prof_r3s; rm -rf $P; mkdir -p $P
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o b -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-logits-full > $P/run.log 2>&1; echo "rocprof rc=$?"
+TR=$(find $P -name "*kernel_trace.csv" | head -1)
+python $REPO/scripts/summarize_trace_steps.py $TR $OUT/r3s_kernel_steps.md --skip 1 --note "bench.py --steps 4 --warmup 1 (configs[1], B = 32), rocprofv3 --kernel-trace --stats; round 3 visit s" | grep "attn_\|steps:"
+find $P -name "*kernel_trace.csv" -delete

@@ -1054,11 +1054,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
     const unsigned dst = lds0 + buf * BWD_BUF;
     dma_rowtile128(Q + ((long)(b * Hq + h) * L) * HD, HD, q0, L, dst, wave, lane);
     dma_rowtile128(dO + (long)b * L * dO_stride + (long)h * HD, dO_stride, q0, L, dst + RowTile<HD>::BYTES, wave, lane);
-    if (tid < 64) {
-      const int qq = q0 + tid;
-      const bool v = qq < L;
-      pl = v ? LSE[(long)(b * Hq + h) * L + qq] * LOG2E : 1.0e30f;
-      pd = v ? Delta[(long)(b * Hq + h) * L + qq] : 0.f;
+    // (raw values only: any arithmetic on them here makes the compiler wait for the loads right behind the DMA issues -- and with
+    // the in-order counter for every DMA of the tile just requested, which serialised the whole prefetch; round-3 ISA reading)
+    pl = 1.0e30f; pd = 0.f;
+    if (tid < 64 && q0 + tid < L) {
+      pl = LSE[(long)(b * Hq + h) * L + q0 + tid];
+      pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
     }
   };
   if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
@@ -1069,7 +1070,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       char* dOs = Qs + RowTile<HD>::BYTES;
       float* Ls = (float*)(dOs + RowTile<HD>::BYTES);  // [64] lse * log2e
       float* Ds = Ls + 64;                             // [64] delta
-      if (tid < 64) { Ls[tid] = pl; Ds[tid] = pd; }
+      if (tid < 64) { Ls[tid] = pl * LOG2E; Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
