@@ -302,8 +302,21 @@ int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float*
   if (M <= 0) return TA_OK;
   LoraTnArgs p0 = {(const bf16_t*)X0, Cn0, (const bf16_t*)Y0, R0, out0, so_c0, so_j0, post0, r0, b00, b10, lora_tn_rows(M, Cn0), 0, 0};
   LoraTnArgs p1 = {(const bf16_t*)X1, Cn1, (const bf16_t*)Y1, R1, out1, so_c1, so_j1, post1, r1, b01, b11, lora_tn_rows(M, Cn1), 0, 0};
-  p0.gx = ta_cdiv(Cn0, 256); p0.gy = ta_cdiv(M, p0.rows);
-  p1.gx = ta_cdiv(Cn1, 256); p1.gy = ta_cdiv(M, p1.rows);
+  p0.gx = ta_cdiv(Cn0, 256); p1.gx = ta_cdiv(Cn1, 256);
+  // Rows per workgroup of the pair (round 3): as many as leave about ONE workgroup per CU over both problems.  Every workgroup ends
+  // with 256 x R float atomics on addresses shared with the other row chunks of its column strip, and a rows-per-workgroup sweep of
+  // the LoRA step (profiles/r03_t_ab_lora_tn_rows.txt: 47.5 / 46.2 / 45.8 / 47.1 / 51.4 ms at 96 / 192 / 576 / 1152 / 3008 rows)
+  // says the launch is bound by them until the chip runs out of workgroups.  TA355_LORA_TN_WGS = the target count (default 384: 45.2 / 45.1 / 44.95 / 45.25 ms at 256 / 320 / 384 / 512, profiles/r03_u_ab_lora_tn_wgs.txt),
+  // TA355_LORA_TN_ROWS = a fixed row count as before.
+  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
+  static const int wgs_env = [] { const char* e = getenv("TA355_LORA_TN_WGS"); return e && *e ? atoi(e) : 384; }();
+  if (rows_env <= 0 && wgs_env > 0) {
+    const long want = ((long)M * (p0.gx + p1.gx) + wgs_env - 1) / wgs_env;
+    const int rows = (int)((want < 32 ? 32 : want) + 31) / 32 * 32;
+    p0.rows = p1.rows = rows;
+  }
+  p0.gy = ta_cdiv(M, p0.rows);
+  p1.gy = ta_cdiv(M, p1.rows);
   TA_LAUNCH(lora_tn_dual_kernel, dim3(p0.gx * p0.gy + p1.gx * p1.gy), dim3(256), 0, st, p0, p1, M);
   TA_CHECK_LAUNCH();
   return TA_OK;
