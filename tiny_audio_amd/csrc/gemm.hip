@@ -969,6 +969,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       hn += gridDim.x;
     }
     if (lag) __builtin_amdgcn_s_barrier();
+    // (Round 3, measured and removed: giving every DMA three barrier intervals to land instead of two -- the leading group waiting for
+    // K tile kt + 1 only in front of the iteration's last barrier, the lagging group requesting K tile kt + 2 right behind the barrier
+    // that ends its last reads of stage cs.  Bit-identical, race hunt clean; the late wait changed nothing (40.79 vs 40.70 ms per
+    // step) and the early request cost 2.1 ms (42.8): both groups' DMA bursts then leave in the same interval instead of one apart.
+    // DMA latency is not what these GEMMs wait for.  profiles/r03_w_ab_dma_schedule.txt)
     for (int kt = cur.kb; kt < cur.ke; ++kt) {
       const int cs = ((kt - cur.kb) & 1) ^ ph;
       const bool more = kt + 1 < cur.ke;
