@@ -838,6 +838,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   const char* a_base; const char* w_base;
   unsigned a_off[NA], w_off[NB];
   const int w_step = p.w_blocked ? 8192 : BK * 2;
+  // experiment (TA355_GEMM_DEBUG bit 10, scripts/a_blocked_probe.py): A given as [M/64][K/64][64][64] blocks, like w_blocked
+  const bool a_blk = (p.dbg & 1024) != 0;
+  const int a_step = a_blk ? 8192 : BK * 2;
   // wave-uniform LDS byte address of this wave's 1-KB DMA window in stage 0
   const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem + wave * 1024);
   const int swz = l15 >> 1;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
     for (int i = 0; i < NA; ++i) glds16_s(ab, a_off[i], base + i * 8192);
 #pragma unroll
     for (int i = 0; i < NB; ++i) glds16_s(wb, w_off[i], base + A_BYTES + i * 8192);
-    a_base += BK * 2; w_base += w_step;
+    a_base += a_step; w_base += w_step;
   };
   // Offsets are relative to the tile's first row of each operand (the base carries the rest), so they stay far below 4 GB
   // whatever the operand's size; only A under a non-identity row map is addressed from the start of A (host: < 4 GB, no gather).
@@ -883,7 +886,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   };
   auto first_dma = [&](const TileCtx& c, int st) {              // sources of tile c + its first K tile into stage st
     const int te = fresh_tid(), lr = te >> 3, clog = (te & 7) ^ ((lr >> 1) & 7);
-    if (p.a_plain) {
+    if (a_blk) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a_off[i] = (unsigned)((((long)(i * nkt) << 12) + (lr << 6) + clog * 8) * 2);
+      a_base = (const char*)(p.A + ((((long)((c.rbase + c.m0) >> 6)) * nkt + c.kb) << 12));
+    } else if (p.a_plain) {
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         a_off[i] = (unsigned)(((long)(min(c.m0 + i * 64 + lr, c.Mact - 1) - c.m0) * p.lda + clog * 8) * 2);
