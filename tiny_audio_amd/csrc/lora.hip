@@ -184,19 +184,20 @@ constexpr int SK_WAVES = 8;
 // gate|up and down groups: NCB = 2, 1, 1, 1); the rest of the 64-wide image is zero by construction and is written as zeros
 // without being fetched or multiplied.  The W fragments (re-read from L2 by every workgroup) were 4 KB per k-step and wave
 // against 2 KB of X: the kernel ran at half the HBM rate on L2 traffic it did not need.
-template <int NCB>
+// RB = 16-row blocks per workgroup: 2 (M / 32 workgroups: 188 for the B = 32 step, on 256 CUs) or 1 (376, twice the loads in flight)
+template <int NCB, int RB>
 __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf16_t* __restrict__ X, int K,
                                                                        const bf16_t* __restrict__ W,
                                                                        bf16_t* __restrict__ out, int M) {
-  __shared__ float red[SK_WAVES][32][NCB * 16 + 1];
+  __shared__ float red[SK_WAVES][16 * RB][NCB * 16 + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 32;
-  lf32x4 acc[2][NCB];
+  const int m0 = blockIdx.x * (16 * RB);
+  lf32x4 acc[RB][NCB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RB; ++a)
 #pragma unroll
     for (int b = 0; b < NCB; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
-  const int ra = min(m0 + i, M - 1), rb = min(m0 + 16 + i, M - 1);       // clamped rows are never stored
+  const int ra = min(m0 + i, M - 1), rb = min(m0 + (RB - 1) * 16 + i, M - 1);       // clamped rows are never stored
   const bf16_t* xa = X + (long)ra * K + g * 8;
   const bf16_t* xb = X + (long)rb * K + g * 8;
   // W is stored in k-step-major blocks [K/32][64][32]: the four fragment loads of one k-step read 4 KB contiguously.
@@ -210,12 +211,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
   const int rot = ns ? (int)((blockIdx.x * 7u) % (unsigned)ns) : 0;
   auto kof = [&](int sidx) { int q = sidx + rot; if (q >= ns) q -= ns; return (wave + SK_WAVES * q) * 32; };
   constexpr int PF = 3;
-  lbf16x8 xr[PF][2], wr[PF][NCB];
+  lbf16x8 xr[PF][RB], wr[PF][NCB];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < ns) {
       const int kp = kof(p);
-      xr[p][0] = *(const lbf16x8*)(xa + kp); xr[p][1] = *(const lbf16x8*)(xb + kp);
+      xr[p][0] = *(const lbf16x8*)(xa + kp); if (RB > 1) xr[p][RB - 1] = *(const lbf16x8*)(xb + kp);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kp >> 5) * 64 + cb * 16) * 32);
     }
@@ -224,32 +225,32 @@ __global__ __launch_bounds__(SK_WAVES * 64) void lora_skinny_nt_kernel(const bf1
     for (int p = 0; p < PF; ++p) {
       const int sc = s0 + p;
       if (sc < ns) {                                 // wave-uniform
-        const lbf16x8 a0 = xr[p][0], a1 = xr[p][1];
+        const lbf16x8 a0 = xr[p][0], a1 = xr[p][RB - 1];
         lbf16x8 b[NCB];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) b[cb] = wr[p][cb];
         if (sc + PF < ns) {                          // refill this ring slot
           const int kf = kof(sc + PF);
-          xr[p][0] = *(const lbf16x8*)(xa + kf); xr[p][1] = *(const lbf16x8*)(xb + kf);
+          xr[p][0] = *(const lbf16x8*)(xa + kf); if (RB > 1) xr[p][RB - 1] = *(const lbf16x8*)(xb + kf);
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) wr[p][cb] = *(const lbf16x8*)(wp + ((long)(kf >> 5) * 64 + cb * 16) * 32);
         }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
           acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[cb], acc[0][cb], 0, 0, 0);
-          acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[1][cb], 0, 0, 0);
+          if (RB > 1) acc[RB - 1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[cb], acc[RB - 1][cb], 0, 0, 0);
         }
       }
     }
   }
 #pragma unroll
-  for (int rbk = 0; rbk < 2; ++rbk)
+  for (int rbk = 0; rbk < RB; ++rbk)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[wave][rbk * 16 + g * 4 + q][cb * 16 + i] = acc[rbk][cb][q];
   __syncthreads();
-  for (int e = tid; e < 32 * 64; e += SK_WAVES * 64) {
+  for (int e = tid; e < 16 * RB * 64; e += SK_WAVES * 64) {
     const int row = e >> 6, col = e & 63;
     float v = 0.f;
     if (col < NCB * 16) {
@@ -327,11 +328,15 @@ int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, i
   if (M <= 0) return TA_OK;
   static const bool full = [] { const char* e = getenv("TA355_LORA_NT_FULL"); return e && *e == '1'; }();   // A/B: all 64 columns
   const int ncb = full ? 4 : (R + 15) / 16;
-  const dim3 grid(ta_cdiv(M, 32)), blk(SK_WAVES * 64);
-  if (ncb == 1) TA_LAUNCH((lora_skinny_nt_kernel<1>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
-  else if (ncb == 2) TA_LAUNCH((lora_skinny_nt_kernel<2>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
-  else if (ncb == 3) TA_LAUNCH((lora_skinny_nt_kernel<3>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
-  else TA_LAUNCH((lora_skinny_nt_kernel<4>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M);
+  // 32 rows per workgroup; TA355_LORA_NT_ROWS=16: twice the workgroups (376 instead of 188 for the B = 32 step) -- measured equal to
+  // slightly slower (45.26 vs 45.47 ms per LoRA step, profiles/r03_y_ab_lora_nt_rows.txt): the launch is not short of loads in flight
+  static const int rows_env = [] { const char* e = getenv("TA355_LORA_NT_ROWS"); return e && *e ? atoi(e) : 0; }();
+  const bool r16 = rows_env == 16;
+  const dim3 grid(ta_cdiv(M, r16 ? 16 : 32)), blk(SK_WAVES * 64);
+#define SKNT(NCB_, RB_) TA_LAUNCH((lora_skinny_nt_kernel<NCB_, RB_>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M)
+  if (r16) { if (ncb == 1) SKNT(1, 1); else if (ncb == 2) SKNT(2, 1); else if (ncb == 3) SKNT(3, 1); else SKNT(4, 1); }
+  else { if (ncb == 1) SKNT(1, 2); else if (ncb == 2) SKNT(2, 2); else if (ncb == 3) SKNT(3, 2); else SKNT(4, 2); }
+#undef SKNT
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
