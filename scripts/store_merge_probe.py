@@ -6,7 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tiny_audio_amd import ops
 
-SHAPES = [("enc fc1 (variant 3)", 16000, 5120, 1280, "3"), ("enc q|k|v (variant 3)", 16000, 3840, 1280, "3"), ("lm q|k|v (auto: 192x256)", 6016, 4096, 1024, ""),
+SHAPES = [("enc fc1 (auto: 256x320)", 16000, 5120, 1280, ""), ("enc q|k|v (auto)", 16000, 3840, 1280, ""), ("enc fc2 (auto)", 16000, 1280, 5120, ""),
+          ("lm gate|up (auto)", 6016, 6144, 1024, ""), ("lm d(act) (auto)", 6016, 3072, 1024, ""), ("ragged 1000x700x192 (variant 4)", 1000, 704, 192, "4"),
+          ("enc fc1 (variant 3)", 16000, 5120, 1280, "3"), ("enc q|k|v (variant 3)", 16000, 3840, 1280, "3"), ("lm q|k|v (auto: 192x256)", 6016, 4096, 1024, ""),
           ("lm d(attn-out) (auto)", 6016, 2048, 1024, ""), ("sq 8192 (variant 3)", 8192, 8192, 8192, "3"), ("ragged 1000x700x192 (variant 3)", 1000, 704, 192, "3"),
           ("ragged 777x264x64 (variant 12)", 777, 264, 64, "12")]
 

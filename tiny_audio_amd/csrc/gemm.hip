@@ -125,20 +125,18 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 // residual taken as the accumulators' start value -- the encoder's epilogues wait for no global load at all.
 #define EPI_LDS_BIAS 0        /* float[BN2]: the tile's bias columns (clamped into the matrix) */
 #define EPI_LDS_TAB 2048      /* GELU: the chord table (8 KB); rope: BM2 rows x 128 B, 16-B chunk c of local row r at slot c ^ (r & 7) */
+// (Round 3, built, measured and removed: ROW-MERGED stores -- the two 32-column pairs of a strip exchanged once more between lane l15
+// and l15 ^ 8 with DPP moves, so that an instruction stores rows 0-7 resp. 8-15 of the strip with 128 contiguous bytes per row (8
+// lines per instruction instead of 16 half lines), also with the 256x320 tile's columns re-mapped to 64 line-aligned columns + a
+// 16-column tail per wave.  Bit-identical.  Against the pair form of the SAME build it looked like -10 % per launch (fc1 on 256x256
+// tiles 236.6 -> 214.0 us); against the previous build of the library it is equal on the 256-column tiles and 0.3-0.8 ms per step
+// slower on 256x320 (profiles/r03_ad_gemm_lib_probe.txt, r03_ad_ab_store_merge_libs.txt): what the first comparison measured was the
+// slowdown of carrying both forms in one epilogue.  The store issue rate is not what the 11 k epilogue cycles of a tile are made of.)
 template <int NT> struct EpiPre { uint2 r[NT]; };
-// STORE = 1 (round 3, the 256-column ping-pong tiles): ROW-MERGED stores.  The store path costs ~2.8 cycles per 128-B line an
-// instruction touches, and the lane-exchanged form above still touches 16 lines per instruction (16 rows x 64 B: 22 B/clk per CU,
-// 11 k of the 78 k cycles a 256x320 tile takes, profiles/r03_z_gemm_wg_life_v4.txt).  Here the two 32-column pairs of a strip are
-// exchanged once more between lane l15 and l15 ^ 8 (two DPP moves per dword), so that one instruction stores rows 0-7 and the next
-// rows 8-15 of the strip, 128 contiguous bytes per row: 8 lines per instruction.  Every lane of the wave takes part (a lane whose own
-// row lies past the matrix still carries half of a valid row), so the strip is entered by the whole wave; MergeRows holds the two
-// rows a lane stores to.
-struct MergeRows { long rx, ry; bool okx, oky, own; int hi; };
-template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false, int STORE = 0>
+template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
                                                int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
-                                               bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0,
-                                               const MergeRows* mr = nullptr) {
+                                               bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
@@ -173,7 +171,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = nb + j * 16 + g * 4;
-    const bool in = n < p.N && (STORE == 0 || mr->own);
+    const bool in = n < p.N;
     f32x4 v = acc[j];
     if (LNF_ROW) {
       const float4 c = lc[j];
@@ -238,38 +236,12 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     }
   }
   if (OUT_BF16 && wide && !SWIGLU) {
-    if (STORE == 1 && NT >= 4 && !(p.dbg & 2048)) {            // (TA355_GEMM_DEBUG bit 11: the pair form below, A/B)
-      uint32_t q[2][4];
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const auto a = __builtin_amdgcn_permlane16_swap(o[2 * pp].x, o[2 * pp + 1].x, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(o[2 * pp].y, o[2 * pp + 1].y, false, false);
-        q[pp][0] = a[0]; q[pp][1] = b[0]; q[pp][2] = a[1]; q[pp][3] = b[1];
-      }
-      uint32_t x[4], y[4];
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        x[d] = __builtin_amdgcn_update_dpp(q[0][d], q[1][d], 0x128, 0xf, 0xc, false);   // lanes 8-15 of a row: pair 1 of row l15 - 8
-        y[d] = __builtin_amdgcn_update_dpp(q[1][d], q[0][d], 0x128, 0xf, 0x3, false);   // lanes 0-7: pair 0 of row l15 + 8
-      }
-      const int col = nb + mr->hi * 32 + 16 * (g & 1) + 8 * (g >> 1);
-      if (mr->okx && col < p.N) *(uint4*)(Cb + (mr->rx + col) * 2) = make_uint4(x[0], x[1], x[2], x[3]);
-      if (mr->oky && col < p.N) *(uint4*)(Cb + (mr->ry + col) * 2) = make_uint4(y[0], y[1], y[2], y[3]);
-#pragma unroll
-      for (int j = 4; j + 1 < NT; j += 2) {
-        const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
-        const int c2 = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
-        if (c2 < p.N && mr->own) *(uint4*)(Cb + (roff + c2) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j + 1 < NT; j += 2) {
-        const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
-        const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
-        if (col < p.N && (STORE == 0 || mr->own)) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
-      }
+    for (int j = 0; j + 1 < NT; j += 2) {
+      const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
+      const auto b = __builtin_amdgcn_permlane16_swap(o[j].y, o[j + 1].y, false, false);
+      const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
+      if (col < p.N) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
     }
   }
 }
@@ -279,7 +251,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 //   1  strips in PAIRS: the residual of strips i and i + 1 in one batch (4 round trips per 8 strips; +NT registers)
 //   2  one strip ahead (the one-wave-per-SIMD kernel: registers to spare; in the 8-wave kernels at 256 VGPRs this form spilled
 //      into the main loop)
-template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0, bool ELS = false, int STORE = 0>
+template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0, bool ELS = false>
 __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int Mact, int rbase, int nb,
                                               int g, bool wide, const float* bias, const float2* lut, const char* els = nullptr,
                                               int ecol0 = 0, int erow0 = 0) {
@@ -301,17 +273,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
   };
   auto strip = [&](int i, const EpiPre<NT>* pre) {
     const int ml = ml0 + i * 16;
-    if constexpr (STORE == 1) {
-      static_assert(!HAS_RES, "row-merged stores: the residual is the accumulators' start value");
-      const int base = ml & ~15;                               // (tile and wave-group row offsets are multiples of 16)
-      if (base < Mact) {                                       // wave-uniform: the whole wave enters
-        const int l15 = ml & 15, mlx = base + (l15 & 7), mly = mlx + 8;
-        const MergeRows mr = {row_off(rbase + min(mlx, Mact - 1)), row_off(rbase + min(mly, Mact - 1)), mlx < Mact, mly < Mact, ml < Mact, l15 >> 3};
-        const int m = rbase + min(ml, Mact - 1);
-        epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS, 1>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r, els, ecol0,
-                                                           erow0 + i * 16, &mr);
-      }
-    } else if (ml < Mact) {
+    if (ml < Mact) {
       const int m = rbase + ml;
       epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r, els, ecol0, erow0 + i * 16);
     }
@@ -1092,12 +1054,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
       const int erow0 = e_wm * (BM2 / 2) + e_l15;
-      constexpr int MERGE = (BN2 == 256 && OUT_BF16) ? 1 : 0;       // row-merged stores (the 64-column = 128-B wave rows of the 256-wide tiles)
       if (res_init)
-        epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, true, MERGE>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
-                                                                    wide, cur.biasp, lut, els, cur.n0, erow0);
+        epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, true>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
+                                                             wide, cur.biasp, lut, els, cur.n0, erow0);
       else
-        epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, (BM2 == 192 ? 1 : 0), true, (HAS_RES ? 0 : MERGE)>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase,
+        epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, (BM2 == 192 ? 1 : 0), true>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase,
                                                                                   cur.n0 + e_wn * (BN2 / 4), e_g, wide, cur.biasp, lut, els, cur.n0, erow0);
     }
     if (LIFE) {
@@ -1745,7 +1706,8 @@ static int pick_variant(int M, int N, int K, int splits) {
   const int forced = (e && *e) ? atoi(e) : -1;
   if (forced >= 0 && forced <= 12) return forced;     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
   static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
-  const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, TA355_RATE_256x320_PP, TA355_RATE_96x128};
+  static const double r320 = [] { const char* v = getenv("TA355_RATE_256x320"); return v && *v ? atof(v) : TA355_RATE_256x320_PP; }();   // experiment
+  const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, r320, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
   int best = 0; double best_t = 1e300;
   for (int v = 0; v < (no96 ? 5 : 6); ++v) {
