@@ -133,10 +133,12 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 // slower on 256x320 (profiles/r03_ad_gemm_lib_probe.txt, r03_ad_ab_store_merge_libs.txt): what the first comparison measured was the
 // slowdown of carrying both forms in one epilogue.  The store issue rate is not what the 11 k epilogue cycles of a tile are made of.)
 template <int NT> struct EpiPre { uint2 r[NT]; };
+// oret != nullptr (bf16 outputs): the strip's packed results are handed back instead of stored (epilogue_tile_full stores them)
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
                                                int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
-                                               bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0) {
+                                               bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0,
+                                               uint2* oret = nullptr) {
   // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
   // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
   // merely present behind a run-time flag.
@@ -230,12 +232,13 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     } else if (OUT_BF16) {
       o[j].x = pack2bf(v[0], v[1]);
       o[j].y = pack2bf(v[2], v[3]);
-      if (in && (!wide || (j == NT - 1 && (NT & 1)))) *(uint2*)(Cb + (roff + n) * 2) = o[j];
+      if (oret) oret[j] = o[j];
+      else if (in && (!wide || (j == NT - 1 && (NT & 1)))) *(uint2*)(Cb + (roff + n) * 2) = o[j];
     } else if (in) {
       *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
-  if (OUT_BF16 && wide && !SWIGLU) {
+  if (OUT_BF16 && wide && !SWIGLU && !oret) {
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
@@ -243,6 +246,46 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       const int col = nb + 16 * (j + (g & 1)) + 8 * (g >> 1);
       if (col < p.N) *(uint4*)(Cb + (roff + col) * 2) = make_uint4(a[0], b[0], a[1], b[1]);
     }
+  }
+}
+// FULL tiles of the persistent kernel (every row and column inside the matrix, identity row map, bf16 out, no residual left for the
+// epilogue): ROW-MERGED stores, second attempt.  The first one (see above) spent what it saved on per-strip row offsets and guards;
+// here the tile is known to be full, so there are no guards, the two row pointers of a lane are set up once per tile and stepped by
+// 16 rows per strip, and what remains per strip is 8 DPP moves: the two 32-column pairs are exchanged between lane l15 and l15 ^ 8,
+// one instruction then stores rows 0-7 of the strip and the next rows 8-15, 128 contiguous bytes per row.  Fragments beyond the
+// first four (the 16-column tail of a 320-column tile) go out as before.
+template <int MI, int NT, int ACT, bool ELS>
+__device__ __forceinline__ void epilogue_tile_full(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int rbase, int nb, int g,
+                                                   const float* bias, const float2* lut, const char* els, int ecol0, int erow0) {
+  static_assert(NT >= 4, "two column pairs per strip");
+  const int l15 = ml0 & 15;                                   // (tile and wave-group row offsets are multiples of 16)
+  const long own0 = p.c_off + (long)(rbase + ml0) * p.ldc;
+  const long step = 16L * p.ldc;
+  const int colx = nb + (l15 >> 3) * 32 + 16 * (g & 1) + 8 * (g >> 1);
+  char* px = Cb + (p.c_off + (long)(rbase + ml0 - (l15 & 8)) * p.ldc + colx) * 2;       // row base + (l15 & 7) of strip 0
+  char* py = px + 16L * p.ldc;                                                            // 8 rows further (x 2 bytes)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    uint2 o[NT];
+    epilogue_strip<NT, ACT, true, false, ELS>(acc[i], p, Cb, own0 + i * step, nb, g, true, rbase + ml0 + i * 16, bias, lut, nullptr, false, els,
+                                              ecol0, erow0 + i * 16, o);
+    uint32_t q[2][4];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const auto a = __builtin_amdgcn_permlane16_swap(o[2 * pp].x, o[2 * pp + 1].x, false, false);
+      const auto b = __builtin_amdgcn_permlane16_swap(o[2 * pp].y, o[2 * pp + 1].y, false, false);
+      q[pp][0] = a[0]; q[pp][1] = b[0]; q[pp][2] = a[1]; q[pp][3] = b[1];
+    }
+    uint32_t x[4], y[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      x[d] = __builtin_amdgcn_update_dpp(q[0][d], q[1][d], 0x128, 0xf, 0xc, false);   // lanes 8-15 of a row: pair 1 of row l15 - 8
+      y[d] = __builtin_amdgcn_update_dpp(q[1][d], q[0][d], 0x128, 0xf, 0x3, false);   // lanes 0-7: pair 0 of row l15 + 8
+    }
+    *(uint4*)(px + i * step * 2) = make_uint4(x[0], x[1], x[2], x[3]);
+    *(uint4*)(py + i * step * 2) = make_uint4(y[0], y[1], y[2], y[3]);
+#pragma unroll
+    for (int j = 4; j < NT; ++j) *(uint2*)(Cb + (own0 + i * step + nb + j * 16 + g * 4) * 2) = o[j];
   }
 }
 // The strips of one wave's part of a tile: rows ml0 + 16 i (i < MI); the bf16 residual is requested one strip ahead.
@@ -1054,7 +1097,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
       const int erow0 = e_wm * (BM2 / 2) + e_l15;
-      if (res_init)
+      // full tiles (TA355_GEMM_DEBUG bit 11 switches this off): row-merged stores
+      const bool full = OUT_BF16 && wide && p.c_plain && (!HAS_RES || res_init) && ACT != 6 && cur.m0 + BM2 <= cur.Mact && cur.n0 + BN2 <= p.N &&
+                        !(p.dbg & 2048);
+      if constexpr (OUT_BF16 && ACT != 6) {
+        if (full) epilogue_tile_full<MI, NT, ACT, true>(acc, p, Cb, cur.m0 + erow0, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g, cur.biasp, lut, els, cur.n0, erow0);
+      }
+      if (full) { }
+      else if (res_init)
         epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, true>(acc, p, Cb, cur.m0 + erow0, cur.Mact, cur.rbase, cur.n0 + e_wn * (BN2 / 4), e_g,
                                                              wide, cur.biasp, lut, els, cur.n0, erow0);
       else
