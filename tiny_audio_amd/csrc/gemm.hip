@@ -125,13 +125,13 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 // residual taken as the accumulators' start value -- the encoder's epilogues wait for no global load at all.
 #define EPI_LDS_BIAS 0        /* float[BN2]: the tile's bias columns (clamped into the matrix) */
 #define EPI_LDS_TAB 2048      /* GELU: the chord table (8 KB); rope: BM2 rows x 128 B, 16-B chunk c of local row r at slot c ^ (r & 7) */
-// (Round 3, built, measured and removed: ROW-MERGED stores -- the two 32-column pairs of a strip exchanged once more between lane l15
+// (Round 3, FIRST attempt at row-merged stores, built, measured and removed -- the form that stayed is epilogue_tile_full below.  The two 32-column pairs of a strip exchanged once more between lane l15
 // and l15 ^ 8 with DPP moves, so that an instruction stores rows 0-7 resp. 8-15 of the strip with 128 contiguous bytes per row (8
 // lines per instruction instead of 16 half lines), also with the 256x320 tile's columns re-mapped to 64 line-aligned columns + a
 // 16-column tail per wave.  Bit-identical.  Against the pair form of the SAME build it looked like -10 % per launch (fc1 on 256x256
 // tiles 236.6 -> 214.0 us); against the previous build of the library it is equal on the 256-column tiles and 0.3-0.8 ms per step
 // slower on 256x320 (profiles/r03_ad_gemm_lib_probe.txt, r03_ad_ab_store_merge_libs.txt): what the first comparison measured was the
-// slowdown of carrying both forms in one epilogue.  The store issue rate is not what the 11 k epilogue cycles of a tile are made of.)
+// slowdown of carrying both forms -- with per-strip row offsets and guards for every lane -- in one epilogue.)
 template <int NT> struct EpiPre { uint2 r[NT]; };
 // oret != nullptr (bf16 outputs): the strip's packed results are handed back instead of stored (epilogue_tile_full stores them)
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
