@@ -351,10 +351,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
 // the accumulators in EVERY tile variant, not an addend of the epilogue: the sum is then fl(..fl(fl(r + a0 w0) + a1 w1)..) + b
 // whatever tile the launch-time model picks (the B = 32 step and the same clips at B = 4 run different variants and are compared
 // in the tests), and the kernels' epilogues have no residual load left to wait for.  Loads in batches of <= 4 strips.
-// TA355_GEMM_RES_INIT=0 (p.dbg bit 4): the r02 form, residual added in the epilogue.
+// TA355_GEMM_RES_INIT=0 (p.dbg bit 20): the r02 form, residual added in the epilogue.
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ bool residual_is_start(const GemmArgs& p) {
-  return HAS_RES && ACT == 0 && OUT_BF16 && p.res_bf16 && p.splits == 1 && !(p.dbg & 16);
+  return HAS_RES && ACT == 0 && OUT_BF16 && p.res_bf16 && p.splits == 1 && !(p.dbg & (1 << 20));
 }
 template <int MI, int NT>
 __device__ __forceinline__ void residual_start(f32x4 (*acc)[NT], const GemmArgs& p, int ml0, int Mact, int rbase, int nb, int g) {
@@ -1825,7 +1825,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     const char* gl = getenv("TA355_GELU_LUT");            // 0 = arithmetic erf-GELU in the ping-pong kernel's epilogue (A/B, tests)
     if (gl && *gl == '0') a.dbg |= 8;
     const char* ri = getenv("TA355_GEMM_RES_INIT");       // 0 = the ping-pong kernel adds a bf16 residual in its epilogue (A/B)
-    if (ri && *ri == '0') a.dbg |= 16;
+    if (ri && *ri == '0') a.dbg |= 1 << 20;     // (bits 4-6 of TA355_GEMM_DEBUG select the v5 experiments below: this flag sat on bit 4 and turned them on)
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
   // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
@@ -1879,7 +1879,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     if constexpr (ACT == 0) TA_LAUNCH((gemm_nt_kernel_v6<OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   }
   else if (variant == 10) {
-    const int ex = a.dbg >> 4;                                  // TA355_GEMM_DEBUG = 16 * EXP (plain bf16 GEMMs only)
+    const int ex = (a.dbg >> 4) & 7;                            // TA355_GEMM_DEBUG = 16 * EXP (plain bf16 GEMMs only)
     if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) {
       if (ex == 1) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 1>), dim3(grid), dim3(256), 0, st, a);
       else if (ex == 2) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 2>), dim3(grid), dim3(256), 0, st, a);
