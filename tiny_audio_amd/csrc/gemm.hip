@@ -255,7 +255,8 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
 // one instruction then stores rows 0-7 of the strip and the next rows 8-15, 128 contiguous bytes per row.  Fragments beyond the
 // first four (the 16-column tail of a 320-column tile) go out as before.  40.89 -> 40.60 ms per step against the previous library
 // (profiles/r03_ag_ab_store_merge_full_tiles.txt).  Re-mapping the 320-column tile's waves to 64 LINE-ALIGNED columns + a tail (three of
-// the four waves' 128-B runs straddle two lines here) added nothing on top: 40.02 vs 39.98 ms (r03_ah_..._cmap.txt); not kept.
+// the four waves' 128-B runs straddle two lines here) added nothing on top: 40.02 vs 39.98 ms (r03_ah_..._cmap.txt); not kept.  The same
+// full-tile form in the one-tile-per-CU kernel (v5) and in v2 (LoRA K extension): no measurable change (r03_am_...); not kept either.
 template <int MI, int NT, int ACT, bool ELS>
 __device__ __forceinline__ void epilogue_tile_full(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int rbase, int nb, int g,
                                                    const float* bias, const float2* lut, const char* els, int ecol0, int erow0) {
