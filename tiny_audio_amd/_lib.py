@@ -10,6 +10,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import glob
 import os
 import re
 import shutil
@@ -20,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
-SOURCES = ["gemm.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
+SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
            "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "api.hip"]
 
 
@@ -132,7 +133,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     Sources are compiled to objects in parallel (csrc/build/, only those older than their inputs) and then linked."""
     from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "host_util.h"), HEADER]
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [HEADER]      # every header (ADVICE r3: gelu_lut.h / logmel_twiddles.h were missing)
     deps = srcs + hdrs
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
@@ -144,13 +145,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # attention_enc.hip: no NaN can reach its row maxima (scores are finite MFMA sums; masked keys are -1e30, not -inf), and
     # without this every fmaxf on an MFMA result is preceded by a canonicalising v_max_f32 x, x (12 extra VALU per key tile)
     extra = {"attention_enc.hip": ["-fno-honor-nans"]}
+    # gemm_v7.hip keeps its accumulators in AGPRs on purpose (inline-assembly MFMAs with "+a" operands)
+    no_vgpr_form = {"gemm_v7.hip"}
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
             return obj, None
-        cmd = [hipcc_path(), *flags, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        fl = [f for f in flags if os.path.basename(src) not in no_vgpr_form or f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")]
+        cmd = [hipcc_path(), *fl, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
