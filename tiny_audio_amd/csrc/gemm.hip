@@ -1334,6 +1334,16 @@ static int pick_variant(int M, int N, int K, int splits) {
     const double t = (double)((tiles + 255) / 256) * 192.0 * 256.0 / r12;
     if (r12 > 0.0 && t < best_t) { best_t = t; best = 12; }
   }
+  // gemm_v7.hip (one wave per SIMD, AGPR accumulators) instead of the ping-pong kernel on the same tile, per shape family:
+  // TA355_V7_MASK bits: 1 N = 1280 (o_proj / fc2 / conv2), 2 N = 3840 (q|k|v), 4 N = 5120 (fc1), 8 other 256x320, 16 the 192x256 tile, 32 256x256
+  {
+    static const int v7m = [] { const char* v = getenv("TA355_V7_MASK"); return v && *v ? atoi(v) : 0; }();
+    if (v7m) {
+      if (best == 4) { const int bit = N == 1280 ? 1 : (N == 3840 ? 2 : (N == 5120 ? 4 : 8)); if (v7m & bit) best = 14; }
+      else if (best == 12 && (v7m & 16)) best = 15;
+      else if (best == 3 && (v7m & 32)) best = 13;
+    }
+  }
   // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
   static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
   if (ring && (best == 3 || best == 4)) best += 3;

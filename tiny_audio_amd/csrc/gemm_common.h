@@ -115,6 +115,9 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 // tiles 236.6 -> 214.0 us); against the previous build of the library it is equal on the 256-column tiles and 0.3-0.8 ms per step
 // slower on 256x320 (profiles/r03_ad_gemm_lib_probe.txt, r03_ad_ab_store_merge_libs.txt): what the first comparison measured was the
 // slowdown of carrying both forms -- with per-strip row offsets and guards for every lane -- in one epilogue.)
+#ifndef TA355_GELU_ALWAYS_LUT
+#define TA355_GELU_ALWAYS_LUT 0     /* gemm_v7.hip: 1 -- its table is always staged, the arithmetic form is not compiled in */
+#endif
 template <int NT> struct EpiPre { uint2 r[NT]; };
 // oret != nullptr (bf16 outputs): the strip's packed results are handed back instead of stored (epilogue_tile_full stores them)
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
@@ -170,7 +173,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     }
     if (bias) { v[0] += bq[j].x; v[1] += bq[j].y; v[2] += bq[j].z; v[3] += bq[j].w; }
     if (BASE == 1) {
-      if (lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
+      if (TA355_GELU_ALWAYS_LUT || lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
       else { v[0] = gelu_erf_fast(v[0]); v[1] = gelu_erf_fast(v[1]); v[2] = gelu_erf_fast(v[2]); v[3] = gelu_erf_fast(v[3]); }
     }
     if (BASE == 2) {

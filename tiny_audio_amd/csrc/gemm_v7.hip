@@ -27,11 +27,13 @@
 //   results are bit-identical to the other tiles.
 // Not served here (the launch falls back): gathered A rows, grouped launches, the K extension, blocked W, K ranges, fewer than
 // four k-steps per tile, the folded-LayerNorm / fused-SwiGLU epilogues.
+#define TA355_GELU_ALWAYS_LUT 1
 #include "gemm_common.h"
 #include <type_traits>
 
 #define V7_NS 4                     /* ring stages */
 #define V7_LUT_BYTES (GELU_LUT_N * 8)
+#define V7_BIAS_BYTES 768        /* per wave: the bias of its <= 160 columns (+ 32 floats the clamped reads of a ragged tile may touch) */
 
 template <int N> __device__ __forceinline__ void v7_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -51,9 +53,9 @@ template <int NT, int PIN> __device__ __forceinline__ void v7_pin_strip(f32x4* a
   for (int j = 0; j < NT; ++j)
     if (j < PIN) asm volatile("" : "+a"(a[j]));
 }
-template <int MI, int NT, int ACT, int PIN>
+template <int MI, int NT, int ACT, int PIN, bool ELS>
 __device__ __forceinline__ void v7_epilogue_full(f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int rbase, int nb, int g,
-                                                 const float* bias, const float2* lut) {
+                                                 const float* bias, const float2* lut, const char* els, int ecol0) {
   static_assert(NT % 2 == 0, "pairs of fragments");
   const int l15 = ml0 & 15;
   const long own0 = p.c_off + (long)(rbase + ml0) * p.ldc;
@@ -65,9 +67,8 @@ __device__ __forceinline__ void v7_epilogue_full(f32x4 (*acc)[NT], const GemmArg
   for (int i = 0; i < MI; ++i) {
     uint2 o[NT];
     v7_pin_strip<NT, PIN>(acc[i]);
-    epilogue_strip<NT, ACT, true, false, false>(acc[i], p, Cb, own0 + i * step, nb, g, true, rbase + ml0 + i * 16, bias, lut, nullptr, false,
-                                                nullptr, 0, 0, o);
-    __builtin_amdgcn_sched_barrier(0);                           // (strip by strip: the accumulators leave their AGPRs one strip at a time)
+    epilogue_strip<NT, ACT, true, false, ELS>(acc[i], p, Cb, own0 + i * step, nb, g, true, rbase + ml0 + i * 16, bias, lut, nullptr, false,
+                                              els, ecol0, 0, o);
 #pragma unroll
     for (int q4 = 0; q4 + 3 < NT; q4 += 4) {
       uint32_t q[2][4];
@@ -140,8 +141,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
   constexpr int NQ = NJ0 / 4;                                      // the AGPR columns in groups of four (64 output columns = one 128-B line of bf16)
   static_assert(NJ0 % 4 == 0, "quads");
   constexpr bool GELU = ACT == 1;
-  static_assert(V7_NS * STAGE + V7_LUT_BYTES <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) char smem[V7_NS * STAGE + V7_LUT_BYTES];
+  constexpr int LUT_BYTES = GELU ? V7_LUT_BYTES : 0;
+  constexpr bool ELS = ACT != 2;                                   // bias through LDS (rope keeps its table in global memory: 32 KB per tile)
+  static_assert(V7_NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[V7_NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -157,11 +160,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
   const int b_rd = PA * 1024 + wn * (NJ * 1024) + rd;
   const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
 
-  if (GELU && !(p.dbg & 8)) {                                    // the chord table of the erf-GELU epilogue, once per workgroup
+  if (GELU) {                                                    // the chord table of the erf-GELU epilogue, once per workgroup
     for (int i = tid; i < V7_LUT_BYTES / 16; i += 256) ((uint4*)(smem + V7_NS * STAGE))[i] = ((const uint4*)kGeluLut)[i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (published by the first barrier below)
   }
-  const float2* lut = (GELU && !(p.dbg & 8)) ? (const float2*)(smem + V7_NS * STAGE) : nullptr;
+  const float2* lut = GELU ? (const float2*)(smem + V7_NS * STAGE) : nullptr;
+  char* bias_lds = smem + V7_NS * STAGE + LUT_BYTES + wave * V7_BIAS_BYTES;   // wave-private: no barrier around it
 
   // ---- DMA side: THREE k-steps ahead of the MFMAs.  Inside a tile the two base pointers step by 64 B per k-step; when the MFMAs
   //      stand three k-steps before a tile's end, the DMA side moves to the workgroup's next tile (dma_setup) -- host: every tile has
@@ -298,23 +302,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
       char* Cb = (char*)p.C;
       if (p.splits > 1) Cb += (long)cur.z * p.slab_stride * 4;
       const bool wide = epilogue_wide_ok(p);
+      // One wave per SIMD: nobody hides a load's latency here.  The wave's bias columns come from global memory ONCE per tile (one
+      // round trip) into its private LDS row; the strips read them with ds_read_b128 (the per-strip bias loads of the shared epilogue
+      // cost 24 L2 round trips per tile: o_proj 12.6 us of epilogue against 7 for the ping-pong kernel)
+      if (ELS && cur.biasp) {
+        if (ln < BN7 / 2 / 4 + 8) {
+          const int n = col0 + 4 * ln;
+          *(float4*)(bias_lds + ln * 16) = *(const float4*)(cur.biasp + (n < p.N ? n : p.N - 4));
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       const bool full = OUT_BF16 && wide && p.c_plain && (!HAS_RES || res_init) && cur.m0 + BM7 <= cur.Mact && cur.n0 + BN7 <= p.N &&
                         !(p.dbg & 2048);
       auto part = [&](auto* acc, auto nt_tag, auto pin_tag, int nb) {   // one column group of the wave's tile
         constexpr int NT = decltype(nt_tag)::value, PIN = decltype(pin_tag)::value;
         if constexpr (OUT_BF16) {
-          if (full) v7_epilogue_full<MI, NT, ACT, PIN>(acc, p, Cb, row0, cur.rbase, nb, e_g, cur.biasp, lut);
+          if (full) v7_epilogue_full<MI, NT, ACT, PIN, ELS>(acc, p, Cb, row0, cur.rbase, nb, e_g, cur.biasp, lut, bias_lds, col0);
         }
         if (full) { }
-        else if (res_init) epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, false, PIN>(acc, p, Cb, row0, cur.Mact, cur.rbase, nb, e_g, wide, cur.biasp, lut);
-        else epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, 0, false, PIN>(acc, p, Cb, row0, cur.Mact, cur.rbase, nb, e_g, wide, cur.biasp, lut);
+        else if (res_init) epilogue_tile<MI, NT, ACT, OUT_BF16, false, 0, ELS, PIN>(acc, p, Cb, row0, cur.Mact, cur.rbase, nb, e_g, wide, cur.biasp, lut, bias_lds, col0, 0);
+        else epilogue_tile<MI, NT, ACT, OUT_BF16, HAS_RES, 0, ELS, PIN>(acc, p, Cb, row0, cur.Mact, cur.rbase, nb, e_g, wide, cur.biasp, lut, bias_lds, col0, 0);
       };
       if constexpr (NJ1 > 0) part(acc1, std::integral_constant<int, NJ1>{}, std::integral_constant<int, 0>{}, col0 + 16 * NJ0);   // (first: frees its VGPRs)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         part(acc0[q], std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, col0 + 64 * q);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (!more) break;
