@@ -62,7 +62,7 @@ def apply_logits_processors(scores, seq, repetition_penalty=1.0, no_repeat_ngram
 
 
 def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False, repetition_penalty=1.0,
-                    no_repeat_ngram_size=0):
+                    no_repeat_ngram_size=0, processors_see_prompt=True):
     """-> generated token ids [B, n_new] (prompt stripped), n_new <= max_new_tokens.  The prompt must be unpadded
     (attention_mask all ones), which is what ASRModel.generate builds.  ``return_margins`` also returns the
     top-1 minus top-2 logit gap of every decision (how robust the argmax is to bf16 rounding)."""
@@ -78,7 +78,10 @@ def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, ret
                                      lora=W.get("lora"), lora_scale=cfg.get("lora_scale", 0.0))
         last = logits[:, -1].astype(np.float32)
         if repetition_penalty != 1.0 or no_repeat_ngram_size > 0:
-            seq = np.concatenate([np.asarray(batch["input_ids"], np.int64)] + [o[:, None] for o in out], axis=1)
+            # processors_see_prompt=False: the reference's generate_streaming hands language_model.generate inputs_embeds WITHOUT
+            # input_ids (tiny_audio/asr_modeling.py:723-729), so HF starts from an empty id sequence: generated tokens only
+            head = [np.asarray(batch["input_ids"], np.int64)] if processors_see_prompt else [np.zeros((B, 0), np.int64)]
+            seq = np.concatenate(head + [o[:, None] for o in out], axis=1)
             last = apply_logits_processors(last, seq, repetition_penalty, no_repeat_ngram_size)
         nxt = last.argmax(-1)
         srt = np.sort(last, axis=-1)

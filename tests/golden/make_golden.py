@@ -469,9 +469,33 @@ def gen_generate_penalties():
     model.generation_config.eos_token_id = [SMALL["eos_id"], SMALL["pad_id"]]
     model.generation_config.pad_token_id = SMALL["pad_id"]
     out = {}
+    # round 4: generate_streaming calls language_model.generate with inputs_embeds ONLY (tiny_audio/asr_modeling.py:
+    # 723-729), so HF's processors see the generated tokens alone there.  Its call is reproduced on the arguments the reference's own
+    # generate() hands to the LM (captured below), minus input_ids: tokens_stream_*.
+    lm_generate = model.language_model.generate
+    seen = {}
+
+    def spy(*a_, **k_):
+        seen.clear(); seen.update(k_)
+        return lm_generate(*a_, **k_)
+    model.language_model.generate = spy
     for name, g in (("plain", {}), ("rep", dict(repetition_penalty=1.3)), ("ngram", dict(no_repeat_ngram_size=2)),
                     ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2)), ("rep_strong", dict(repetition_penalty=5.0))):
         out["tokens_" + name] = model.generate(**kw, max_new_tokens=16, **g).numpy()
+        k2 = {k: v for k, v in seen.items() if k != "input_ids"}
+        out["tokens_stream_" + name] = lm_generate(**k2).numpy()
+    # a prompt that CONTAINS the tokens the model likes to emit: only there do the two modes part (a penalty over prompt + generated
+    # tokens moves the first decisions, a penalty over the generated tokens alone does not)
+    ids2 = ids.copy()
+    ids2[:, -4:-1] = out["tokens_plain"][0, :3]
+    kw2 = dict(kw, input_ids=t(ids2))
+    for name, g in (("rep", dict(repetition_penalty=1.3)), ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2))):
+        out["tokens2_" + name] = model.generate(**kw2, max_new_tokens=16, **g).numpy()
+        k2 = {k: v for k, v in seen.items() if k != "input_ids"}
+        out["tokens2_stream_" + name] = lm_generate(**k2).numpy()
+        assert (out["tokens2_" + name] != out["tokens2_stream_" + name]).any(), "the streaming fixture must discriminate the two modes"
+    out["input_ids2"] = ids2
+    model.language_model.generate = lm_generate
     save("generate_penalties_small.npz", input_features=feats, audio_attention_mask=amask, input_ids=ids, n_audio=np.array(n_audio), **out)
     print("generate penalties:", {k: v.tolist() for k, v in out.items()})
 

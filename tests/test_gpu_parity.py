@@ -489,7 +489,7 @@ def test_mosa_projector_true_width():
 
 
 # ============================================================================ greedy generation (section 8(f) rank 1)
-def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12, **processors):
+def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12, processors_see_prompt=True, **processors):
     """Greedy parity that is robust to bf16 near-ties: feed the HIP path's OWN tokens to the fp32 oracle and require
     every decision to be the oracle's argmax or within `tol` logits of it (bf16 logits carry ~0.03 of rounding);
     pad-after-EOS and the stopping rule are checked exactly."""
@@ -504,7 +504,7 @@ def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.1
         logits, _ = OQ.lm_forward(x, np.ones(x.shape[:2], np.int64), W["lm"], cfg["lm"], keep_cache=False)
         last = logits[:, -1]
         if processors:
-            seq = np.concatenate([np.asarray(batch["input_ids"], np.int64), tokens[:, :t]], axis=1)
+            seq = np.concatenate([np.asarray(batch["input_ids"], np.int64), tokens[:, :t]], axis=1) if processors_see_prompt else tokens[:, :t]
             last = OG.apply_logits_processors(last.astype(np.float32), seq, **processors)
         for b in range(B):
             if not unfinished[b]:
@@ -584,6 +584,34 @@ def test_generate_with_repetition_penalty_and_no_repeat_ngram(golden):
     m.config.repetition_penalty = 1.3                            # the setting may also come from the config (asr_config.py:155-160)
     out_cfg = m.generate(**kw, max_new_tokens=16).cpu().numpy()
     assert np.array_equal(out_cfg, m.generate(**kw, max_new_tokens=16, repetition_penalty=1.3).cpu().numpy())
+
+
+def test_generate_streaming_penalties_see_generated_tokens_only(golden):
+    """the reference's generate_streaming gives HF inputs_embeds without input_ids, so its repetition / n-gram processors
+    never see the prompt; generate() does.  Fixture: a prompt that contains the model's favourite tokens (the two modes part from
+    the first decision on), tokens from the reference's own LM call in both modes."""
+    g = golden("generate_penalties_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    wE, wL, wP = OW.init_encoder(S["enc"], 0), R.gen_lm_weights(), OW.init_mlp_projector(E, D, H)
+    m = build_model(S["enc"], S["lm"], H, wE, wL, wP, audio_token_id=S["audio_token_id"], pad_token_id=S["pad_id"],
+                    eos_token_id=S["eos_id"])
+    W = dict(encoder=wE, lm=wL, projector=wP)
+    cfg = dict(enc=S["enc"], lm=S["lm"], projector_type="mlp", k=S["k"], audio_token_id=S["audio_token_id"])
+    for name, opts in (("rep", dict(repetition_penalty=1.3)), ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2))):
+        full = m.generate(input_ids=torch.from_numpy(g["input_ids2"]), input_features=torch.from_numpy(g["input_features"]),
+                          audio_attention_mask=torch.from_numpy(g["audio_attention_mask"]),
+                          attention_mask=torch.ones(g["input_ids2"].shape, dtype=torch.int64), max_new_tokens=16, **opts).cpu().numpy()
+        assert (full[:, :2] == g["tokens2_" + name][:, :2]).all(), name
+        for b in range(2):                                   # streaming: one clip at a time
+            toks = list(m.generate_streaming(torch.from_numpy(g["input_features"][b:b + 1]), torch.from_numpy(g["audio_attention_mask"][b:b + 1]),
+                                             input_ids=torch.from_numpy(g["input_ids2"][b:b + 1]), return_token_ids=True,
+                                             max_new_tokens=16, **opts))
+            got = np.array(toks, dtype=np.int64)[None, :]
+            want = g["tokens2_stream_" + name][b:b + 1]
+            assert (got[:, :2] == want[:, :2]).all() and (got[:, :2] != g["tokens2_" + name][b:b + 1, :2]).any(), (name, b, got, want)
+            batch = dict(input_ids=g["input_ids2"][b:b + 1], input_features=g["input_features"][b:b + 1])
+            _check_greedy_against_oracle(got, batch, W, cfg, (S["eos_id"], S["pad_id"]), S["pad_id"], processors_see_prompt=False, **opts)
 
 
 def test_logits_process_kernel_vs_oracle():

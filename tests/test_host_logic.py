@@ -544,6 +544,29 @@ def test_causal_lm_output_is_model_output_shaped():
         o3.hidden_states
 
 
+def test_causal_lm_output_rebuilds_from_a_mapping_as_accelerate_does():
+    """under bf16=True accelerate wraps model.forward in convert_to_fp32, whose recursively_apply rebuilds every Mapping
+    as type(data)({k: f(v)}) -- ModelOutput.__init__ accepts that; so must this class (it used to put the dict under 'loss')."""
+    import copy
+    import pickle
+    from accelerate.utils import convert_to_fp32, send_to_device
+    from tiny_audio_amd.asr_modeling import CausalLMOutput
+    o = CausalLMOutput(loss=torch.tensor(1.5), logits=torch.zeros(2, 3, 8, dtype=torch.bfloat16), nll=torch.ones(3), n_label_tokens=3,
+                       loss_ce=torch.tensor(1.5))
+    r = convert_to_fp32(o)
+    assert type(r) is CausalLMOutput and list(r.keys()) == ["loss", "logits"]
+    assert torch.is_tensor(r["loss"]) and float(r["loss"]) == 1.5 and r.logits.dtype == torch.float32 and r[0] is r.loss
+    assert send_to_device(o, "cpu").logits.shape == (2, 3, 8)
+    same = type(o)(o)                                    # a rebuild from the output itself keeps the attribute extras
+    assert same.n_label_tokens == 3 and same.nll is o.nll and float(same.loss_ce) == 1.5
+    plain = type(o)(dict(o))                             # from a plain dict they cannot travel: None, not an error
+    assert plain.loss is o.loss and plain.n_label_tokens is None
+    for c in (copy.copy(o), copy.deepcopy(o), pickle.loads(pickle.dumps(o))):
+        assert type(c) is CausalLMOutput and c.n_label_tokens == 3 and float(c.loss) == 1.5 and c.logits.shape == (2, 3, 8)
+    with pytest.raises(KeyError):
+        CausalLMOutput({"loss": torch.tensor(0.0), "hidden_states": 1})
+
+
 def test_hf_label_names_are_just_labels():
     """HF Trainer derives label_names from the forward signature (every parameter whose name contains "label"); a second such
     parameter made Trainer.predict treat the batches as unlabelled (round 3: label_meta now travels through **kwargs)."""

@@ -228,6 +228,14 @@ def test_greedy_generate_with_logits_processors(golden):
                        ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2)), ("rep_strong", dict(repetition_penalty=5.0))):
         np.testing.assert_array_equal(OG.greedy_generate(batch, W, cfg, **kw, **opts), g["tokens_" + name], err_msg=name)
     assert not np.array_equal(g["tokens_plain"], g["tokens_rep"]) and not np.array_equal(g["tokens_plain"], g["tokens_ngram"])
+    # round 4: the streaming call (inputs_embeds only: the processors see the generated tokens alone), on a prompt that contains the
+    # model's favourite tokens -- the one case where the two modes part
+    batch2 = dict(batch, input_ids=g["input_ids2"])
+    for name, opts in (("rep", dict(repetition_penalty=1.3)), ("both", dict(repetition_penalty=1.3, no_repeat_ngram_size=2))):
+        np.testing.assert_array_equal(OG.greedy_generate(batch2, W, cfg, **kw, **opts), g["tokens2_" + name], err_msg=name)
+        np.testing.assert_array_equal(OG.greedy_generate(batch2, W, cfg, **kw, **opts, processors_see_prompt=False),
+                                      g["tokens2_stream_" + name], err_msg="stream " + name)
+        assert not np.array_equal(g["tokens2_" + name], g["tokens2_stream_" + name])
     for row in g["tokens_ngram"]:                            # the property itself: no bigram occurs twice in prompt + output
         seq = list(g["input_ids"][0]) + list(row)
         big = list(zip(seq[len(g["input_ids"][0]) - 1:-1], seq[len(g["input_ids"][0]):]))

@@ -10,6 +10,7 @@ There is no CPU path: without libta355.so / a GPU every entry point raises.
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
 from typing import Iterator, Optional
 
 import torch
@@ -36,6 +37,14 @@ class CausalLMOutput(dict):
 
     def __init__(self, loss=None, logits=None, nll=None, n_label_tokens=None, aux_loss=None, loss_ce=None):
         super().__init__()
+        if isinstance(loss, Mapping):                 # ModelOutput.__init__ accepts a mapping as its first argument, and library code
+            src = loss                                # rebuilds outputs that way: accelerate's convert_to_fp32 / send_to_device do
+            loss, logits = src.get("loss"), src.get("logits")     # type(data)({k: f(v) ...}) around model.forward under bf16=True
+            unknown = [k for k in src if k not in self._items]
+            if unknown:
+                raise KeyError(f"CausalLMOutput has no item {unknown[0]!r}")
+            if isinstance(src, CausalLMOutput):       # (a rebuild from a plain dict cannot carry the attribute extras: they become None)
+                nll, n_label_tokens, aux_loss, loss_ce = src.nll, src.n_label_tokens, src.aux_loss, src.loss_ce
         for k, v in (("loss", loss), ("logits", logits)):
             if v is not None:
                 dict.__setitem__(self, k, v)
@@ -54,6 +63,9 @@ class CausalLMOutput(dict):
 
     def to_tuple(self):
         return tuple(self.values())
+
+    def __reduce__(self):                             # copy / pickle keep the extras
+        return (CausalLMOutput, (dict.get(self, "loss"), dict.get(self, "logits"), self.nll, self.n_label_tokens, self.aux_loss, self.loss_ce))
 
 
 def _is_cjk(ch: str) -> bool:
@@ -393,7 +405,9 @@ class ASRModel(nn.Module):
             eos = set(args["eos_ids"])
             pieces = _TextPieces(self.tokenizer) if not return_token_ids else None
             gate = _ThinkGate()
-            for col in self.language_model.greedy_decode_iter(per_token=True, **args):
+            # (the reference's streaming call passes inputs_embeds only, so HF's repetition / n-gram processors start from an empty
+            # input_ids there and see the generated tokens alone -- generate() passes the prompt ids as well)
+            for col in self.language_model.greedy_decode_iter(per_token=True, processors_see_prompt=False, **args):
                 if col.dim() != 1:                       # the closing full [B, n_new] tensor
                     break
                 tok = int(col[0])

@@ -486,7 +486,8 @@ class Qwen3MI355X(torch.nn.Module):
         return out
 
     def greedy_decode_iter(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
-                           sync_every=8, use_graph=True, per_token=True, repetition_penalty=1.0, no_repeat_ngram_size=0):
+                           sync_every=8, use_graph=True, per_token=True, repetition_penalty=1.0, no_repeat_ngram_size=0,
+                           processors_see_prompt=True):
         """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
         config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
         emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
@@ -544,7 +545,9 @@ class Qwen3MI355X(torch.nn.Module):
 
         def advance():
             if rep != 1.0 or ngram > 0:            # HF logits processors over prompt ids + generated tokens (device-side, graph-safe)
-                _lib.check(L_.ta_logits_process(ptr(logits), self.vocab_pad, c.vocab_size, ptr(ids), L, ptr(out_seq), max_new,
+                # processors_see_prompt=False: the generated tokens only -- what HF's processors see when generate() is given
+                # inputs_embeds WITHOUT input_ids (the reference's generate_streaming, tiny_audio/asr_modeling.py:723-729)
+                _lib.check(L_.ta_logits_process(ptr(logits), self.vocab_pad, c.vocab_size, ptr(ids), L if processors_see_prompt else 0, ptr(out_seq), max_new,
                                                 ptr(step_dev), B, rep, ngram, stream()), "ta_logits_process")
             _lib.check(L_.ta_argmax_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, ptr(amax), stream()), "ta_argmax_f32")
             _lib.check(L_.ta_greedy_advance(ptr(amax), ptr(eos), n_eos, int(pad_id), ptr(finished), ptr(next_ids), ptr(out_seq),
