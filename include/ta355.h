@@ -380,8 +380,14 @@ int ta_gemm_bf16_tn(const void* Y, const void* X, float* out, int M, int Ny, int
                     hipStream_t st);
 /* in-situ GEMM timing for bench.py's roofline leg: HIP events on the launch stream around every GEMM kernel.
  * collect(): host pointers; sums + clears the records (total kernel ms, total 2*M*N*K flops, launches). */
-int ta_profile_gemm(int enable);
+int ta_profile_gemm(int enable);   /* 0 off, 1 time every launch (collect below), 2 log every launch's shape (ta_profile_gemm_log) */
 int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launches);
+/* round 4: the launches since ta_profile_gemm(2) as rows of 24 longs {M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, act,
+ * out_bf16, has_residual, residual_bf16, has_bias, splits, rope_cols, rope_rows, flags, K2, tile variant, groups, lnf mode,
+ * persistent} (flags: 1 gather, 2 segments, 4 K range, 8 K extension, 16 blocked W, 32 grouped, 64 LayerNorm fold, 128 SwiGLU
+ * backward, 256 / 512 identity A / C row map).  Host memory; returns the row count (out may be NULL).  The step-shape parity test
+ * (tests/test_gpu_round4.py) runs one real B = 32 step under it and replays every distinct launch against an fp32 matmul. */
+long ta_profile_gemm_log(long* out, long max_rows);
 
 int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
                      const float* rowscale, int M, int H, float eps, hipStream_t st);

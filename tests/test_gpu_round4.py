@@ -159,3 +159,129 @@ def test_v7_unserved_launches_fall_back():
     with variant(14):
         y = ops.gemm_nt(A, W, out_dtype=F32, k_ext=(A2, W2))
     assert relerr(y, A.float() @ W.float().T + A2.float() @ W2.float().T) < 2e-3
+
+
+# ============================================================================ the step's own GEMM launches, recorded and replayed
+# (the hand-kept STEP_GEMMS list of round 3 went stale in the round it was written -- the encoder's q|k|v launch
+# with rope_cols = 2560 was in the step and not in the list.)  ta_profile_gemm(2) logs every launch of ONE real B = 32 training step
+# (shape, row maps, epilogue instantiation, split count, the tile variant the launch-time model chose); every distinct record is
+# replayed here against an fp32 matmul UNDER THE RECORDED VARIANT.
+LOG_FIELDS = ("M", "N", "K", "lda", "a_rpb", "a_bs", "ldc", "c_rpb", "c_bs", "c_off", "act", "out_bf16", "has_res", "res_bf16", "has_bias",
+              "splits", "rope_cols", "rope_rows", "flags", "K2", "variant", "groups", "lnf_mode", "persistent")
+
+
+def _gemm_log():
+    import ctypes as C
+    from tiny_audio_amd import _lib
+    L = _lib.lib()
+    fn = L.ta_profile_gemm_log
+    n = fn(None, 0)
+    buf = (C.c_long * (n * len(LOG_FIELDS)))()
+    fn(C.cast(buf, C.c_void_p), n)
+    rows = [tuple(buf[i * len(LOG_FIELDS):(i + 1) * len(LOG_FIELDS)]) for i in range(n)]
+    return [dict(zip(LOG_FIELDS, r)) for r in rows]
+
+
+def _rows_index(M, ld, rpb, bs, off, width):
+    """element index of (logical row r, column c) under the affine row map: off + (r // rpb) * bs + (r % rpb) * ld + c"""
+    r = torch.arange(M, device=DEV, dtype=torch.int64)
+    base = off + (r // rpb) * bs + (r % rpb) * ld
+    return base[:, None] + torch.arange(width, device=DEV, dtype=torch.int64)[None, :]
+
+
+def _replay(rec):
+    M, N, K = rec["M"], rec["N"], rec["K"]
+    a_rpb = rec["a_rpb"] if rec["a_rpb"] < 2 ** 30 else M
+    c_rpb = rec["c_rpb"] if rec["c_rpb"] < 2 ** 30 else M
+    aidx = _rows_index(M, rec["lda"], a_rpb, rec["a_bs"], 0, K)
+    A = rnd(int(aidx.max()) + 1, seed=1, dtype=BF16)
+    W = rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)
+    ref = A[aidx].float() @ W.float().T
+    del aidx
+    odt = BF16 if rec["out_bf16"] else F32
+    kw = dict(a_map=(rec["lda"], 0 if a_rpb >= M else a_rpb, rec["a_bs"]), c_map=(rec["ldc"], 0 if c_rpb >= M else c_rpb, rec["c_bs"], rec["c_off"]))
+    bias = rnd(N, seed=3, scale=0.5) if rec["has_bias"] else None
+    cidx = _rows_index(M, rec["ldc"], c_rpb, rec["c_bs"], rec["c_off"], N)
+    c_len = int(cidx.max()) + 1
+    out = torch.zeros(c_len, device=DEV, dtype=odt)
+    want = ref + (bias if bias is not None else 0.0)
+    act = rec["act"]
+    if act == 1:
+        want = torch.nn.functional.gelu(want)
+    rope = None
+    if act == 2:
+        rows = rec["rope_rows"]
+        ang = torch.rand(rows, 16, device=DEV) * 6.283
+        tab = torch.stack([ang.cos(), ang.sin()], -1).contiguous()            # [rows, 16, 2] (cos, sin) of pair i at position m % rows
+        rope = (tab, rows, rec["rope_cols"])
+        y = want.clone()
+        pos = torch.arange(M, device=DEV) % rows
+        for h0 in range(0, rec["rope_cols"], 64):                           # pairs (2 i, 2 i + 1) of the first 32 columns of every 64-wide head
+            blk = want[:, h0:h0 + 32].reshape(M, 16, 2)
+            c, s_ = tab[pos, :, 0], tab[pos, :, 1]
+            y[:, h0:h0 + 32] = torch.stack([blk[..., 0] * c - blk[..., 1] * s_, blk[..., 1] * c + blk[..., 0] * s_], -1).reshape(M, 32)
+        want = y
+    res = None
+    if rec["has_res"]:
+        res = rnd(M, N, seed=4, dtype=BF16 if rec["res_bf16"] else F32)
+        want = want + res.float()
+    with variant(rec["variant"]):
+        if rec["has_res"] and rec["res_bf16"]:
+            flat = torch.zeros(c_len, device=DEV, dtype=BF16); flat[cidx] = res          # the residual shares C's row map
+            got = ops.gemm_nt(A, W, M, N, K, out=out if odt == BF16 else out, bias=bias, act=act, residual_bf16=flat, **kw)
+        elif rec["has_res"]:
+            flat = torch.zeros(c_len, device=DEV, dtype=F32); flat[cidx] = res
+            got = ops.gemm_nt(A, W, M, N, K, out=out, bias=bias, act=act, residual=flat, **kw)
+        else:
+            got = ops.gemm_nt(A, W, M, N, K, out=out, bias=bias, act=act, splits=rec["splits"], rope=rope, **kw)
+    tol = 1.5e-2 if rec["out_bf16"] else 2e-3
+    e = relerr(got.reshape(-1)[cidx], want)
+    assert e < tol, (rec, e)
+    return e
+
+
+def test_gemm_launches_of_a_real_b32_step_replayed_vs_fp32():
+    import ctypes as C  # noqa: F401
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.asr_processing import LogMelFeatureExtractor
+    from oracle import weights as OW
+    assert "TA355_GEMM_VARIANT" not in os.environ
+    torch.manual_seed(0)
+    cfg = ASRConfig(audio_token_dropout=0.0)
+    m = ASRModel(cfg, device=DEV, init="random", seed=0)
+    m.train()
+    B, Lq, V = 32, 192, cfg.text_config.vocab_size
+    g = torch.Generator(device=DEV); g.manual_seed(1234)
+    wav = 0.1 * torch.randn(B, 160000, device=DEV, generator=g)
+    feats, _ = LogMelFeatureExtractor(128, DEV).extract(wav, torch.full((B,), 160000, device=DEV, dtype=torch.int64))
+    ids, att, lab, counts = OW.synthetic_tokens(B, 125, V, cfg.audio_token_id, cfg.pad_token_id, cfg.eos_token_id, L=Lq)
+    T = torch.from_numpy
+    L_ = _lib.lib()
+    L_.ta_profile_gemm(2)
+    try:
+        out = m(input_ids=T(ids), input_features=feats, attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts),
+                return_logits=False, num_items_in_batch=36 * B)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        log = _gemm_log()
+    finally:
+        L_.ta_profile_gemm(0)
+    del m, out
+    torch.cuda.empty_cache()
+    assert len(log) > 300, len(log)                                   # 361 launches per step at the round-3 head
+    distinct = {}
+    for r in log:
+        distinct.setdefault(tuple(r[k] for k in LOG_FIELDS), r)
+    recs = list(distinct.values())
+    # the step must contain the launches round 3's hand-kept list missed, or this test is looking at the wrong thing
+    assert any(r["M"] == 16000 and r["N"] == 3840 and r["K"] == 1280 and r["act"] == 2 and r["rope_cols"] == 2560 for r in recs), "encoder q|k|v"
+    assert any(r["N"] == 151680 for r in recs) and any(r["K"] == 151680 for r in recs), "loss head and its dX"
+    served = [r for r in recs if not (r["flags"] & (1 | 2 | 4 | 8 | 16 | 32 | 64 | 128))]
+    assert len(served) == len(recs), [r for r in recs if r not in served]   # the MLP step has no gather / grouped / K-extension launch
+    worst = {}
+    for r in recs:
+        e = _replay(r)
+        worst[(r["M"], r["N"], r["K"], r["act"], r["variant"])] = e
+    print(f"[step GEMMs] {len(log)} launches, {len(recs)} distinct; worst relative error {max(worst.values()):.2e}")

@@ -1297,6 +1297,10 @@ namespace {
 struct ProfRec { hipEvent_t a, b; double flops; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
+// ta_profile_gemm(2): a log of every launch's shape, epilogue and chosen tile (no events): the step-shape parity test replays it
+#define TA_GEMM_LOG_FIELDS 24
+bool g_log_on = false;
+std::vector<long> g_log;
 }  // namespace
 
 // Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 5 = 96x128 (same kernel), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong,
@@ -1468,11 +1472,36 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
   else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
+  if (g_log_on) {
+    const long flags = (a.a_idx ? 1 : 0) | (a.seg ? 2 : 0) | (a.krange ? 4 : 0) | (a.A2 ? 8 : 0) | (a.w_blocked ? 16 : 0) | (a.grp_n > 0 ? 32 : 0) |
+                       (a.lnf_mode ? 64 : 0) | (a.sw_gu ? 128 : 0) | (a.a_plain ? 256 : 0) | (a.c_plain ? 512 : 0);
+    const long rec[TA_GEMM_LOG_FIELDS] = {a.M, a.N, a.K, a.lda, a.a_rpb, a.a_bs, a.ldc, a.c_rpb, a.c_bs, a.c_off, ACT, OUT_BF16 ? 1 : 0,
+                                          HAS_RES ? 1 : 0, a.res_bf16, a.bias ? 1 : 0, a.splits, a.rope_cols, a.rope_rows, flags, a.K2, variant,
+                                          a.grp_n, a.lnf_mode, persist ? 1 : 0};
+    g_log.insert(g_log.end(), rec, rec + TA_GEMM_LOG_FIELDS);
+  }
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
 
-extern "C" int ta_profile_gemm(int enable) { g_prof_on = enable != 0; return TA_OK; }
+extern "C" int ta_profile_gemm(int enable) {
+  g_prof_on = enable == 1;
+  g_log_on = enable == 2;
+  if (enable == 2) g_log.clear();
+  return TA_OK;
+}
+// the launches logged since ta_profile_gemm(2): rows of 24 longs {M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, act (the epilogue
+// instantiation: 0 none, 1 GELU, 2 rope, 3-6 the folded-LayerNorm / fused-SwiGLU forms), out_bf16, has_residual, residual_bf16,
+// has_bias, splits, rope_cols, rope_rows, flags (1 gather, 2 segments, 4 K range, 8 K extension, 16 blocked W, 32 grouped,
+// 64 LayerNorm fold, 128 SwiGLU backward, 256 / 512 identity A / C row map), K2, tile variant as launched, groups, lnf mode,
+// persistent}.  Returns the number of rows (at most max_rows are written; out may be NULL to count).
+extern "C" long ta_profile_gemm_log(long* out, long max_rows) {
+  const long n = (long)(g_log.size() / TA_GEMM_LOG_FIELDS);
+  if (out)
+    for (long i = 0; i < n && i < max_rows; ++i)
+      for (int f = 0; f < TA_GEMM_LOG_FIELDS; ++f) out[i * TA_GEMM_LOG_FIELDS + f] = g_log[i * TA_GEMM_LOG_FIELDS + f];
+  return n;
+}
 // sums (and clears) the recorded launches: total kernel milliseconds, total algorithmic flops (2*M*N*K), launch count
 extern "C" int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launches) {
   double ms = 0.0, fl = 0.0;
