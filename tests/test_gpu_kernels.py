@@ -354,6 +354,39 @@ def test_attention_bwd_with_fused_qkv_post(L, masked):
     assert torch.equal(got.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:], ref.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:])
 
 
+@pytest.mark.parametrize("L,masked,B", [(192, True, 2), (192, False, 5), (150, True, 3), (129, False, 2)])
+def test_attention_bwd_one_workgroup_per_kv_head(L, masked, B):
+    """Round 4: ta_attention_bwd_gqa (one workgroup per (clip, kv head): K / V resident in LDS, dK / dV of both query heads in AGPRs,
+    Delta computed inside, q|k|v post backward in the epilogue) against ta_attn_bwd_prep + ta_attention_bwd_qkv -- the same products
+    in the same accumulation order; only Delta's 128-term sum runs in another order -- and against the unfused chain."""
+    Hq, Hkv, hd = 4, 2, 128
+    NQKV = (Hq + 2 * Hkv) * hd
+    x0 = rnd(B * L, NQKV, seed=1).to(BF16)
+    qn, kn = 1 + 0.1 * rnd(hd, seed=2), 1 + 0.1 * rnd(hd, seed=3)
+    cos, sin = rope_tables(256, hd, 1e6)
+    Q, K, V, QT, KT, VT, rq, rk = ops.lm_qkv_post_fwd(x0, qn, kn, cos, sin, B, Hq, Hkv, L)
+    kmask = None
+    if masked:
+        kmask = torch.ones(B, L, dtype=torch.int32, device=DEV); kmask[1, L - 9:] = 0
+    scale = hd ** -0.5
+    O, lse = ops.attention_fwd(Q, K, VT, L, True, scale, kmask=kmask)
+    O_tok = O.transpose(1, 2).reshape(B * L, Hq * hd).contiguous() if O.dim() == 4 else O      # token-major [B*L, Hq*hd]
+    dO = rnd(B * L, Hq * hd, seed=9).to(BF16)
+    delta, dOT = ops.attn_bwd_prep(dO, O, B, Hq, L)
+    ref = ops.attention_bwd_qkv(Q, K, V, dO, lse, delta, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+    got = ops.attention_bwd_gqa(Q, K, V, dO, O_tok, lse, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+    assert got is not None and torch.isfinite(got.float()).all()
+    assert relerr(got, ref) < 4e-3 and cos_sim(got, ref) > 0.99999, (relerr(got, ref), cos_sim(got, ref))
+    dQ, dK, dV = ops.attention_bwd(Q, QT, K, KT, V, dO, dOT, lse, delta, L, True, scale, kmask=kmask)
+    ref2 = ops.lm_qkv_post_bwd(dQ, dK, dV, x0, rq, rk, qn, kn, cos, sin, B, Hq, Hkv, L)
+    assert relerr(got, ref2) < 1.5e-2 and cos_sim(got, ref2) > 0.9999
+    for _ in range(5):                                   # race hunt: the single Q / dO buffer is re-filled under the epilogue
+        again = ops.attention_bwd_gqa(Q, K, V, dO, O_tok, lse, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+        assert torch.equal(again, got)
+    assert ops.attention_bwd_gqa(Q[:, :, :100].contiguous(), K[:, :, :100].contiguous(), V[:, :, :100].contiguous(), dO[:B * 100], O_tok[:B * 100],
+                                 lse[:, :, :100].contiguous(), x0[:B * 100], rq, rk, qn, kn, cos, sin, 100, scale) is None   # L <= 128: not served
+
+
 # ----------------------------------------------------------------------------- element-wise / movement
 def test_swiglu():
     M, F = 300, 768

@@ -707,11 +707,26 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
     if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
-    RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue (TA355_ATTN_BWD_FUSED=0:
     // head-major dQ / dK / dV + ta_lm_qkv_post_bwd, which also serves the trainable-norm case)
     static const bool fuse_post = [] { const char* e = getenv("TA355_ATTN_BWD_FUSED"); return !(e && *e == '0'); }();
-    if (fuse_post && !(g && (g->dqn || g->dkn))) {
+    // round 4: one workgroup per (clip, kv head) -- K / V resident, Delta inside, no ta_attn_bwd_prep.  OPT-IN (TA355_ATTN_BWD_GQA=1):
+    // measured 92.8 us per layer warm / 117.5 cold against 91.8 / 106.0 for the tiled kernels + the Delta pass, and 41.08 against 40.45
+    // ms per step (profiles/r04_g_*, r04_h_*): with the dK / dV accumulators of all 192 keys in registers only ONE 4-wave workgroup
+    // fits a CU, and a single wave per SIMD waits out every LDS round trip of its 2 280 fragment reads by itself (67 of the 93 us are
+    // the tile-pair arithmetic at ~15 cycles per instruction).  Outside its envelope (L <= 128 or > 192, other group sizes) it
+    // answers TA_ERR_ARG and the tiled path runs.
+    static const bool gqa_bwd = [] { const char* e = getenv("TA355_ATTN_BWD_GQA"); return e && *e == '1'; }();
+    bool attn_done = false;
+    if (gqa_bwd && fuse_post && !(g && (g->dqn || g->dkn))) {
+      const int rc = ta_attention_bwd_gqa(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.ao, p.lse, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
+                                          w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.hd, scale, st);
+      if (rc == TA_OK) attn_done = true;
+      else if (rc != TA_ERR_ARG) return rc;
+    }
+    if (!attn_done) RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
+    if (attn_done) {
+    } else if (fuse_post && !(g && (g->dqn || g->dkn))) {
       RC(ta_attention_bwd_qkv(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
                               w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     } else {

@@ -209,6 +209,22 @@ def attention_fwd_qkv(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, scale, eps=1e
     return O, lse, Q, K, V, rq, rk
 
 
+def attention_bwd_gqa(Q, K, V, dO, O, lse, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
+    """Round 4: the same product as ``attn_bwd_prep`` + ``attention_bwd_qkv`` from ONE workgroup per (clip, kv head) (128 < L <= 192,
+    two query heads per kv head): K / V resident in LDS, Delta computed inside from ``O`` (token-major like ``dO``).  Returns
+    d(qkv0) token-major, or None when the shape is outside the kernel's envelope."""
+    B, Hq, _, hd = Q.shape
+    Hkv = K.shape[1]
+    dqkv = torch.empty((B * L, (Hq + 2 * Hkv) * hd), device=Q.device, dtype=BF16)
+    rc = lib().ta_attention_bwd_gqa(ptr(Q), ptr(K), ptr(V), ptr(dO), dO.shape[-1], ptr(O), ptr(lse), ptr(kmask), ptr(qkv0), ptr(rq),
+                                    ptr(rk), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv, L, hd,
+                                    scale, stream())
+    if rc == 1:                                   # TA_ERR_ARG: not served
+        return None
+    check(rc, "ta_attention_bwd_gqa")
+    return dqkv
+
+
 def attention_bwd_qkv(Q, K, V, dO, lse, delta, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
     """Causal GQA attention backward with the q|k|v post-processing backward in its epilogue: returns d(qkv0) token-major."""
     B, Hq, _, hd = Q.shape
