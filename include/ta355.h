@@ -402,6 +402,11 @@ int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_bf16, float*
                         hipStream_t st);
 int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
                         const float* dres, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
+/* round 4: the same with the residual gradient ALSO bf16 -- the LM's d(x) stream in the reference's dtype (its bf16 model back-
+ * propagates bf16 activations' gradients); dres_bf16 may alias dx_bf16 (updated in place), dx_f32 is optional (NULL except where an
+ * f32 consumer follows: the embedding / audio-row gather at the bottom of the stack) */
+int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
+                         const void* dres_bf16, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
 
 /* LayerNorm statistics only: stats[row] = (rstd, -mean * rstd) of x [M, H] (f32 or bf16), for ta_gemm_opts.lnf_* */
 int ta_layernorm_stats(const void* x, int x_is_bf16, float* stats, int M, int H, float eps, hipStream_t st);

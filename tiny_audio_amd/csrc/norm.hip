@@ -226,11 +226,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 //   dn = dy * act'(n)           (ACT==1, n = w*x*rstd recomputed)
 //   dx = rstd * (dn*w - xh * mean(dn*w*xh)),  xh = x*rstd        (+ dres if given)
 //   dw += sum_rows dn * xh      (if dw != null; LDS partials + one atomicAdd per column per block)
-template <int MAXV, int ACT, bool X_BF16 = false, bool DY_BF16 = false>
+// DRES_BF16 (round 4): the residual gradient `dres` is bf16 and may BE the output image dxb (in place: a lane reads its four
+// elements before it writes them) -- the LM's d(x) stream kept in bf16, the dtype the reference's bf16 model back-propagates in
+template <int MAXV, int ACT, bool X_BF16 = false, bool DY_BF16 = false, bool DRES_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ rstd_in,
                                                           const float* __restrict__ w, const float* dres,
-                                                          float* dxf, bf16_t* __restrict__ dxb,
+                                                          float* dxf, bf16_t* dxb,
                                                           float* __restrict__ dw, int M, int H) {
   extern __shared__ float dw_part[];   // [H] when dw != null
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -282,8 +284,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
           o.x = r * (dn[i].x - xh[i].x * mdot); o.y = r * (dn[i].y - xh[i].y * mdot);
           o.z = r * (dn[i].z - xh[i].z * mdot); o.w = r * (dn[i].w - xh[i].w * mdot);
           if (dres) {
-            const float4 e = ((const float4*)(dres + (long)row * H))[c];
-            o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+            if (DRES_BF16) {
+              const uint2 u = ((const uint2*)((const bf16_t*)dres + (long)row * H))[c];
+              o.x += bf2f((bf16_t)(u.x & 0xffff)); o.y += bf2f((bf16_t)(u.x >> 16)); o.z += bf2f((bf16_t)(u.y & 0xffff)); o.w += bf2f((bf16_t)(u.y >> 16));
+            } else {
+              const float4 e = ((const float4*)(dres + (long)row * H))[c];
+              o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+            }
           }
           if (dxf) ((float4*)(dxf + (long)row * H))[c] = o;
           if (dxb) {
@@ -411,6 +418,24 @@ extern "C" int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x
   else TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, false>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, dx_f32,  \
                  (bf16_t*)dx_bf16, (float*)nullptr, M, H);
   DISPATCH_MAXV(H, RBB_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// the same with the residual gradient read as bf16 (dres_bf16 may alias dx_bf16: the bf16 d(x) stream updated in place)
+extern "C" int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
+                                    const void* dres_bf16, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  const float* x = (const float*)x_bf16;
+  const float* dyf = (const float*)dy;
+  const float* dres = (const float*)dres_bf16;
+#define RBS_CALL(V)                                                                                                                       \
+  if (dy_is_bf16) TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, true, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres,      \
+                            dx_f32, (bf16_t*)dx_bf16, (float*)nullptr, M, H);                                                             \
+  else TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, false, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, dx_f32,       \
+                 (bf16_t*)dx_bf16, (float*)nullptr, M, H);
+  DISPATCH_MAXV(H, RBS_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
