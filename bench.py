@@ -484,10 +484,10 @@ def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
     return out
 
 
-def cpu_baseline(model, cfg, L, reps=3):
+def cpu_baseline(model, cfg, L, reps=5, warmups=2):
     """The numpy oracle (a 'port': the reference's Python cannot travel) timed on the host cores on a bounded
     sample: ONE 10 s clip, one full-depth training step (forward + backward), fp32, same weights as the GPU model;
-    one untimed warm-up pass, then the median of ``reps`` passes."""
+    ``warmups`` untimed passes, then the median of ``reps`` passes (median of >= 5 after 2 warm-ups)."""
     from oracle import features as OF
     from oracle import model as OM
     from oracle import weights as OW
@@ -501,20 +501,20 @@ def cpu_baseline(model, cfg, L, reps=3):
     ids, att, lab, counts = OW.synthetic_tokens(1, 125, lm.vocab_size, cfg.audio_token_id, cfg.pad_token_id,
                                                 cfg.eos_token_id, L=L)
     times, loss = [], 0.0
-    for i in range(reps + 1):
+    for i in range(reps + warmups):
         t0 = time.perf_counter()
         wav, lens = OF.pad_batch([OW.synthetic_wave(0)])
         feats, _ = OF.log_mel(wav, lens)
         batch = dict(input_ids=ids, attention_mask=att, labels=lab, input_features=feats, audio_token_counts=counts)
         out = OM.asr_forward(batch, W, ocfg, training=True)
         OM.asr_backward(out, W, ocfg)
-        if i > 0:
+        if i >= warmups:
             times.append(time.perf_counter() - t0)
         loss = float(out["loss"])
     dt = sorted(times)[len(times) // 2]
     return {"value": round(10.0 / dt, 3), "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port", "_loss": loss,
             "sample": "1 clip x 1 full-depth training step (log-mel + fwd + bwd, fp32 numpy/OpenBLAS oracle): median of "
-                      f"{reps} passes after 1 warm-up, {dt:.1f} s each ({min(times):.1f}-{max(times):.1f}), loss {loss:.4f}"}
+                      f"{reps} passes after {warmups} warm-ups, {dt:.1f} s each ({min(times):.1f}-{max(times):.1f}), loss {loss:.4f}"}
 
 
 if __name__ == "__main__":

@@ -388,6 +388,9 @@ int ta_profile_gemm_collect(double* total_ms, double* total_flops, long* launche
  * backward, 256 / 512 identity A / C row map).  Host memory; returns the row count (out may be NULL).  The step-shape parity test
  * (tests/test_gpu_round4.py) runs one real B = 32 step under it and replays every distinct launch against an fp32 matmul. */
 long ta_profile_gemm_log(long* out, long max_rows);
+/* round 4: the GEMM launcher reads its environment knobs (TA355_GEMM_VARIANT, TA355_GEMM_DEBUG, TA355_V7_MASK, ... : DESIGN.md 7b)
+ * ONCE, at its first launch; this re-reads them (tests and A/B scripts that switch a knob between launches). */
+int ta_gemm_reload_knobs(void);
 
 int ta_layernorm_f32(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32,
                      const float* rowscale, int M, int H, float eps, hipStream_t st);

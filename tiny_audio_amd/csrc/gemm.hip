@@ -1303,17 +1303,60 @@ bool g_log_on = false;
 std::vector<long> g_log;
 }  // namespace
 
+// Round 4: the product library carries the variants the launch-time model can choose (0-5, 10, 12) plus gemm_v7.hip's (13-15, opt-in);
+// the ring form (6 / 7), the stamped timing builds (8 / 9), the 32x32x16 form of v5 (11) and v5's timing experiments exist only in a
+// library built with -DTA355_EXPERIMENTS (TA355_BUILD_EXPERIMENTS=1 for tiny_audio_amd/_lib.build; scripts/gemm_phase_times.py,
+// gemm_wg_life.py, gemm_v5_exp.py, gemm_ab.py --ring need it).  gemm.hip then compiles in ~55 s instead of ~100.
 // Tile variant: 0 = 128x128 (4 waves, 2 WG/CU), 5 = 96x128 (same kernel), 1 = 256x256, 2 = 256x128 (8 waves, 1 WG/CU), 3 = 256x256 ping-pong,
 // 4 = 256x320 ping-pong (N = 1280 / 3840 / 5120 divide exactly: M = 16000 x N = 1280 is 252 tiles = ONE round of 256 CUs).
 // Model: time ~ rounds(tiles / resident slots) * tile area / relative rate; pick the cheapest.  The relative rates
 // come from scripts/gemm_bench.py on MI355X (see profiles/).  TA355_GEMM_VARIANT=0..3 forces one (experiments, tests).
 #include <cstdlib>
+// Every environment knob of the GEMM launcher, read ONCE (round 4: they were 17 getenv calls PER LAUNCH, and a debug bit that aliased
+// an experimental build corrupted a reported A/B in round 3).  ta_gemm_reload_knobs() re-reads the environment: tests and the A/B
+// scripts that switch a knob between launches call it (tiny_audio_amd/ops.py does so when it sees one of them change).
+struct GemmKnobs {
+  int variant, no96, v5_mink, v7_mask, ring, persist_kext, m32, group_m, group_m_auto, epi_narrow, dbg, persist;
+  double r320, r10, r12;
+  void load() {
+    auto s = [](const char* n) -> const char* { const char* v = getenv(n); return (v && *v) ? v : nullptr; };
+    auto i = [&](const char* n, int d) { const char* v = s(n); return v ? atoi(v) : d; };
+    auto f = [&](const char* n, double d) { const char* v = s(n); return v ? atof(v) : d; };
+    variant = i("TA355_GEMM_VARIANT", -1);        // force one tile variant (tests, microbenchmarks)
+    no96 = i("TA355_GEMM_NO96", 0) == 1;
+    r320 = f("TA355_RATE_256x320", TA355_RATE_256x320_PP);
+    r10 = f("TA355_RATE_192x128", TA355_RATE_192x128);
+    r12 = f("TA355_RATE_192x256", TA355_RATE_192x256_PP);
+    v5_mink = i("TA355_V5_MINK", 2048);
+    v7_mask = i("TA355_V7_MASK", 0);
+    ring = i("TA355_GEMM_RING", 0) == 1;
+    persist_kext = i("TA355_GEMM_PERSIST_KEXT", 0) == 1;
+    m32 = i("TA355_GEMM_M32", 0) == 1;
+    group_m = i("TA355_GROUP_M", 0);
+    group_m_auto = i("TA355_GROUP_M_AUTO", 0) == 1;
+    epi_narrow = i("TA355_EPI_WIDE", 1) == 0;
+    persist = i("TA355_GEMM_PERSIST", 1);         // 0: one workgroup per tile (v2); 2: persistent only for launches of more than one round
+    dbg = i("TA355_GEMM_DEBUG", 0);               // experiments: 1 no epilogue stores, 2 one K tile only, 4 life stamps, ...
+    if (i("TA355_GELU_LUT", 1) == 0) dbg |= 8;    // arithmetic erf-GELU instead of the chord table (A/B, tests)
+    if (i("TA355_GEMM_RES_INIT", 1) == 0) dbg |= 1 << 20;   // bf16 residual added in the epilogue instead of being the accumulators' start
+  }
+};
+static GemmKnobs& knobs() {
+  static GemmKnobs k = [] { GemmKnobs x; x.load(); return x; }();
+  return k;
+}
+extern "C" int ta_gemm_reload_knobs(void) { knobs().load(); return TA_OK; }
+
 static int pick_variant(int M, int N, int K, int splits) {
-  const char* e = getenv("TA355_GEMM_VARIANT");                 // read per call: tests switch it between launches
-  const int forced = (e && *e) ? atoi(e) : -1;
-  if (forced >= 0 && forced <= 15) return forced;     // 13 / 14 / 15: gemm_v7.hip (256x256, 256x320, 192x256)     // 6 / 7: the 4-slot ring form (v3) of the 256x256 / 256x320 ping-pong tiles
-  static const bool no96 = [] { const char* v = getenv("TA355_GEMM_NO96"); return v && *v == '1'; }();   // experiment
-  static const double r320 = [] { const char* v = getenv("TA355_RATE_256x320"); return v && *v ? atof(v) : TA355_RATE_256x320_PP; }();   // experiment
+  const GemmKnobs& kn = knobs();
+  const int forced = kn.variant;
+#ifdef TA355_EXPERIMENTS
+  if (forced >= 0 && forced <= 15) return forced;     // 6 / 7: the 4-slot ring (v3), 8 / 9: the stamped builds, 11: v6 -- experiment builds only
+#else
+  if (forced >= 0 && forced <= 15 && !(forced >= 6 && forced <= 9) && forced != 11) return forced;   // 13 / 14 / 15: gemm_v7.hip
+#endif
+  const bool no96 = kn.no96;
+  const double r320 = kn.r320;
   const double rate[6] = {1.0, TA355_RATE_256x256, TA355_RATE_256x128, TA355_RATE_256x256_PP, r320, TA355_RATE_96x128};
   const int bm[6] = {128, 256, 256, 256, 256, 96}, bn[6] = {128, 256, 128, 256, 320, 128}, slots[6] = {512, 256, 256, 256, 256, 512};
   int best = 0; double best_t = 1e300;
@@ -1325,48 +1368,48 @@ static int pick_variant(int M, int N, int K, int splits) {
     if (t < best_t) { best_t = t; best = v; }
   }
   {                                                  // 10 = 192x128, one 4-wave workgroup per CU (v5)
-    static const double r10 = [] { const char* v = getenv("TA355_RATE_192x128"); return v && *v ? atof(v) : TA355_RATE_192x128; }();
+    const double r10 = kn.r10;
     const long tiles = (long)ta_cdiv(M, 192) * ta_cdiv(N, 128) * splits;
     const double t = (double)((tiles + 255) / 256) * 192.0 * 128.0 / r10;
     // only long contractions: with one workgroup per CU nothing overlaps its prologue and epilogue (K = 1280: 33 vs 28 us for 96x128)
-    static const int mink = [] { const char* v = getenv("TA355_V5_MINK"); return v && *v ? atoi(v) : 2048; }();
+    const int mink = kn.v5_mink;
     if (r10 > 0.0 && K / splits >= mink && t < best_t) { best_t = t; best = 10; }
   }
   {                                                  // 12 = 192x256 ping-pong, persistent (v4 with BM2 = 192)
-    static const double r12 = [] { const char* v = getenv("TA355_RATE_192x256"); return v && *v ? atof(v) : TA355_RATE_192x256_PP; }();
+    const double r12 = kn.r12;
     const long tiles = (long)ta_cdiv(M, 192) * ta_cdiv(N, 256) * splits;
     const double t = (double)((tiles + 255) / 256) * 192.0 * 256.0 / r12;
-    if (r12 > 0.0 && t < best_t) { best_t = t; best = 12; }
+    // (the same minimum contraction length as for v5's own choice -- two K tiles -- so that tiny-K launches stay on the small tiles)
+    if (r12 > 0.0 && K / splits >= 128 && t < best_t) { best_t = t; best = 12; }
   }
   // gemm_v7.hip (one wave per SIMD, AGPR accumulators) instead of the ping-pong kernel on the same tile, per shape family:
   // TA355_V7_MASK bits: 1 N = 1280 (o_proj / fc2 / conv2), 2 N = 3840 (q|k|v), 4 N = 5120 (fc1), 8 other 256x320, 16 the 192x256 tile, 32 256x256
   {
-    static const int v7m = [] { const char* v = getenv("TA355_V7_MASK"); return v && *v ? atoi(v) : 0; }();
+    const int v7m = kn.v7_mask;
     if (v7m) {
       if (best == 4) { const int bit = N == 1280 ? 1 : (N == 3840 ? 2 : (N == 5120 ? 4 : 8)); if (v7m & bit) best = 14; }
       else if (best == 12 && (v7m & 16)) best = 15;
       else if (best == 3 && (v7m & 32)) best = 13;
     }
   }
-  // TA355_GEMM_RING=1 (experiment): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
-  static const bool ring = [] { const char* v = getenv("TA355_GEMM_RING"); return v && *v == '1'; }();
-  if (ring && (best == 3 || best == 4)) best += 3;
+#ifdef TA355_EXPERIMENTS
+  // TA355_GEMM_RING=1 (experiment build): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
+  if (kn.ring && (best == 3 || best == 4)) best += 3;
+#endif
   return best;
 }
 
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 static int launch_gemm(GemmArgs a, hipStream_t st) {
+  const GemmKnobs& kn = knobs();
   int variant = pick_variant(a.M, a.N, a.K, a.splits);
   const bool a_far = !a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32);   // row-mapped A is addressed from its start with 32-bit offsets
   if ((variant == 10 || variant == 11) && (a.w_blocked || a.a_idx || a_far)) variant = 5;     // v5 / v6: no gather, plain W only
-  {
-    static const bool pk12 = [] { const char* e = getenv("TA355_GEMM_PERSIST_KEXT"); return e && *e == '1'; }();
-    if (variant == 12 && (a.a_idx || a_far || (a.A2 && !pk12))) variant = 3;                  // the 192-row tile exists in the persistent form only
-  }
-  if (variant == 10 && ACT == 0) {                  // TA355_GEMM_M32=1 (experiment): plain linears on the 32x32x16 form of the same tile (v6)
-    const char* e = getenv("TA355_GEMM_M32");
-    if (e && *e == '1') variant = 11;
-  }
+  // the 192-row tile exists in the persistent form only (TA355_GEMM_PERSIST=0 maps it back to the 256x256 tile on v2)
+  if (variant == 12 && (a.a_idx || a_far || (a.A2 && !kn.persist_kext) || kn.persist == 0)) variant = 3;
+#ifdef TA355_EXPERIMENTS
+  if (variant == 10 && ACT == 0 && kn.m32) variant = 11;   // TA355_GEMM_M32=1: plain linears on the 32x32x16 form of the same tile (v6)
+#endif
   if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
   if (a.w_blocked && variant >= 6 && variant != 12) return TA_ERR_ARG;         // the ring kernel (and v5 / v6) stage plain [N, K] weights only
   if (variant >= 13 && variant <= 15 && !gemm_v7_serves(variant, ACT, OUT_BF16, HAS_RES, a)) variant = variant == 13 ? 3 : (variant == 14 ? 4 : 12);
@@ -1378,36 +1421,28 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
   {
-    const char* gm = getenv("TA355_GROUP_M");             // experiments: tile-order group height
-    a.group_m = gm && *gm ? atoi(gm) : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD
+    a.group_m = kn.group_m > 0 ? kn.group_m : (variant != 0 && a.tiles_m <= 8 ? a.tiles_m : 0);   // few M-tiles (LM head): one group, W panels read once per XCD (TA355_GROUP_M: experiments)
     // 12 column tiles of 320 (the encoder's q | k | v GEMM, 3 rounds): groups of 16 row tiles instead of 4 -- an XCD's round is then
     // 16 row tiles x 2 column tiles.  Cold operands (profiles/r03_c_gemm_enc_groupm_cold.txt): 146.3 us against 153.9 (g = 8:
     // 148.1); N = 5120 / 1280 shapes are flat in g.  Experiment only (TA355_GROUP_M_AUTO=1): no gain in the step.
-    static const bool gauto = [] { const char* v = getenv("TA355_GROUP_M_AUTO"); return v && *v == '1'; }();   // opt-in: in the STEP it measured 42.85 vs 42.79 ms (profiles/r03_d_ab_groupm.txt)
-    if (!(gm && *gm) && gauto && variant == 4 && a.tiles_n == 12 && a.tiles_m >= 32) a.group_m = 16;
-    const char* e = getenv("TA355_EPI_WIDE");             // experiments: 0 = 8-B bf16 stores
-    a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !(e && *e == '0');
-    const char* d = getenv("TA355_GEMM_DEBUG");           // experiments: 1 = no epilogue stores, 2 = one K tile only
-    a.dbg = d && *d ? atoi(d) : 0;
-    const char* gl = getenv("TA355_GELU_LUT");            // 0 = arithmetic erf-GELU in the ping-pong kernel's epilogue (A/B, tests)
-    if (gl && *gl == '0') a.dbg |= 8;
-    const char* ri = getenv("TA355_GEMM_RES_INIT");       // 0 = the ping-pong kernel adds a bf16 residual in its epilogue (A/B)
-    if (ri && *ri == '0') a.dbg |= 1 << 20;     // (bits 4-6 of TA355_GEMM_DEBUG select the v5 experiments below: this flag sat on bit 4 and turned them on)
+    const bool gauto = kn.group_m_auto;       // opt-in: in the STEP it measured 42.85 vs 42.79 ms (profiles/r03_d_ab_groupm.txt)
+    if (kn.group_m <= 0 && gauto && variant == 4 && a.tiles_n == 12 && a.tiles_m >= 32) a.group_m = 16;
+    a.wide = (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !kn.epi_narrow;   // (TA355_EPI_WIDE=0: 8-B bf16 stores)
+    a.dbg = kn.dbg;
   }
   // ping-pong tiles as persistent workgroups (v4) unless TA355_GEMM_PERSIST=0; grid = one workgroup per CU at most
   // gathered A rows stay on v2 (their offsets are not bounded by the tile); so does the K extension (LoRA): with its pointer switch
   // the persistent form spills in the tile loop (LoRA step 54.5 ms against 53.6 with v2)
   bool persist = (variant == 3 || variant == 4) && !a.a_idx && !a.A2;
   static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-  { const char* e = getenv("TA355_GEMM_PERSIST"); if (e && *e == '0') persist = false; if (e && *e == '2' && grid <= ncu) persist = false; }   // 2: only launches of more than one round
+  if (kn.persist == 0 || (kn.persist == 2 && grid <= ncu)) persist = false;   // TA355_GEMM_PERSIST: 0 never, 2 only launches of more than one round
   if (a_far) persist = false;
   // round 3: the K extension on the persistent kernel re-measured (TA355_GEMM_PERSIST_KEXT=1; default: v2 as in round 2).  First
   // attempt: 91.8 against 61.6 us per launch (profiles/r03_p_ab_lora.txt) -- the extension's nine DMA offsets, loop-invariant from
   // threadIdx.x, had been hoisted out of the tile loop and pushed the regular offsets into scratch, reloaded behind a vmcnt(0)
   // between the DMA issues of every K tile.  With the offsets derived from a fresh thread index at the switch: no scratch, and the
   // LoRA step is the same on both kernels (45.45 ms each, profiles/r03_r_ab_lora_persist_kext.txt)
-  static const bool pk_env = [] { const char* e = getenv("TA355_GEMM_PERSIST_KEXT"); return e && *e == '1'; }();
-  const bool persist_kext = pk_env && a.A2 && !a.a_idx && !a_far && (variant == 3 || variant == 4 || variant == 12);
+  const bool persist_kext = kn.persist_kext && a.A2 && !a.a_idx && !a_far && (variant == 3 || variant == 4 || variant == 12);
   const int pgrid = grid < ncu ? grid : ncu;
   ProfRec r;
   if (g_prof_on) {
@@ -1430,9 +1465,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
       else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 10) TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES, 0, true>), dim3(grid), dim3(256), 0, st, a);
+#ifdef TA355_EXPERIMENTS
       else if (variant == 11) TA_LAUNCH((gemm_nt_kernel_v6<OUT_BF16, HAS_RES, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+#endif
       else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false, true>), dim3(grid), dim3(512), 0, st, a);
     } else {
       return TA_ERR_ARG;
@@ -1446,10 +1483,11 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   else if (variant == 4 && persist) TA_LAUNCH((gemm_nt_kernel_v4<320, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(512), 0, st, a);
   else if (variant == 3) TA_LAUNCH((gemm_nt_kernel_v2<256, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 4) TA_LAUNCH((gemm_nt_kernel_v2<320, ACT, OUT_BF16, HAS_RES, true>), dim3(grid), dim3(512), 0, st, a);
+#ifdef TA355_EXPERIMENTS
   else if (variant == 11) {
     if constexpr (ACT == 0) TA_LAUNCH((gemm_nt_kernel_v6<OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   }
-  else if (variant == 10) {
+  else if (variant == 10 && ((a.dbg >> 4) & 7)) {
     const int ex = (a.dbg >> 4) & 7;                            // TA355_GEMM_DEBUG = 16 * EXP (plain bf16 GEMMs only)
     if constexpr (ACT == 0 && OUT_BF16 && !HAS_RES) {
       if (ex == 1) TA_LAUNCH((gemm_nt_kernel_v5<0, true, false, 1>), dim3(grid), dim3(256), 0, st, a);
@@ -1470,6 +1508,8 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   }
   else if (variant == 6) TA_LAUNCH((gemm_nt_kernel_v3<256, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
   else if (variant == 7) TA_LAUNCH((gemm_nt_kernel_v3<320, ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(512), 0, st, a);
+#endif
+  else if (variant == 10) TA_LAUNCH((gemm_nt_kernel_v5<ACT, OUT_BF16, HAS_RES>), dim3(grid), dim3(256), 0, st, a);
   else TA_LAUNCH((gemm_nt_kernel_v2<128, ACT, OUT_BF16, HAS_RES, false>), dim3(grid), dim3(512), 0, st, a);
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   if (g_log_on) {

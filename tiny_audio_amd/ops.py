@@ -33,12 +33,30 @@ def _req(t, dtype=None):
     return t
 
 
+# The GEMM launcher reads its environment knobs once (csrc/gemm.hip GemmKnobs); tests and A/B scripts switch them between launches,
+# so the wrapper re-reads them whenever one of the per-launch knobs of rounds 1-3 has changed since the previous call.
+_KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GEMM_DEBUG", "TA355_GROUP_M", "TA355_EPI_WIDE", "TA355_GELU_LUT", "TA355_GEMM_RES_INIT",
+              "TA355_GEMM_PERSIST", "TA355_GEMM_M32", "TA355_V7_MASK")
+_knob_state = None
+
+
+def sync_gemm_knobs():
+    global _knob_state
+    import os
+    cur = tuple(os.environ.get(k) for k in _KNOB_KEYS)
+    if cur != _knob_state:
+        if _knob_state is not None or any(v is not None for v in cur):
+            lib().ta_gemm_reload_knobs()
+        _knob_state = cur
+
+
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
             a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None, w_blocked=False, ln_fold=None):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile);
     rope=(table f32 [rows,16,2], rows) with act=2: interleaved partial rotary embedding in the epilogue (ta355.h)."""
     _req(A, BF16); _req(W, BF16)
+    sync_gemm_knobs()
     opts = None
     if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None or w_blocked or ln_fold is not None:
         from ._lib import GemmOpts
@@ -95,6 +113,7 @@ def gemm_nt_grouped(A, W, out, M, N, K, *, seg=None, krange=None, n_groups=1, bi
     W [n, N, K] (w_stride = N * K), bias [n, N]; K-slice form: ``krange`` int32 [2 * n] 64-wide K-tile ranges, out f32
     [n, M, N] (c_stride = M * N)."""
     _req(A, BF16); _req(W, BF16)
+    sync_gemm_knobs()
     check(lib().ta_gemm_bf16_nt_grouped(ptr(A), ptr(W), ptr(out), M, N, K, ptr(bias), act, int(out.dtype == BF16), ptr(a_idx),
                                         ptr(seg), ptr(krange), n_groups, w_stride, c_stride, stream()), "ta_gemm_bf16_nt_grouped")
     return out
