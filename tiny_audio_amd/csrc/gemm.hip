@@ -1391,6 +1391,11 @@ static int pick_variant(int M, int N, int K, int splits) {
       else if (best == 12 && (v7m & 16)) best = 15;
       else if (best == 3 && (v7m & 32)) best = 13;
     }
+    // (A second form of that kernel on v_mfma_f32_32x32x16_bf16 with an LDS-staged epilogue -- variants 16-18 of one visit -- was built on the
+    // strength of a constant-data probe (1 151 against 1 281 cycles per k-step), passed the same tests, and measured 4-9 % SLOWER than
+    // gemm_v7 on random operands (fc2 179 vs 164 us, 8192^3 1 309 vs 1 406 TF/s: profiles/r04_j_gemm_v8_32x32x16_ab.txt): on real data the
+    // 32x32x16 instruction sustains less than 16x16x32 (the r02 register-only probe already said 2 264 vs 2 424 TF/s).  Removed from the
+    // library; the source is kept as scripts/attic/gemm_v8.hip.txt.)
   }
 #ifdef TA355_EXPERIMENTS
   // TA355_GEMM_RING=1 (experiment build): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
