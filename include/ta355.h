@@ -450,6 +450,13 @@ int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V, const void
                          const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
                          void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
                          hipStream_t st);
+/* round 4: ta_attention_bwd_qkv without the Delta array: Delta = rowsum(dO o O) is computed inside both halves of the backward from O
+ * (token-major [B*L, Hq*128] with dO's row stride) -- no ta_attn_bwd_prep launch in the step */
+int ta_attention_bwd_qkv_o(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
+                           const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
+                           const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
+                           void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                           hipStream_t st);
 /* round 4: the same for the LM's short causal sequences (head_dim 128, L <= 192) as ONE workgroup per (clip, kv head): K / V resident
  * in LDS, dK / dV accumulated over the GQA group's query heads, Delta = rowsum(dO o O) computed inside (O token-major with dO's row
  * stride: no ta_attn_bwd_prep, no Delta array).  TA_ERR_ARG outside that envelope. */

@@ -360,6 +360,9 @@ def test_attention_bwd_with_fused_qkv_post(L, masked):
     got = ops.attention_bwd_qkv(Q, K, V, dO, lse, delta, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
     assert torch.isfinite(got.float()).all()
     assert relerr(got, ref) < 1.5e-2 and cos_sim(got, ref) > 0.9999
+    # round 4: Delta computed inside from O (no ta_attn_bwd_prep): the same products, Delta's 128-term sum in another order
+    got_o = ops.attention_bwd_qkv_o(Q, K, V, dO, O, lse, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+    assert relerr(got_o, got) < 4e-3 and cos_sim(got_o, got) > 0.99999
     # the v section is a pure relayout of the same accumulators: identical
     assert torch.equal(got.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:], ref.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:])
 

@@ -732,9 +732,15 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       if (rc == TA_OK) attn_done = true;
       else if (rc != TA_ERR_ARG) return rc;
     }
-    if (!attn_done) RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
+    // round 4: Delta = rowsum(dO o O) is computed inside the fused backward from O (TA355_ATTN_DELTA_FUSED=0: the separate pass)
+    static const bool delta_in = [] { const char* e = getenv("TA355_ATTN_DELTA_FUSED"); return !(e && *e == '0'); }();
+    const bool fused_path = fuse_post && !(g && (g->dqn || g->dkn));
+    if (!attn_done && !(fused_path && delta_in)) RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     if (attn_done) {
-    } else if (fuse_post && !(g && (g->dqn || g->dkn))) {
+    } else if (fused_path && delta_in) {
+      RC(ta_attention_bwd_qkv_o(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.ao, p.lse, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
+                                w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
+    } else if (fused_path) {
       RC(ta_attention_bwd_qkv(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
                               w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     } else {

@@ -906,7 +906,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
                                                  const bf16_t* __restrict__ dO, long dO_stride,
                                                  const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                  const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
-                                                 int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F) {
+                                                 int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F,
+                                                 const bf16_t* __restrict__ Otok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int nq = (L + 63) / 64, grp = Hq / Hkv;
   int group, member;
@@ -928,7 +929,26 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     dof[ks] = *(const bf16x8*)(dOb + (long)qr * dO_stride + ks * 32 + g * 8);
   }
   const float lse2 = LSE[(long)(b * Hq + h) * L + qr] * LOG2E;
-  const float delta = Delta[(long)(b * Hq + h) * L + qr];
+  // round 4: Delta = rowsum(dO o O) computed HERE when O is given (token-major with dO's row stride) -- the lane's own dO fragments
+  // times the same elements of O, summed over the four lanes of the row -- instead of read from the array ta_attn_bwd_prep wrote
+  float delta;
+  if (Otok) {
+    const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const uint4 o4 = *(const uint4*)(orow + ks * 32 + g * 8);
+      const uint32_t ou[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t du = ((const uint32_t*)&dof[ks])[e];
+        part += bf2f((bf16_t)(du & 0xffff)) * bf2f((bf16_t)(ou[e] & 0xffff)) + bf2f((bf16_t)(du >> 16)) * bf2f((bf16_t)(ou[e] >> 16));
+      }
+    }
+    delta = group_sum(part);
+  } else {
+    delta = Delta[(long)(b * Hq + h) * L + qr];
+  }
   f32x4 dq[HD / 16];
 #pragma unroll
   for (int i = 0; i < HD / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1020,7 +1040,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
                                                   const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                   const int* __restrict__ kmask, bf16_t* __restrict__ dK,
                                                   bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
-                                                  float scale, const QkvPostBwd& F) {
+                                                  float scale, const QkvPostBwd& F, const bf16_t* __restrict__ Otok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int grp = Hq / Hkv;
   int group, kt_idx;
@@ -1048,6 +1068,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   static_assert(HD == 128, "the DMA staging of the backward is written for head_dim 128");
   const unsigned lds0 = lds_addr_of(smem);
   float pl = 1.0e30f, pd = 0.f;
+  uint4 po[4];                                         // (Otok) this thread's quarter of an O row: 32 of its 128 elements, raw
   int it = 0;
   auto issue = [&](int hh, int qt, int buf) {
     const int h = hk * grp + hh, q0 = qt * 64;
@@ -1059,7 +1080,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
     pl = 1.0e30f; pd = 0.f;
     if (tid < 64 && q0 + tid < L) {
       pl = LSE[(long)(b * Hq + h) * L + q0 + tid];
-      pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
+      if (!Otok) pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
+    }
+    if (Otok) {                                        // four threads per query row (tid >> 2), 32 elements each
+      const int qr = min(q0 + (tid >> 2), L - 1);
+      const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD + (tid & 3) * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) po[j] = *(const uint4*)(orow + j * 8);
     }
   };
   if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
@@ -1070,9 +1097,25 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       char* dOs = Qs + RowTile<HD>::BYTES;
       float* Ls = (float*)(dOs + RowTile<HD>::BYTES);  // [64] lse * log2e
       float* Ds = Ls + 64;                             // [64] delta
-      if (tid < 64) { Ls[tid] = pl * LOG2E; Ds[tid] = pd; }
+      if (tid < 64) { Ls[tid] = pl * LOG2E; if (!Otok) Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (Otok) {                                      // Delta of the tile's 64 queries from the dO tile that has just landed
+        const int row = tid >> 2, quarter = tid & 3;
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint4 d4 = *(const uint4*)(dOs + RowTile<HD>::off(row, quarter * 4 + j));
+          const uint32_t du[4] = {d4.x, d4.y, d4.z, d4.w}, ou[4] = {po[j].x, po[j].y, po[j].z, po[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            part += bf2f((bf16_t)(du[e] & 0xffff)) * bf2f((bf16_t)(ou[e] & 0xffff)) + bf2f((bf16_t)(du[e] >> 16)) * bf2f((bf16_t)(ou[e] >> 16));
+        }
+        part += dpp_mov<0xB1>(part);                   // quad_perm [1,0,3,2]
+        part += dpp_mov<0x4E>(part);                   // quad_perm [2,3,0,1]
+        if (quarter == 0) Ds[row] = part;
+        __syncthreads();
+      }
       if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
       else if (hh + 1 < grp) issue(hh + 1, qt_begin, (it + 1) & 1);
       f32x4 s[4], dp[4];
@@ -1154,7 +1197,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
                                                        const float* __restrict__ Delta, const int* __restrict__ kmask,
                                                        bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
                                                        int B, int Hq, int Hkv, int L, int Lp, float scale, int n_dkv,
-                                                       const QkvPostBwd F) {
+                                                       const QkvPostBwd F, const bf16_t* __restrict__ Otok) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (n_dkv < 0) {
     // interleaved order (TA355_ATTN_BWD_MERGED=2): the nq dK/dV workgroups and the grp * nq dQ workgroups of one (clip, kv head) get CONSECUTIVE ids
@@ -1165,15 +1208,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     if (!decode_group(blockIdx.x, gsz, B * Hkv, group, member)) return;
     const int xcd = group & 7, j = group >> 3;
     if (member < nq)
-      attn_bwd_dkv_body<HD, CAUSAL>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F);
+      attn_bwd_dkv_body<HD, CAUSAL>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
     else
-      attn_bwd_dq_body<HD, CAUSAL>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F);
+      attn_bwd_dq_body<HD, CAUSAL>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
     return;
   }
   if ((int)blockIdx.x < n_dkv)
-    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F);
+    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
   else
-    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F);
+    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
 }
 
 
@@ -1564,7 +1607,9 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
 
 static int attention_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
                                 const float* Delta, const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L,
-                                int Lp, int head_dim, int causal, float scale, const QkvPostBwd& F, hipStream_t st) {
+                                int Lp, int head_dim, int causal, float scale, const QkvPostBwd& F, hipStream_t st,
+                                const void* Otok = nullptr) {
+  if (!Delta && !Otok) return TA_ERR_ARG;
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
@@ -1587,7 +1632,8 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   const bf16_t* nul = nullptr;
 #define BWD(C_, GRID_, NDKV_)                                                                                                       \
   TA_LAUNCH((attn_bwd_kernel<HD, C_>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V,      \
-            (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F)
+            (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F,   \
+            (const bf16_t*)Otok)
   if (split) {                                       // the same bodies as two launches: n_dkv = 0 (all dQ) resp. n_dkv = grid (all dK / dV)
     if (causal) { BWD(true, dim3(n_dq), 0); BWD(true, dim3(n_dkv), n_dkv); }
     else { BWD(false, dim3(n_dq), 0); BWD(false, dim3(n_dkv), n_dkv); }
@@ -1661,4 +1707,16 @@ extern "C" int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V,
   QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
   return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, Delta, kmask, nullptr, nullptr, nullptr, B, Hq, Hkv, L, Lp, head_dim, causal,
                               scale, F, st);
+}
+// round 4: the same without ta_attn_bwd_prep -- Delta = rowsum(dO o O) is computed inside both halves of the backward from O
+// (token-major, dO's row stride): one launch and one [B, Hq, L] array less per layer
+extern "C" int ta_attention_bwd_qkv_o(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
+                                      const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
+                                      const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
+                                      void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
+                                      hipStream_t st) {
+  if (!O || !qkv0 || !dqkv || !rq || !rk || !qn_w || !kn_w || !cosT || !sinT) return TA_ERR_ARG;
+  QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
+  return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, nullptr, kmask, nullptr, nullptr, nullptr, B, Hq, Hkv, L, Lp, head_dim, causal,
+                              scale, F, st, O);
 }

@@ -244,6 +244,17 @@ def attention_bwd_gqa(Q, K, V, dO, O, lse, qkv0, rq, rk, qn_w, kn_w, cosT, sinT,
     return dqkv
 
 
+def attention_bwd_qkv_o(Q, K, V, dO, O, lse, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
+    """``attention_bwd_qkv`` with Delta computed inside from ``O`` (token-major like ``dO``): no ``attn_bwd_prep``."""
+    B, Hq, _, hd = Q.shape
+    Hkv, Lp = K.shape[1], pad64(L)
+    dqkv = torch.empty((B * L, (Hq + 2 * Hkv) * hd), device=Q.device, dtype=BF16)
+    check(lib().ta_attention_bwd_qkv_o(ptr(Q), ptr(K), ptr(V), ptr(dO), dO.shape[-1], ptr(O), ptr(lse), ptr(kmask), ptr(qkv0),
+                                       ptr(rq), ptr(rk), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv,
+                                       L, Lp, hd, 1, scale, stream()), "ta_attention_bwd_qkv_o")
+    return dqkv
+
+
 def attention_bwd_qkv(Q, K, V, dO, lse, delta, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
     """Causal GQA attention backward with the q|k|v post-processing backward in its epilogue: returns d(qkv0) token-major."""
     B, Hq, _, hd = Q.shape
