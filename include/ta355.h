@@ -161,6 +161,14 @@ int ta_moe_projector_backward_dev(const ta_moe_weights* w, const void* x_bf16, i
                                   float* d_norm_w, float* d_router_w, float* const* dW1, float* const* db1,
                                   float* const* dW2, float* const* db2, void* ws, long ws_bytes, hipStream_t st);
 
+/* round 4: the share of d(norm.weight) [k * enc_dim] and d(router.weight) [E, k * enc_dim] that comes from the auxiliary losses alone
+ * (d_aux * d aux / d .; overwritten).  Same tape / workspace as the backward.  The trainer keeps it in a shadow of its flat gradient
+ * buffer so that the auxiliary term keeps its full weight under the optimizer's division by the global label-token count without a
+ * second collective (tiny_audio_amd/trainer.py). */
+int ta_moe_router_aux_grads(const ta_moe_weights* w, const void* x_bf16, int B, int S, const float* d_aux_dev, const float* noise,
+                            int training, const void* tape, float* d_norm_w_aux, float* d_router_w_aux, void* ws, long ws_bytes,
+                            hipStream_t st);
+
 /* ---- frozen Qwen3 LM + shifted CE: replaces model.language_model(inputs_embeds=, attention_mask=, labels=)
  *      together with the embed/masked_scatter glue of ASRModel.forward
  *      (tiny_audio/asr_modeling.py:497-526; TF:models/qwen3/modeling_qwen3.py:367-508; TF:loss/loss_utils.py:33-71)

@@ -390,6 +390,65 @@ def test_trainer_two_ranks_flat_allreduce(mode):
     assert g0a == g1a == g0b == g1b == 3.0           # SUM over ranks of the stand-in gradients (1 + 2), first and last element
 
 
+def _moe_trainer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import weights as OW
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    _lib.DRY_RUN = True
+    enc = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4)
+    lm = OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_type="moe", projector_hidden_dim=128, audio_token_id=999)
+    torch.manual_seed(0)
+    m = ASRModel(cfg, device="cpu", init="random")
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
+    tr = ASRTrainer(m, TrainingArguments(gradient_accumulation_steps=2))
+    f = tr.flat
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22 + rank)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
+    m.train()
+    tr.training_step(batch)                  # micro-step 1 (gradient accumulation with an auxiliary loss: no num_items_in_batch needed)
+    n_before = len(calls)
+    # stand-in values for the second micro-step's result: the arithmetic of the fix-up is what is checked (dry-run kernels compute nothing)
+    tr.training_step(batch)                  # micro-step 2: ONE collective over [grads | shadows | count | loss], then the update
+    shadow_names = list(f.shadow_names)
+    f.flat_g.zero_()
+    f.grad_of("projector.router.weight").fill_(1.0); f.shadow("projector.router.weight").fill_(2.0)
+    f.count_slot.fill_(5.0)
+    tr._apply_update()
+    q.put((rank, n_before, len(calls), calls[-1] if calls else 0, f.flat_g.numel(), shadow_names,
+           float(f.grad_of("projector.router.weight").flatten()[0]), float(f.grad_of("projector.norm.weight").flatten()[0]),
+           int(m.projector._aux_shadow["router.weight"].data_ptr() == f.shadow("projector.router.weight").data_ptr())))
+    dist.destroy_process_group()
+
+
+def test_moe_trainer_two_ranks_one_collective():
+    """Round 4: the MoE projector's auxiliary losses no longer cost a second, blocking all-reduce of the token
+    count ahead of the backward -- the auxiliary share of d(norm.weight) / d(router.weight) travels as a SHADOW segment of the flat
+    buffer and g += (N - 1) * shadow restores its full weight in front of the update; gradient accumulation works without
+    num_items_in_batch."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moe_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, n_before, n_calls, last_numel, flat_numel, shadow_names, g_router, g_norm, aliased in res:
+        assert n_before == 0 and n_calls == 1            # no collective in micro-step 1, exactly ONE for the optimizer step
+        assert last_numel == flat_numel                  # ... and it is the flat buffer (gradients + shadows + the two slots)
+        assert shadow_names == ["projector.norm.weight", "projector.router.weight"] and aliased == 1
+        assert g_router == 1.0 + 2.0 * (5.0 - 1.0) and g_norm == 0.0
+
+
 def test_trainer_two_ranks_deferred_update():
     """overlap_allreduce: same collective, same update order, applied one encoder-forward later (hidden under the next
     step's frozen-encoder pass on the GPU)."""

@@ -295,7 +295,7 @@ __global__ void moe_router_bwd_kernel(const float* __restrict__ dtopw, const flo
   for (int e = 0; e < E; ++e) { p[e] = probs[(long)t * E + e]; dp[e] = 0.f; }
   const int i0 = topi[2 * t], i1 = topi[2 * t + 1];
   const float r0 = topraw[2 * t], r1 = topraw[2 * t + 1], den = r0 + r1 + 1e-6f;
-  const float g0 = dtopw[2 * t], g1 = dtopw[2 * t + 1];
+  const float g0 = dtopw ? dtopw[2 * t] : 0.f, g1 = dtopw ? dtopw[2 * t + 1] : 0.f;   // (null: the auxiliary-loss share alone)
   const float common = (g0 * r0 + g1 * r1) / (den * den);
   dp[i0] = g0 / den - common;
   dp[i1] = g1 / den - common;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void moe_norm_bwd_kernel(const float* __restri
   for (int e = 0; e < MOE_MAX_E; ++e) wre[e] = e < E ? wr[(long)e * In + c] : 0.f;
   float acc = 0.f;
   for (int t = t0; t < t1; ++t) {
-    float v = dxn_sh[(long)t * In + c] + dxn_slot[(long)slot_of[2 * t] * In + c] + dxn_slot[(long)slot_of[2 * t + 1] * In + c];
+    float v = dxn_sh ? dxn_sh[(long)t * In + c] + dxn_slot[(long)slot_of[2 * t] * In + c] + dxn_slot[(long)slot_of[2 * t + 1] * In + c] : 0.f;
 #pragma unroll
     for (int e = 0; e < MOE_MAX_E; ++e) if (e < E) v += dlogits[(long)t * E + e] * wre[e];
     const float xs = bf2f(x[(long)(t / rpb) * bs + (long)(t % rpb) * ld + c]);
@@ -559,6 +559,33 @@ static int moe_backward_impl(const ta_moe_weights* w, const void* x, int B, int 
   TA_LAUNCH(moe_router_dw_kernel, dim3(ta_cdiv(d.In, 256), 64), tb, 0, st, s.dlogits, t.xn, d_router_w, d.T, d.In, E, 64);
   TA_LAUNCH(moe_norm_bwd_kernel, dim3(ta_cdiv(d.In, 256), 128), tb, 0, st, s.dxn_sh, s.dxn_slot, t.slot_of, s.dlogits, w->router_w,
             (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In, t.rstd, d_norm_w, d.T, d.In, E, 128);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// round 4: the share of d(norm.weight) / d(router.weight) that comes from the AUXILIARY losses alone (d_aux * d aux / d .): the three
+// tail kernels of the backward with no expert-path inputs.  The trainer keeps it in a shadow of the flat gradient buffer: HF adds the
+// auxiliary term at FULL weight next to a token-normalised CE, so with gradients of CE-sum + aux in the flat buffer and the global
+// token count N known only after the all-reduce, the optimizer's division by N is undone for this share alone
+// (g += (N - 1) * shadow) -- which is what lets MoE run on ONE collective like every other configuration.
+extern "C" int ta_moe_router_aux_grads(const ta_moe_weights* w, const void* x, int B, int S, const float* d_aux_dev, const float* noise,
+                                       int training, const void* tape, float* d_norm_w_aux, float* d_router_w_aux, void* ws,
+                                       long ws_bytes, hipStream_t st) {
+  const MoeDims d = moe_dims(w, B, S);
+  if (B <= 0 || d.N <= 0) return TA_OK;
+  if (!d_aux_dev || !d_norm_w_aux || !d_router_w_aux) return TA_ERR_ARG;
+  MoeTape t = moe_tape(w, B, S, (void*)tape);
+  MoeWs s = moe_ws(w, B, S, ws);
+  if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
+  const int E = d.E;
+  if (hipMemsetAsync(d_norm_w_aux, 0, (size_t)d.In * 4, st) != hipSuccess || hipMemsetAsync(d_router_w_aux, 0, (size_t)E * d.In * 4, st) != hipSuccess)
+    return TA_ERR_LAUNCH;
+  dim3 tb(256);
+  TA_LAUNCH(moe_router_bwd_kernel, dim3(ta_cdiv(d.T, 256)), tb, 0, st, (const float*)nullptr, t.probs, t.topi, t.topraw, t.lse,
+            training ? noise : nullptr, t.psum, s.dlogits, d.T, E, 0.f, d_aux_dev, w->aux_coef, w->z_coef, training);
+  TA_LAUNCH(moe_router_dw_kernel, dim3(ta_cdiv(d.In, 256), 64), tb, 0, st, s.dlogits, t.xn, d_router_w_aux, d.T, d.In, E, 64);
+  TA_LAUNCH(moe_norm_bwd_kernel, dim3(ta_cdiv(d.In, 256), 128), tb, 0, st, (const float*)nullptr, (const float*)nullptr, t.slot_of, s.dlogits,
+            w->router_w, (const bf16_t*)x, (long)S * w->enc_dim, d.N, (long)d.In, t.rstd, d_norm_w_aux, d.T, d.In, E, 128);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

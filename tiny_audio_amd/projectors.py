@@ -126,6 +126,9 @@ class MoEAudioProjector(nn.Module):
     def get_output_length(self, input_length):
         return (input_length - self.k) // self.k + 1
 
+    # the parameters the auxiliary losses reach (through the router logits): ASRTrainer gives them a shadow gradient segment
+    aux_shadow_params = ("norm.weight", "router.weight")
+
     def get_aux_loss(self):
         return self.last_aux_loss
 

@@ -239,6 +239,23 @@ def moe_projector_backward(dy: Tensor, d_aux: Tensor, xb: Tensor, noise: Optiona
     return [g_norm, g_router, GW1, Gb1, GW2, Gb2]
 
 
+def moe_router_aux_grads(d_aux: Tensor, xb: Tensor, noise: Optional[Tensor], tape: Tensor, handle: int, training: bool):
+    """d_aux * d(aux) / d(norm.weight), d(router.weight) alone (ta_moe_router_aux_grads): the part of those two gradients that must
+    NOT be divided by the global token count."""
+    mod = module_of(handle)
+    B, S, _ = xb.shape
+    wts = mod._packed_weights()
+    L_ = _lib.lib()
+    dev = xb.device
+    sn = torch.empty(mod.norm.weight.shape, device=dev, dtype=F32)
+    sr = torch.empty(mod.router.weight.shape, device=dev, dtype=F32)
+    ws = torch.empty(L_.ta_moe_bwd_workspace_bytes(C.byref(wts), B, S), device=dev, dtype=torch.uint8)
+    da = d_aux.to(device=dev, dtype=F32).reshape(1).contiguous()
+    _lib.check(L_.ta_moe_router_aux_grads(C.byref(wts), ptr(xb), B, S, ptr(da), ptr(noise), int(training), ptr(tape), ptr(sn), ptr(sr),
+                                          ptr(ws), ws.numel(), stream()), "ta_moe_router_aux_grads")
+    return sn, sr
+
+
 @moe_projector_backward.register_fake
 def _(dy, d_aux, xb, noise, tape, handle, training):
     mod = module_of(handle)
@@ -269,6 +286,11 @@ def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
                          device=xb.device, dtype=F32)
     g_norm, g_router, GW1, Gb1, GW2, Gb2 = torch.ops.ta355.moe_projector_backward(dy, d_aux, xb, noise, tape, ctx.handle,
                                                                                    ctx.training)
+    shadow = getattr(ctx.module, "_aux_shadow", None)         # (ASRTrainer: the auxiliary-loss share of the two router-path gradients)
+    if shadow is not None and ctx.training:
+        sn, sr = moe_router_aux_grads(d_aux, xb, noise, tape, ctx.handle, ctx.training)
+        shadow["norm.weight"].add_(sn)
+        shadow["router.weight"].add_(sr)
     grads = [g_norm, g_router]                                # the order of MoEAudioProjector._param_list()
     for i in range(GW1.shape[0]):
         grads += [GW1[i], Gb1[i], GW2[i], Gb2[i]]

@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 
 
 @dataclass
@@ -87,11 +87,16 @@ def decay_flags(names, params, overrides: bool, layernorm_ids=frozenset()):
 
 class FlatTrainable:
     """All trainable parameters as views of ONE fp32 buffer; gradients likewise, plus two trailing slots:
-    [ ... grads ..., label_token_count, loss_sum ].  (SURVEY.md section 2a, C1 + C2 folded together.)"""
+    [ ... grads ..., (shadows ...,) label_token_count, loss_sum ].  (SURVEY.md section 2a, C1 + C2 folded together.)
+
+    ``shadow_of``: names of parameters that also get a SHADOW gradient segment between the gradients and the two slots -- the share
+    of their gradient that must keep full weight under the optimizer's division by the global token count (the MoE projector's
+    auxiliary losses, round 4): it travels in the same all-reduce, and ``g += (count - 1) * shadow`` before the update undoes the
+    division for that share."""
 
     EXTRA = 2
 
-    def __init__(self, named_params, device=None):
+    def __init__(self, named_params, device=None, shadow_of=()):
         self.names, self.params = zip(*[(n, p) for n, p in named_params if p.requires_grad])
         device = device or self.params[0].device
         self.sizes = [p.numel() for p in self.params]
@@ -99,8 +104,15 @@ class FlatTrainable:
         for s in self.sizes:
             self.offsets.append(self.offsets[-1] + ((s + 3) // 4) * 4)      # keep every segment 16-byte aligned
         self.n = self.offsets[-1]
+        self.shadow_names = [n for n in self.names if n in set(shadow_of)]
+        self.shadow_offsets, so = {}, self.n
+        for n in self.shadow_names:
+            sz = self.sizes[self.names.index(n)]
+            self.shadow_offsets[n] = (so, sz)
+            so += ((sz + 3) // 4) * 4
+        self.n_all = so                                   # gradients + shadows
         self.flat_p = torch.zeros(self.n, device=device, dtype=torch.float32)
-        self.flat_g = torch.zeros(self.n + self.EXTRA, device=device, dtype=torch.float32)
+        self.flat_g = torch.zeros(self.n_all + self.EXTRA, device=device, dtype=torch.float32)
         self.flat_m = torch.zeros(self.n, device=device, dtype=torch.float32)
         self.flat_v = torch.zeros(self.n, device=device, dtype=torch.float32)
         with torch.no_grad():
@@ -116,11 +128,19 @@ class FlatTrainable:
 
     @property
     def count_slot(self):
-        return self.flat_g[self.n: self.n + 1]
+        return self.flat_g[self.n_all: self.n_all + 1]
 
     @property
     def loss_slot(self):
-        return self.flat_g[self.n + 1: self.n + 2]
+        return self.flat_g[self.n_all + 1: self.n_all + 2]
+
+    def shadow(self, name):
+        o, sz = self.shadow_offsets[name]
+        return self.flat_g[o:o + sz].view_as(self.params[self.names.index(name)])
+
+    def grad_of(self, name):
+        i = self.names.index(name)
+        return self.flat_g[self.offsets[i]:self.offsets[i] + self.sizes[i]].view_as(self.params[i])
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -189,7 +209,13 @@ class ASRTrainer:
         self.model, self.args, self.group = model, args or TrainingArguments(), group
         self.decoder_learning_rate, self.decoder_weight_decay = decoder_learning_rate, decoder_weight_decay
         self.projector_weight_decay = projector_weight_decay
-        self.flat = FlatTrainable(list(model.named_parameters()))
+        # auxiliary losses (MoE balance + z loss) reach projector.norm.weight and projector.router.weight only: their auxiliary share
+        # gets a shadow segment in the flat buffer (see training_step), and the projector fills it in its backward
+        proj = getattr(model, "projector", None)
+        aux_names = [f"projector.{n}" for n in getattr(proj, "aux_shadow_params", ())] if hasattr(proj, "get_aux_loss") else []
+        self.flat = FlatTrainable(list(model.named_parameters()), shadow_of=aux_names)
+        if self.flat.shadow_names:
+            proj._aux_shadow = {n[len("projector."):]: self.flat.shadow(n) for n in self.flat.shadow_names}
         overrides = decoder_learning_rate is not None or decoder_weight_decay is not None or projector_weight_decay is not None
         ln_ids = frozenset(id(p) for m in model.modules() if isinstance(m, torch.nn.LayerNorm) for p in m.parameters(recurse=False))
         self.flat.decay = decay_flags(self.flat.names, self.flat.params, overrides, ln_ids)
@@ -218,25 +244,18 @@ class ASRTrainer:
         if lm is not None and getattr(lm, "train_base", False):
             lm._ft_versions = None              # bf16 W / W^T images are rebuilt before the next forward
 
-    def _global_label_tokens(self, batch, n_local):
-        """Label tokens of this optimizer step over all ranks, as a device scalar (HF Trainer gathers the same number
-        before the forward when average_tokens_across_devices is on: TF:trainer.py get_batch_samples)."""
-        dev = self.flat.flat_p.device
-        cnt = torch.full((1,), float(n_local), device=dev, dtype=torch.float32)
-        if _distributed(self.group):
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
-        return cnt
-
     def training_step(self, batch: dict, num_items_in_batch=None, return_logits: bool = False):
         """One micro-batch: forward + backward of SUM-CE; optimizer step every gradient_accumulation_steps.
         Returns the (not yet normalised) CE sum of this micro-batch.
 
         Auxiliary losses (MoE balance + z loss): HF Trainer back-propagates ``sum(nll) / num_items_in_batch + aux`` per
         micro-batch -- the auxiliary term is NOT token-normalised (tiny_audio/asr_modeling.py:528-531 adds it after the
-        LM's loss).  Here every rank back-propagates the CE SUM and the optimizer divides by the global token count, so
-        the auxiliary term is back-propagated as ``aux * num_items_in_batch`` to keep its full weight.
-        ``num_items_in_batch`` (label tokens of the whole optimizer step, all ranks) is needed only then; it defaults to
-        this micro-batch's count summed over the ranks, which is exact without gradient accumulation."""
+        LM's loss).  Here every rank back-propagates the CE SUM + aux and the optimizer divides by the global token count N,
+        which is known only after the all-reduce.  Round 4: the projector's backward ALSO writes the auxiliary share of the two
+        gradients it reaches (norm.weight, router.weight) into a shadow segment of the flat buffer; shadow and gradients travel in
+        the ONE collective of the step, and ``g += (N - 1) * shadow`` in front of the update leaves ``g_ce / N + g_aux``: full
+        weight, no second collective, no ``num_items_in_batch`` needed (rounds 1-3 all-reduced the count ahead of the backward
+        and back-propagated ``aux * N``).  ``num_items_in_batch`` is accepted and ignored."""
         after_encoder = self._apply_pending if self._pending is not None else None
         if self._pending is None and self._micro == 0 and self._need_zero:
             self._zero()
@@ -246,13 +265,9 @@ class ASRTrainer:
         ce = getattr(out, "loss_ce", None)
         aux = out.aux_loss if (ce is not None and out.aux_loss is not None and out.aux_loss.numel() > 0) else None
         if aux is not None:
-            if num_items_in_batch is None:
-                if self.args.gradient_accumulation_steps > 1:
-                    raise ValueError("a projector with an auxiliary loss under gradient accumulation needs num_items_in_batch "
-                                     "(label tokens of the whole optimizer step over all ranks)")
-                num_items_in_batch = self._global_label_tokens(batch, out.n_label_tokens)
-            n = num_items_in_batch if torch.is_tensor(num_items_in_batch) else float(num_items_in_batch)
-            (ce + aux.to(ce.device) * n).backward()
+            if not self.flat.shadow_names:
+                raise _lib.Ta355Error("a projector with an auxiliary loss must name the parameters it reaches (aux_shadow_params)")
+            (ce + aux.to(ce.device)).backward()
             with torch.no_grad():
                 self._aux_sum = aux.detach().clone() if self._aux_sum is None else self._aux_sum + aux.detach()
         else:
@@ -300,6 +315,11 @@ class ASRTrainer:
     def _apply_update(self):
         a, f = self.args, self.flat
         self.global_step += 1
+        if f.shadow_names:                      # the auxiliary share keeps its full weight under the division by the token count
+            with torch.no_grad():
+                nm1 = f.count_slot - 1.0
+                for n in f.shadow_names:
+                    f.grad_of(n).addcmul_(f.shadow(n), nm1.expand_as(f.shadow(n)))
         self.sqnorm.zero_()
         ops.grad_sqnorm(f.grads, self.sqnorm)
         mult = lr_multiplier(self.global_step - 1, a)
