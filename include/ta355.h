@@ -201,10 +201,15 @@ typedef struct {
   const float* norm_w;
   const float *rope_cos, *rope_sin; /* [max_pos, head_dim/2] */
   const ta_lm_layer* layers;        /* host array */
-  int lora_rank;                    /* 0 = no adapters; else r (8) */
+  int lora_rank;                    /* 0 = no adapters; else r with 3 r <= 64 (the reference default 8; 4 and 16 are tested) */
   float lora_scale;                 /* alpha / r */
   int train_base;                   /* 1 = full decoder fine-tuning (freeze_language_model=False, tiny_audio/asr_config.py:77,
                                        configs/experiments/embedded.yaml:23): the tape also keeps what ta_lm_wgrads needs */
+  int lora_groups;                  /* lora_target_modules subsets (tiny_audio/asr_config.py:72-75): bit g set = group g of
+                                       {1 q|k|v, 2 o, 4 gate|up, 8 down} carries an adapter; 0 = all four.  A group without
+                                       a bit costs nothing (no rank-space GEMM, no K extension, gradients left at zero); inside
+                                       a group, members that are not targeted keep A = B = 0 in the masters and so get exactly
+                                       zero gradients (dA = s (dy B)^T x, dB = dy^T (x A^T)). */
 } ta_lm_weights;
 
 /* Gradients of the LM's own weights (full decoder fine-tuning).  All f32, ACCUMULATED (+=) into the caller's buffers, which

@@ -172,9 +172,10 @@ def init_qformer_projector(enc_dim, llm_dim, hidden=None, layers=2, ffn=None, nq
     return w
 
 
-def init_lora(cfg, rank=8, seed=4, b_std=0.02):
-    """LoRA adapters on q,k,v,o,gate,up,down of every layer (tiny_audio/asr_config.py:142-150, r=8).  peft initialises
-    lora_A kaiming-uniform and lora_B = 0; B is given small random values here so that parity is non-trivial."""
+def init_lora(cfg, rank=8, seed=4, b_std=0.02, targets=None):
+    """LoRA adapters on q,k,v,o,gate,up,down of every layer (tiny_audio/asr_config.py:142-150, r=8), or on the ``targets``
+    subset of them (peft suffix names, e.g. ("q_proj", "v_proj")).  peft initialises lora_A kaiming-uniform and lora_B = 0;
+    B is given small random values here so that parity is non-trivial."""
     rng = np.random.RandomState(seed)
     D, F = cfg["hidden"], cfg["ffn"]
     hq, hkv, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
@@ -183,6 +184,8 @@ def init_lora(cfg, rank=8, seed=4, b_std=0.02):
     lo = {}
     for i in range(cfg["layers"]):
         for n, (o, k) in dims.items():
+            if targets is not None and n.split(".")[-1] not in targets:
+                continue
             b = 1.0 / np.sqrt(k)
             lo[f"model.layers.{i}.{n}.lora_A"] = rng.uniform(-b, b, size=(rank, k)).astype(np.float32)
             lo[f"model.layers.{i}.{n}.lora_B"] = (b_std * rng.standard_normal((o, rank))).astype(np.float32)

@@ -168,25 +168,30 @@ def gen_lora():
     Qwen3 module functionally: every targeted Linear weight is W + (alpha/r) * B @ A (peft's documented forward,
     dropout 0) with A, B as autograd leaves; torch autograd through transformers' Qwen3 gives d loss / dA, dB."""
     from torch.func import functional_call
+    from tests.golden.recipe import LORA_CASES
     cfg = SMALL["lm"]
     wnp = OW.init_lm(cfg, seed=1)
     m = build_lm(cfg, wnp)
     m.requires_grad_(False)
-    lo = {k: t(v).requires_grad_(True) for k, v in OW.init_lora(cfg, rank=8, seed=4).items()}
-    scale = 32.0 / 8.0
-    params = {k: v for k, v in m.named_parameters()}
-    merged = dict(params)
-    for name in sorted({k.rsplit(".", 1)[0] for k in lo}):
-        merged[name + ".weight"] = params[name + ".weight"] + scale * (lo[name + ".lora_B"] @ lo[name + ".lora_A"])
-    merged["lm_head.weight"] = merged["model.embed_tokens.weight"]
-    x, att, lab = lm_input()
-    xt = t(x).requires_grad_(True)
-    out = functional_call(m, merged, args=(), kwargs=dict(inputs_embeds=xt, attention_mask=t(att), labels=t(lab)))
-    out.loss.backward()
-    keep = [k for k in lo if ".layers.0.self_attn.q_proj" in k or ".layers.1.mlp.down_proj" in k
-            or ".layers.0.self_attn.v_proj" in k or ".layers.1.self_attn.o_proj" in k or ".layers.0.mlp.up_proj" in k]
-    save("lora_small.npz", loss=out.loss.detach().numpy(), dx=xt.grad.numpy(), logits_row=out.logits.detach().numpy()[0, 30:34],
-         **{"g." + k: lo[k].grad.numpy() for k in keep})
+    for fname, rank, alpha, targets in LORA_CASES:
+        lo = {k: t(v).requires_grad_(True) for k, v in OW.init_lora(cfg, rank=rank, seed=4, targets=targets).items()}
+        scale = float(alpha) / rank
+        params = {k: v for k, v in m.named_parameters()}
+        merged = dict(params)
+        for name in sorted({k.rsplit(".", 1)[0] for k in lo}):
+            merged[name + ".weight"] = params[name + ".weight"] + scale * (lo[name + ".lora_B"] @ lo[name + ".lora_A"])
+        merged["lm_head.weight"] = merged["model.embed_tokens.weight"]
+        x, att, lab = lm_input()
+        xt = t(x).requires_grad_(True)
+        out = functional_call(m, merged, args=(), kwargs=dict(inputs_embeds=xt, attention_mask=t(att), labels=t(lab)))
+        out.loss.backward()
+        if targets is None and rank == 8:      # (the round-1 fixture keeps its 10 arrays)
+            keep = [k for k in lo if ".layers.0.self_attn.q_proj" in k or ".layers.1.mlp.down_proj" in k
+                    or ".layers.0.self_attn.v_proj" in k or ".layers.1.self_attn.o_proj" in k or ".layers.0.mlp.up_proj" in k]
+        else:
+            keep = [k for k in lo if ".layers.0." in k or ".layers.1.self_attn" in k]
+        save(fname, loss=out.loss.detach().numpy(), dx=xt.grad.numpy(), logits_row=out.logits.detach().numpy()[0, 30:34],
+             **{"g." + k: lo[k].grad.numpy() for k in keep})
 
 
 # ----------------------------------------------------------------------------- 5./6. whole model

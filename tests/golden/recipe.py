@@ -85,6 +85,13 @@ def gen_lm_weights():
     return w
 
 
+# LoRA fixtures (file, rank, alpha, lora_target_modules; None = all 7 linears): the reference default and the other values of
+# tiny_audio/asr_config.py:72-75's knobs -- a partial q|k|v group, a rank that needs three 16-column blocks, a partial gate|up group
+LORA_CASES = (("lora_small.npz", 8, 32, None),
+              ("lora_r4_qv_small.npz", 4, 32, ("q_proj", "v_proj")),
+              ("lora_r16_small.npz", 16, 32, None),
+              ("lora_r8_kou_small.npz", 8, 16, ("k_proj", "o_proj", "up_proj")))
+
 QF = dict(heads=4, layers=2, window=15, downsample=5, eps=1e-12, ffn=512)       # reduced QFormer (hidden = encoder dim 256)
 
 

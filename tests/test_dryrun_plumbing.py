@@ -138,8 +138,26 @@ def test_lora_stage2_plumbing(dry):
     tr.training_step(batch)                                   # masters re-homed into the flat buffer -> pointers rebound
     assert lmod._layers_arr[1].la_d == lmod.lora_la_d.data_ptr() + lmod.lora_la_d[0].numel() * 4
     assert lmod.lora_la_d.data_ptr() >= tr.flat.flat_p.data_ptr()
+    # other values of asr_config.py:72-75's knobs (round 4): rank 16 on a target subset -> peft's count, untargeted members stay zero
+    # and are not exported, the C struct carries the live groups; 3 r > 64 and unknown targets are refused
+    m3 = ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16, lora_alpha=16,
+                            lora_target_modules=["q_proj", "v_proj", "down_proj"]), device="cpu", init="random")
+    l3 = m3.language_model
+    assert l3.lora_rank == 16 and l3.lora_groups == 0b1001 and l3._w.lora_groups == 0b1001 and abs(l3._w.lora_scale - 1.0) < 1e-6
+    D, F, hd = 256, 512, lm["head_dim"]
+    assert l3.lora_param_count() == 3 * 16 * ((D + 4 * hd) + (D + 2 * hd) + (F + D))
+    la3, gu3 = l3.lora_la_qkv.detach(), l3.lora_la_gu.detach()
+    assert float(la3[:, 16:32].abs().max()) == 0.0 and float(la3[:, :16].abs().max()) > 0 and float(gu3.abs().max()) == 0.0
+    sd3 = l3.export_lora_state_dict(prefix="model.", suffix="")
+    assert len(sd3) == 3 * 3 * 2 and not any("k_proj" in k or "o_proj" in k or "gate_proj" in k for k in sd3)
+    lo3 = OW.init_lora(lm, rank=16, seed=4, targets=("q_proj", "v_proj", "down_proj"))
+    l3.load_lora_state_dict(lo3)
+    back3 = l3.export_lora_state_dict(prefix="model.", suffix="")
+    assert set(back3) == set(lo3) and all(np.array_equal(back3[k].numpy(), lo3[k]) for k in lo3)
     with pytest.raises(NotImplementedError):
-        ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=16), device="cpu", init="none")
+        ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_rank=32), device="cpu", init="none")
+    with pytest.raises(ValueError):
+        ASRModel(ASRConfig(audio_config=enc, text_config=lm, use_lora=True, lora_target_modules=["q_proj", "lm_head"]), device="cpu", init="none")
 
 
 def test_full_finetune_plumbing(dry, tmp_path):

@@ -314,13 +314,18 @@ def _lora_case(cfg, wL, lo, x_ids, att, lab):
         assert relmax(npy(got_g[k]), ref_g[k]) < 6e-2, k
 
 
-def test_lora_vs_golden_config(golden):
-    """Reduced config of tests/golden/lora_small.npz (values produced by the reference's Qwen3 + merged adapters)."""
-    g = golden("lora_small.npz")
+@pytest.mark.parametrize("case", R.LORA_CASES, ids=lambda c: c[0][:-4])
+def test_lora_vs_golden_config(golden, case):
+    """Reduced configs of tests/golden/lora*_small.npz (values produced by the reference's Qwen3 + merged adapters): the reference
+    default (r = 8, all 7 linears) and other values of tiny_audio/asr_config.py:72-75's lora_rank / lora_alpha /
+    lora_target_modules -- members outside the target list stay exactly zero and are not exported."""
+    fname, rank, alpha, targets = case
+    g = golden(fname)
     cfg = R.SMALL["lm"]
-    wL, lo = OW.init_lm(cfg, seed=1), OW.init_lora(cfg, rank=8, seed=4)
+    wL, lo = OW.init_lm(cfg, seed=1), OW.init_lora(cfg, rank=rank, seed=4, targets=targets)
     lm = Qwen3MI355X(LMConfig(cfg), DEV).load_state_dict_hf(wL)
-    lm.enable_lora(rank=8, alpha=32).load_lora_state_dict(lo)
+    lm.enable_lora(rank=rank, alpha=alpha, target_modules=None if targets is None else list(targets)).load_lora_state_dict(lo)
+    assert lm.lora_param_count() == sum(v.size for v in lo.values())          # peft's trainable-parameter count
     x, att, lab = R.lm_input()                                    # inputs_embeds-level fixture: feed as "audio" rows
     B, L, D = x.shape
     ids = torch.full((B, L), R.SMALL["audio_token_id"], dtype=torch.int64, device=DEV)
@@ -334,11 +339,20 @@ def test_lora_vs_golden_config(golden):
     d_audio, _, lg = lm.backward_from_ctx(ctx, B * L)
     valid = att.astype(bool)
     assert cosine(npy(d_audio).reshape(B, L, D)[valid], g["dx"][valid]) > 0.999
+    masters = [p_.detach().clone() for p_ in lm.lora_parameters()]
     for p_, g_ in zip(lm.lora_parameters(), lg):
         p_.data.copy_(g_)
     got = lm.export_lora_state_dict(prefix="model.", suffix="")
+    assert set(got) == set(lo)
     for k in [k[2:] for k in g.files if k.startswith("g.")]:
         assert cosine(npy(got[k]), g["g." + k]) > 0.998, k
+    # what is not targeted has zero masters AND zero gradients, element for element
+    n_live = sum(int((g_ != 0).sum()) for g_ in lg)
+    assert n_live <= lm.lora_param_count() and n_live > 0.98 * lm.lora_param_count()
+    for m_, g_ in zip(masters, lg):
+        dead_rows = (m_ == 0).all(dim=-1)
+        if targets is not None:
+            assert bool((g_[dead_rows] == 0).all())
 
 
 def test_lora_true_width_vs_oracle():

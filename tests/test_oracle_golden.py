@@ -147,6 +147,32 @@ def test_qwen3_lora_grads(golden):
         assert relerr(grads[k], g["g." + k]) < 2e-4, k
 
 
+@pytest.mark.parametrize("case", R.LORA_CASES[1:], ids=lambda c: c[0][:-4])
+def test_qwen3_lora_rank_and_target_subsets(golden, case):
+    """tiny_audio/asr_config.py:72-75 (lora_rank, lora_alpha, lora_target_modules): other ranks and target subsets of the
+    restated adapter formula vs torch autograd through the reference's Qwen3 (fixtures of make_golden.py:gen_lora)."""
+    fname, rank, alpha, targets = case
+    g = golden(fname)
+    cfg = R.SMALL["lm"]
+    w, lo = OW.init_lm(cfg, seed=1), OW.init_lora(cfg, rank=rank, seed=4, targets=targets)
+    n_t = 7 if targets is None else len(targets)
+    assert len(lo) == 2 * n_t * cfg["layers"]
+    x, att, lab = R.lm_input()
+    scale = float(alpha) / rank
+    logits, cache = OQ.lm_forward(x, att, w, cfg, lora=lo, lora_scale=scale)
+    loss, dlogits, _ = OQ.causal_lm_loss(logits, lab)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert relerr(logits[0, 30:34], g["logits_row"]) < 5e-5
+    grads = {}
+    dx = OQ.lm_backward_dx(dlogits, w, cfg, cache, lo, scale, grads)
+    assert relerr(dx, g["dx"]) < 1e-4
+    assert set(grads) == set(lo)
+    keys = [k[2:] for k in g.files if k.startswith("g.")]
+    assert keys
+    for k in keys:
+        assert relerr(grads[k], g["g." + k]) < 2e-4, k
+
+
 def test_qformer_projector(golden):
     """Section 8(f) rank 4: QFormer projector forward + every parameter gradient vs the reference module (eval mode)."""
     from oracle import qformer as OQF

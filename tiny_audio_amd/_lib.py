@@ -84,7 +84,8 @@ class LmWeights(C.Structure):
                 ("max_pos", C.c_int), ("eps", C.c_float),
                 ("embed_f32", C.c_void_p), ("embed_bf16", C.c_void_p), ("embed_t_bf16", C.c_void_p),
                 ("norm_w", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float), ("train_base", C.c_int)]
+                ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float), ("train_base", C.c_int),
+                ("lora_groups", C.c_int)]
 
 
 class LmLayerWgrads(C.Structure):

@@ -99,6 +99,9 @@ def load_pretrained(model_cls, pretrained_path: str, device="cuda", config: Opti
             a = json.load(f)
         if int(a.get("r", config.lora_rank)) != model.language_model.lora_rank:
             raise ValueError("adapter rank differs from config.lora_rank")
+        have = {t.split(".")[-1] for t in model.language_model.lora_targets}
+        if "target_modules" in a and {t.split(".")[-1] for t in a["target_modules"]} != have:
+            raise ValueError("adapter target_modules differ from config.lora_target_modules")
         model.language_model.lora_alpha = int(a.get("lora_alpha", config.lora_alpha))
         model.language_model._finalize_lora_scale()
         model.language_model.load_lora_state_dict(load_file(af))

@@ -242,6 +242,19 @@ inline bool lm_res_bf16() {
   static const bool v = [] { const char* e = getenv("TA355_LM_RES_F32"); return !(e && *e == '1'); }();
   return v;
 }
+// side stream of the LoRA backward (see lora_bwd in ta_lm_backward): created once per process, on the device current at first use
+struct LoraSide { hipStream_t s; hipEvent_t fork[2], join[2]; };
+static LoraSide* lora_side() {
+  static LoraSide ls;
+  static const bool ok = [] {
+    if (hipStreamCreateWithFlags(&ls.s, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 2; ++i)
+      if (hipEventCreateWithFlags(&ls.fork[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ls.join[i], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }();
+  return ok ? &ls : nullptr;
+}
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
@@ -306,7 +319,7 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
   return t;
 }
 struct LmWs {
-  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB;
+  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB, *dyB2;
   float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
   // trainable LM: transposed bf16 images of one dW product's operands ([rows, Kp], Kp = tokens rounded up to 64) and
   // the split-K slabs of the dW GEMMs
@@ -341,6 +354,7 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dv = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
   s.dqkv = c.take<bf16_t>((size_t)d.M * d.NQKV);
   s.dyB = c.take<bf16_t>((size_t)d.M * 64);
+  s.dyB2 = c.take<bf16_t>((size_t)d.M * 64);
   const int sp = pick_splits(nl, d.D, w->vocab_pad);
   s.skws = c.take<float>((size_t)ta_gemm_splitk_ws_bytes(nl, d.D, sp) / 4 + 4);
   s.tA = s.tB = nullptr; s.wsk = nullptr;
@@ -381,7 +395,8 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
   const float scale = 1.0f / sqrtf((float)d.hd);
   const bool lora = w->lora_rank > 0;
   const int r = w->lora_rank;
-  if (lora && r != 8) return TA_ERR_ARG;   // one 64-wide K tile holds up to 3 members of rank 8
+  if (lora && (r < 1 || 3 * r > 64)) return TA_ERR_ARG;   // one 64-wide K tile holds the 3 members of the q|k|v group
+  const int lgm = lora ? (w->lora_groups ? w->lora_groups : 15) : 0;      // groups that carry an adapter (1 qkv, 2 o, 4 gate|up, 8 down)
   // y = x W^T + xa Bext^T with xa = x (s Acat)^T: one skinny GEMM for xa, then the frozen GEMM runs one extra K-tile
   ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen GEMM (consumed and cleared by it)
   auto lora_fwd = [&](const bf16_t* x, int in, const LoraImg& g, bf16_t* xa, int members) -> int {
@@ -426,14 +441,14 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     for (int l = 0; l < reps; ++l) {
       const ta_lm_layer& Ll = w->layers[l];
       const LmLayerTape ql = imgs_of(l);
-      RC(ta_i_lora_pack_a(Ll.la_qkv, w->lora_scale, ql.i_qkv.a, ql.i_qkv.at, 3 * r, d.D, per, strided ? ms[0] : 0, is_, st));
-      RC(ta_i_lora_pack_b(Ll.lb_qkv, ql.i_qkv.b, ql.i_qkv.bt, d.NQKV, r, bq, bk, per, strided ? ms[1] : 0, is_, st));
-      RC(ta_i_lora_pack_a(Ll.la_o, w->lora_scale, ql.i_o.a, ql.i_o.at, r, bq, per, strided ? ms[2] : 0, is_, st));
-      RC(ta_i_lora_pack_b(Ll.lb_o, ql.i_o.b, ql.i_o.bt, d.D, r, NB, NB, per, strided ? ms[3] : 0, is_, st));
-      RC(ta_i_lora_pack_a(Ll.la_gu, w->lora_scale, ql.i_gu.a, ql.i_gu.at, 2 * r, d.D, per, strided ? ms[4] : 0, is_, st));
-      RC(ta_i_lora_pack_b(Ll.lb_gu, ql.i_gu.b, ql.i_gu.bt, 2 * d.F, r, d.F, NB, per, strided ? ms[5] : 0, is_, st));
-      RC(ta_i_lora_pack_a(Ll.la_d, w->lora_scale, ql.i_d.a, ql.i_d.at, r, d.F, per, strided ? ms[6] : 0, is_, st));
-      RC(ta_i_lora_pack_b(Ll.lb_d, ql.i_d.b, ql.i_d.bt, d.D, r, NB, NB, per, strided ? ms[7] : 0, is_, st));
+      if (lgm & 1) RC(ta_i_lora_pack_a(Ll.la_qkv, w->lora_scale, ql.i_qkv.a, ql.i_qkv.at, 3 * r, d.D, per, strided ? ms[0] : 0, is_, st));
+      if (lgm & 1) RC(ta_i_lora_pack_b(Ll.lb_qkv, ql.i_qkv.b, ql.i_qkv.bt, d.NQKV, r, bq, bk, per, strided ? ms[1] : 0, is_, st));
+      if (lgm & 2) RC(ta_i_lora_pack_a(Ll.la_o, w->lora_scale, ql.i_o.a, ql.i_o.at, r, bq, per, strided ? ms[2] : 0, is_, st));
+      if (lgm & 2) RC(ta_i_lora_pack_b(Ll.lb_o, ql.i_o.b, ql.i_o.bt, d.D, r, NB, NB, per, strided ? ms[3] : 0, is_, st));
+      if (lgm & 4) RC(ta_i_lora_pack_a(Ll.la_gu, w->lora_scale, ql.i_gu.a, ql.i_gu.at, 2 * r, d.D, per, strided ? ms[4] : 0, is_, st));
+      if (lgm & 4) RC(ta_i_lora_pack_b(Ll.lb_gu, ql.i_gu.b, ql.i_gu.bt, 2 * d.F, r, d.F, NB, per, strided ? ms[5] : 0, is_, st));
+      if (lgm & 8) RC(ta_i_lora_pack_a(Ll.la_d, w->lora_scale, ql.i_d.a, ql.i_d.at, r, d.F, per, strided ? ms[6] : 0, is_, st));
+      if (lgm & 8) RC(ta_i_lora_pack_b(Ll.lb_d, ql.i_d.b, ql.i_d.bt, d.D, r, NB, NB, per, strided ? ms[7] : 0, is_, st));
     }
   }
   for (int l = 0; l < w->n_layers; ++l) {
@@ -453,7 +468,7 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
       return gemm_opt(A, Wm, out, M, d.D, K, nullptr, res, 0, 0, o, st);
     };
     RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
-    if (lora) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv, 3));
+    if (lgm & 1) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv, 3));
     RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging (TA355_ATTN_FWD_FUSED=0: two kernels)
     static const bool fuse_fwd = [] { const char* e = getenv("TA355_ATTN_FWD_FUSED"); return !(e && *e == '0'); }();
@@ -471,15 +486,15 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
         return TA_ERR_LAUNCH;
     }
     if (!fused_fwd) RC(ta_attention_fwd(p.q, p.k, p.vt, p.ao, p.lse, kmask, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
-    if (lora) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o, 1));
+    if (lgm & 2) RC(lora_fwd(p.ao, d.nq * d.hd, p.i_o, p.xa_o, 1));
     RC(res_gemm(p.ao, Lw.wo, p.x1, d.nq * d.hd, p.x_in));
     bf16_t* xn2 = keep ? p.xn2_s : s.xn;
     bf16_t* act = keep ? p.act_s : s.act;
     RC(norm(p.x1, Lw.ln_post_w, xn2, p.r_post));
-    if (lora) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu, 2));
+    if (lgm & 4) RC(lora_fwd(xn2, d.D, p.i_gu, p.xa_gu, 2));
     RC(gemm_opt(xn2, Lw.wgu, p.gu, M, 2 * d.F, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     RC(ta_swiglu_fwd(p.gu, act, M, d.F, st));
-    if (lora) RC(lora_fwd(act, d.F, p.i_d, p.xa_d, 1));
+    if (lgm & 8) RC(lora_fwd(act, d.F, p.i_d, p.xa_d, 1));
     RC(res_gemm(act, Lw.wd, x_next, d.F, p.x1));
   }
   return TA_OK;
@@ -587,6 +602,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   const float scale = 1.0f / sqrtf((float)d.hd);
   if (d_audio && hipMemsetAsync(d_audio, 0, (size_t)n_audio_rows * d.D * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
   const int r = w->lora_rank;
+  const int lgm = lora ? (w->lora_groups ? w->lora_groups : 15) : 0;
   const int bq = d.nq * d.hd, bk = bq + d.nkv * d.hd;            // member row boundaries inside the fused qkv group
   auto zero_lora = [&](const ta_lm_lora_grads& g) -> bool {
     auto z = [&](float* q, size_t n) { return hipMemsetAsync(q, 0, n * 4, st) == hipSuccess; };
@@ -624,18 +640,42 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   //   dx  = dy W + dyB (sAcat) (K extension of the dX GEMM) dAcat = s (dyB)^T x
   // `arm` only prepares the K extension; the caller then issues the frozen dX GEMM.
   ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen dX GEMM
+  // round 4 experiment, OPT-IN (TA355_LORA_SIDE_STREAM=1): the two adapter-gradient products of a group (dB = dy^T xa, dA = s (dy B)^T x:
+  // HBM-bound streams over dy and x whose results nothing in the backward chain waits for) on a SIDE stream, beside the frozen dX GEMM
+  // that follows on the caller's stream.  Ordering: fork event after the group's dyB kernel; the caller's stream waits for the side
+  // kernel of group k before it leaves the lora_bwd of group k + 1 -- no kernel between two lora_bwd calls overwrites the earlier
+  // group's dy (d(x) bf16 / dgu / dqkv are rewritten only after the NEXT group's dX GEMM), and dyB alternates between two buffers.
+  // Measured 47.38 ms per LoRA step against 46.33 in line (3 + 3 runs, one box, profiles/r04_n_ab_lora_side_stream.txt): the GEMMs are
+  // one persistent workgroup per CU with 123-147 KB of LDS, so the side kernel's workgroups do not fit beside them -- they take CUs
+  // from the next GEMM's first round instead, and that round then ends with a straggler.
+  static const bool side_env = [] { const char* e = getenv("TA355_LORA_SIDE_STREAM"); return e && *e == '1'; }();
+  LoraSide* side = (lora && side_env && lgm == 15) ? lora_side() : nullptr;   // (target subsets change which kernels lie between two groups)
+  int side_n = 0;                                    // groups forked so far
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1) -> int {
-    RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, members * r, st));
+    bf16_t* dyB = (side && (side_n & 1)) ? s.dyB2 : s.dyB;
+    RC(ta_i_lora_skinny_nt(dy, N, g.bt, dyB, M, members * r, st));
     static const bool dual = [] { const char* e = getenv("TA355_LORA_TN_DUAL"); return !(e && *e == '0'); }();
-    if (dual) {                                        // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
-      RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, s.dyB, members * r, dla, 1, in, w->lora_scale,
-                              0, 0, 0, M, st));
-    } else {
-      RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, st));
-      RC(ta_i_lora_skinny_tn(x, in, s.dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, st));
+    hipStream_t ts = st;
+    if (side) {
+      const int k = side_n & 1;
+      if (hipEventRecord(side->fork[k], st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork[k], 0) != hipSuccess) return TA_ERR_LAUNCH;
+      ts = side->s;
     }
-    kx = opts_kext(s.dyB, g.at);
+    if (dual) {                                        // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
+      RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, dyB, members * r, dla, 1, in, w->lora_scale,
+                              0, 0, 0, M, ts));
+    } else {
+      RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, ts));
+      RC(ta_i_lora_skinny_tn(x, in, dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, ts));
+    }
+    if (side) {
+      const int k = side_n & 1;
+      if (hipEventRecord(side->join[k], side->s) != hipSuccess) return TA_ERR_LAUNCH;
+      if (side_n > 0 && hipStreamWaitEvent(st, side->join[k ^ 1], 0) != hipSuccess) return TA_ERR_LAUNCH;   // the previous group's
+      ++side_n;
+    }
+    kx = opts_kext(dyB, g.at);
     return TA_OK;
   };
   auto take_ext = [&]() { const ta_gemm_opts o = kx; kx = opts_none(); return o; };
@@ -693,7 +733,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     const ta_lm_layer& Lw = w->layers[l];
     const LmLayerTape& p = store[l];
     // ---- MLP: x2 = x1 + down(silu(gate) * up)
-    if (lora) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
+    if (lgm & 8) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
     const ta_lm_layer_wgrads* g = wg ? &wg->layers[l] : nullptr;
     if (g) RC(wgrad(s.dxb, d.D, p.act_s, d.F, g->dwd));
     // Measured (same box, 3 runs each): fusing the SwiGLU backward into this GEMM's epilogue makes the step 0.4 ms SLOWER
@@ -706,13 +746,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       RC(gemm_opt(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, o, st));
     }
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
-    if (lora) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
+    if (lgm & 4) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
     if (g) RC(wgrad(s.dgu, 2 * d.F, p.xn2_s, d.D, g->dwgu));
     RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
     if (g && g->dln_post) RC(ta_rmsnorm_dw(s.dxn, gb, p.x1, lm_res_bf16(), p.r_post, g->dln_post, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
-    if (lora) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
+    if (lgm & 2) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
     if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue (TA355_ATTN_BWD_FUSED=0:
@@ -750,7 +790,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
                             g ? g->dqn : nullptr, g ? g->dkn : nullptr, B, d.nq, d.nkv, L, st));
     }
     if (g) RC(wgrad(s.dqkv, d.NQKV, p.xn_s, d.D, g->dwqkv));
-    if (lora) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
+    if (lgm & 1) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
     RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));
     if (g && g->dln_in) RC(ta_rmsnorm_dw(s.dxn, gb, p.x_in, lm_res_bf16(), p.r_in, g->dln_in, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, l == 0));
@@ -759,5 +799,6 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     return TA_ERR_LAUNCH;
   if (d_audio && src_row) RC(ta_audio_grad_gather(src_row, dx, d_audio, M, d.D, st));
   if (wg && wg->dembed) RC(ta_embed_grad_scatter(ids, src_row, dx, wg->dembed, M, d.D, w->vocab, st));
+  if (side && side_n > 0 && hipStreamWaitEvent(st, side->join[(side_n - 1) & 1], 0) != hipSuccess) return TA_ERR_LAUNCH;   // join
   return TA_OK;
 }

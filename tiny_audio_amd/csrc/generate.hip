@@ -351,6 +351,7 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
   if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
   ta_i_lora_layer_imgs imgs[64];
   if (lora) lora_imgs_carve(w, (void*)lora_img, imgs);
+  const int lgm = lora ? (w->lora_groups ? w->lora_groups : 15) : 0;
   const float scale = 1.0f / sqrtf((float)HD);
   const size_t layer_elems = (size_t)B * Hkv * Lmax * HD;
   const size_t smem = ((size_t)Lmax + HD + 8 + 16 * HD) * sizeof(float);
@@ -374,17 +375,17 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
     bf16_t* kc = (bf16_t*)kcache + (size_t)l * layer_elems;
     bf16_t* vc = (bf16_t*)vcache + (size_t)l * layer_elems;
     RC(ta_rmsnorm_fwd(s.x, Lw.ln_in_w, s.xn, nullptr, s.r, B, D, w->eps, 0, st));
-    RC(linear(s.xn, Lw.wqkv, s.qkv0, NQKV, D, nullptr, true, lora ? &imgs[l].g[0] : nullptr));
+    RC(linear(s.xn, Lw.wqkv, s.qkv0, NQKV, D, nullptr, true, (lgm & 1) ? &imgs[l].g[0] : nullptr));
     TA_LAUNCH(lm_qkv_post_decode_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, s.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos,
               w->rope_sin, pos, slot_dev, s.q, kc, vc, Hq, Hkv, Lmax, w->eps);
     TA_CHECK_LAUNCH();
     TA_LAUNCH(attn_decode_kernel, dim3(Hq, B), dim3(256), smem, st, s.q, kc, vc, kmask, slot_dev, s.ao, Hq, Hkv, Lmax, scale);
     TA_CHECK_LAUNCH();
-    RC(linear(s.ao, Lw.wo, s.x1, D, bq, s.x, false, lora ? &imgs[l].g[1] : nullptr));
+    RC(linear(s.ao, Lw.wo, s.x1, D, bq, s.x, false, (lgm & 2) ? &imgs[l].g[1] : nullptr));
     RC(ta_rmsnorm_fwd(s.x1, Lw.ln_post_w, s.xn, nullptr, s.r, B, D, w->eps, 0, st));
-    RC(linear(s.xn, Lw.wgu, s.gu, 2 * F, D, nullptr, true, lora ? &imgs[l].g[2] : nullptr));
+    RC(linear(s.xn, Lw.wgu, s.gu, 2 * F, D, nullptr, true, (lgm & 4) ? &imgs[l].g[2] : nullptr));
     RC(ta_swiglu_fwd(s.gu, s.act, B, F, st));
-    RC(linear(s.act, Lw.wd, s.x, D, F, s.x1, false, lora ? &imgs[l].g[3] : nullptr));
+    RC(linear(s.act, Lw.wd, s.x, D, F, s.x1, false, (lgm & 8) ? &imgs[l].g[3] : nullptr));
   }
   RC(ta_rmsnorm_fwd(s.x, w->norm_w, s.hn, nullptr, s.r, B, D, w->eps, 0, st));
   RC(linear(s.hn, w->embed_bf16, logits, w->vocab_pad, D, nullptr, false, nullptr));

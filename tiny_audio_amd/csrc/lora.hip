@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void lora_pack_b_kernel(const float* __restric
   outT[(((long)(n >> 5) * 64 + j) << 5) + (n & 31)] = v;       // [N/32][64][32]
 }
 
-// out[c*so_c + (j - jlo(c))*so_j] += post * sum_m X[m, c] * Y[m, j],  j < R <= 32;  X bf16 [M, C], Y bf16 [M, 64].
+// out[c*so_c + (j - jlo(c))*so_j] += post * sum_m X[m, c] * Y[m, j],  j < R <= 64;  X bf16 [M, C], Y bf16 [M, 64].
 // The adapter gradients  dB = dY^T xa  and  dA = s (dY B)^T x  are "TN" products: the contraction index m is the ROW
 // index of both row-major operands, while an MFMA lane wants 8 consecutive k of one row/column.  Tiles of 32 rows are
 // therefore staged through LDS row-major (coalesced 16-B global loads) and read back transposed (8 ds_read_u16 per
@@ -68,10 +68,10 @@ __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
   const int c0 = bx * 256;
   const int m_begin = by * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
-  const int jblocks = R > 16 ? 2 : 1;
-  lf32x4 acc[2][4];
+  const int jblocks = (R + 15) >> 4;       // 1..4 (round 4: rank 16 makes the q|k|v group 48 wide)
+  lf32x4 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (lf32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -109,9 +109,9 @@ __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_
     // (row 8g + (n >> 2) [+4], columns 4 (n & 3) ..) of a [4 rows][16 columns] block and receives the 4 rows of column n --
     // two reads give the 8 consecutive k of one MFMA operand (the scalar version needed 8 ds_read_u16 per operand).
     const int trow = g * 8 + (i >> 2), tcol = (i & 3) * 4;
-    lbf16x8 a[2];
+    lbf16x8 a[4];
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+    for (int jb = 0; jb < 4; ++jb)
       if (jb < jblocks) {
         const lbf16x4 lo = tr_read(sy + trow * 64 + ((jb ^ (trow & 3)) * 16) + tcol);
         const lbf16x4 hi = tr_read(sy + (trow + 4) * 64 + ((jb ^ ((trow + 4) & 3)) * 16) + tcol);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_
       const lbf16x4 hi = tr_read(sx + (trow + 4) * 256 + ((cg ^ ((trow + 4) & 3)) * 16) + tcol);
       const lbf16x8 b = (lbf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
+      for (int jb = 0; jb < 4; ++jb)
         if (jb < jblocks) acc[jb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jb], b, acc[jb][cb], 0, 0, 0);
     }
   };
@@ -141,7 +141,7 @@ __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_
     int jlo = 0, jhi = R;
     if (r > 0) { jlo = (c < b0 ? 0 : (c < b1 ? 1 : 2)) * r; jhi = jlo + r; }
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+    for (int jb = 0; jb < 4; ++jb)
       if (jb < jblocks) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -287,7 +287,7 @@ static int lora_tn_rows(int M, int Cn) {
 }
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
                         int r, int b0, int b1, hipStream_t st) {
-  if (R > 32 || R <= 0 || ldy != 64 || Cn % 8) return TA_ERR_ARG;
+  if (R > 64 || R <= 0 || ldy != 64 || Cn % 8) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
   const int rows = lora_tn_rows(M, Cn);
   TA_LAUNCH(lora_tn_mfma_kernel, dim3(ta_cdiv(Cn, 256), ta_cdiv(M, rows)), dim3(256), 0, st, (const bf16_t*)X, Cn, (const bf16_t*)Y,
@@ -299,7 +299,7 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
 int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float* out0, long so_c0, long so_j0, float post0, int r0,
                          int b00, int b10, const void* X1, int Cn1, const void* Y1, int R1, float* out1, long so_c1, long so_j1,
                          float post1, int r1, int b01, int b11, int M, hipStream_t st) {
-  if (R0 > 32 || R0 <= 0 || R1 > 32 || R1 <= 0 || (Cn0 % 8) || (Cn1 % 8)) return TA_ERR_ARG;
+  if (R0 > 64 || R0 <= 0 || R1 > 64 || R1 <= 0 || (Cn0 % 8) || (Cn1 % 8)) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
   LoraTnArgs p0 = {(const bf16_t*)X0, Cn0, (const bf16_t*)Y0, R0, out0, so_c0, so_j0, post0, r0, b00, b10, lora_tn_rows(M, Cn0), 0, 0};
   LoraTnArgs p1 = {(const bf16_t*)X1, Cn1, (const bf16_t*)Y1, R1, out1, so_c1, so_j1, post1, r1, b01, b11, lora_tn_rows(M, Cn1), 0, 0};

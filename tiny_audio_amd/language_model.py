@@ -39,6 +39,8 @@ class Qwen3MI355X(torch.nn.Module):
         self._w = None
         self._layers_arr = None
         self.lora_rank = 0
+        self.lora_groups = 0
+        self.lora_targets = set()
         self._lora_bound = None
         self.train_base = False          # full decoder fine-tuning (freeze_language_model=False)
         self.want_train_base = False     # ... requested before the weights exist: enabled by _finalize
@@ -61,35 +63,65 @@ class Qwen3MI355X(torch.nn.Module):
 
     @torch.no_grad()
     def enable_lora(self, rank=8, alpha=32, dropout=0.0, target_modules=None, seed=0):
-        """peft ``LoraConfig(r, lora_alpha, target_modules=all 7 linears, bias='none')`` on every decoder layer:
-        lora_A ~ kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(in)), lora_B = 0, y += (alpha/r) B A x.  The trainable
-        fp32 masters are 8 Parameters [n_layers, ...] in the stacked group layout of include/ta355.h."""
+        """peft ``LoraConfig(r, lora_alpha, target_modules, bias='none')`` on every decoder layer (tiny_audio/asr_modeling.py:289-301,
+        defaults tiny_audio/asr_config.py:72-75: r = 8, alpha = 32, all 7 linears): lora_A ~ kaiming_uniform(a=sqrt(5)) =
+        U(+-1/sqrt(in)), lora_B = 0, y += (alpha/r) B A x.  The trainable fp32 masters are 8 Parameters [n_layers, ...] in the
+        stacked group layout of include/ta355.h.
+
+        ``rank``: any r with 3 r <= 64 (the q|k|v group's three adapters share one 64-wide K tile).
+        ``target_modules``: any subset of the 7 linears (peft suffix names).  A group none of whose members is targeted is
+        switched off in the C library (``ta_lm_weights.lora_groups``); inside a live group the members that are not targeted
+        keep A = B = 0, which makes both of their gradients exactly zero (dA = s (dy B)^T x, dB = dy^T (x A^T)), so AdamW
+        never moves them; ``export_lora_state_dict`` / ``lora_param_count`` only see the targeted ones."""
         if self.train_base or self.want_train_base:
             raise NotImplementedError("LoRA on top of a trainable base LM is not built")
-        if rank != 8:
-            raise NotImplementedError("the fused adapter tile is built for lora_rank=8 (the reference default)")
+        if not (1 <= int(rank) and 3 * int(rank) <= 64):
+            raise NotImplementedError("lora_rank must satisfy 3 * rank <= 64 (one 64-wide K tile per adapter group)")
         if dropout:
             raise NotImplementedError("lora_dropout > 0 is not built (reference default 0.0, asr_config.py:74)")
-        want = {"q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"}
-        if target_modules is not None and set(target_modules) != want:
-            raise NotImplementedError("lora_target_modules must be the reference default (all 7 linears)")
+        all_t = [t for _, ts in LORA_GROUPS for t in ts]
+        if target_modules is None:
+            targets = set(all_t)
+        else:
+            short = {t.split(".")[-1]: t for t in all_t}
+            unknown = [t for t in target_modules if t.split(".")[-1] not in short]
+            if unknown or not list(target_modules):
+                raise ValueError(f"lora_target_modules {unknown or '[]'}: expected a non-empty subset of {sorted(short)}")
+            targets = {short[t.split(".")[-1]] for t in target_modules}
+        rank = int(rank)
         Lyr, dev = self.config.num_hidden_layers, self.device_
         gen = torch.Generator(device="cpu"); gen.manual_seed(seed)
-        for g, (members, fin) in self._lora_dims().items():
+        self.lora_groups = 0
+        for gi, (g, (members, fin)) in enumerate(self._lora_dims().items()):
             bound = 1.0 / math.sqrt(fin)
             a = (torch.rand((Lyr, len(members) * rank, fin), generator=gen, dtype=F32) * 2 - 1) * bound
+            for j, (t, _) in enumerate(members):
+                if t not in targets:
+                    a[:, j * rank:(j + 1) * rank] = 0
+                else:
+                    self.lora_groups |= 1 << gi
             b = torch.zeros((Lyr, sum(o for _, o in members), rank), dtype=F32)
             setattr(self, f"lora_la_{g}", torch.nn.Parameter(a.to(dev)))
             setattr(self, f"lora_lb_{g}", torch.nn.Parameter(b.to(dev)))
-        self.lora_rank, self.lora_alpha = rank, alpha
+        self.lora_rank, self.lora_alpha, self.lora_targets = rank, alpha, targets
         self._lora_bound = None
-        if self._w is not None:
-            self._w.lora_rank, self._w.lora_scale = rank, float(alpha) / rank
+        self._finalize_lora_scale()
         return self
+
+    def lora_param_count(self):
+        """peft's trainable-parameter count: r (in + out) per targeted linear and layer (the stacked masters also hold the
+        zero blocks of members that are not targeted)."""
+        if not self.lora_rank:
+            return 0
+        n = 0
+        for g, (members, fin) in self._lora_dims().items():
+            n += sum(self.lora_rank * (fin + o) for t, o in members if t in self.lora_targets)
+        return n * self.config.num_hidden_layers
 
     def _finalize_lora_scale(self):
         if self._w is not None and self.lora_rank:
             self._w.lora_rank, self._w.lora_scale = self.lora_rank, float(self.lora_alpha) / self.lora_rank
+            self._w.lora_groups = self.lora_groups
 
     @torch.no_grad()
     def load_lora_state_dict(self, sd):
@@ -109,8 +141,9 @@ class Qwen3MI355X(torch.nn.Module):
             for i in range(self.config.num_hidden_layers):
                 row = 0
                 for j, (t, o) in enumerate(members):
-                    la.data[i, j * r:(j + 1) * r].copy_(found[f"layers.{i}.{t}.lora_A"])
-                    lb.data[i, row:row + o].copy_(found[f"layers.{i}.{t}.lora_B"])
+                    if t in self.lora_targets:
+                        la.data[i, j * r:(j + 1) * r].copy_(found[f"layers.{i}.{t}.lora_A"])
+                        lb.data[i, row:row + o].copy_(found[f"layers.{i}.{t}.lora_B"])
                     row += o
         return self
 
@@ -122,8 +155,9 @@ class Qwen3MI355X(torch.nn.Module):
             for i in range(self.config.num_hidden_layers):
                 row = 0
                 for j, (t, o) in enumerate(members):
-                    sd[f"{prefix}layers.{i}.{t}.lora_A{suffix}"] = la[i, j * r:(j + 1) * r].clone()
-                    sd[f"{prefix}layers.{i}.{t}.lora_B{suffix}"] = lb[i, row:row + o].clone()
+                    if t in self.lora_targets:
+                        sd[f"{prefix}layers.{i}.{t}.lora_A{suffix}"] = la[i, j * r:(j + 1) * r].clone()
+                        sd[f"{prefix}layers.{i}.{t}.lora_B{suffix}"] = lb[i, row:row + o].clone()
                     row += o
         return sd
 
@@ -370,9 +404,8 @@ class Qwen3MI355X(torch.nn.Module):
         for f in ("embed_f32", "embed_bf16", "embed_t_bf16", "norm_w", "rope_cos", "rope_sin"):
             setattr(w, f, b[f].data_ptr())
         w.layers = C.cast(arr, C.POINTER(_lib.LmLayer))
-        if self.lora_rank:
-            w.lora_rank, w.lora_scale = self.lora_rank, float(self.lora_alpha) / self.lora_rank
         self._layers_arr, self._w, self._lora_bound = arr, w, None
+        self._finalize_lora_scale()
         if self.train_base or self.want_train_base:      # (re)seed the masters from the weights just loaded
             self.train_base = False
             self.enable_full_finetune()
