@@ -25,6 +25,20 @@ for n in (1, N):
     torch.cuda.synchronize()
     res[n] = (time.perf_counter() - t0) / 3
 per_tok = (res[N] - res[1]) / (N - 1)
+# decode roofline: a step streams every LM weight once (bf16 linears of all layers + the tied lm_head) and the KV cache of the
+# positions so far (prompt 152 + on average N / 2 generated); HBM peak 8 TB/s (MI355X_MICROARCH.md)
+t = cfg.text_config
+D, F, nl = t.hidden_size, t.intermediate_size, t.num_hidden_layers
+nq, nkv, hd = t.num_attention_heads, t.num_key_value_heads, t.head_dim
+vocab_pad = (t.vocab_size + 127) // 128 * 128
+w_bytes = 2 * (nl * (D * (nq + 2 * nkv) * hd + nq * hd * D + 3 * D * F) + vocab_pad * D)
+kv_bytes = 2 * 2 * nl * B * nkv * hd * (ids.shape[1] + N // 2)
+floor_ms = (w_bytes + kv_bytes) / 8e12 * 1e3
 print(json.dumps({"B": B, "new_tokens": N, "prompt_pass_ms": round(res[1] * 1e3, 2), "per_token_ms": round(per_tok * 1e3, 3),
                   "tokens_per_s": round(B / per_tok, 1), "total_ms": round(res[N] * 1e3, 1),
-                  "rtf_audio_s_per_s": round(B * 10.0 / res[N], 1)}))
+                  "rtf_audio_s_per_s": round(B * 10.0 / res[N], 1),
+                  "roofline": {"bound": "hbm", "weight_bytes": w_bytes, "kv_cache_bytes": kv_bytes, "peak": 8000.0, "unit": "GB/s",
+                               "achieved": round((w_bytes + kv_bytes) / per_tok / 1e9, 1),
+                               "frac": round(floor_ms / (per_tok * 1e3), 4), "floor_ms_per_token": round(floor_ms, 4),
+                               "frac_weights_only": round(w_bytes / 8e12 / per_tok, 4)},
+                  "fused": os.environ.get("TA355_DECODE_FUSED", "1") != "0"}))

@@ -285,3 +285,65 @@ def test_gemm_launches_of_a_real_b32_step_replayed_vs_fp32():
         e = _replay(r)
         worst[(r["M"], r["N"], r["K"], r["act"], r["variant"])] = e
     print(f"[step GEMMs] {len(log)} launches, {len(recs)} distinct; worst relative error {max(worst.values()):.2e}")
+
+
+# ============================================================================ fused decode step (csrc/decode_fused.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,slot,grp", [(5, 40, 2), (20, 70, 2), (32, 37, 2), (32, 300, 2), (9, 33, 4), (7, 21, 1)])
+def test_decode_step_fused_vs_unfused(B, slot, grp):
+    """ta_lm_decode_step on the five fused launches per layer (RMSNorm folded into q|k|v and gate|up, SwiGLU in the epilogue,
+    q/k norm + RoPE + cache append + attention in one kernel, 4-column o / down workgroups) against the round-3 nine-launch
+    sequence on the same inputs: same logits up to summation order, same rows appended to the cache, ragged key masks,
+    a cache longer than one 256-key pass, every row block (B <= 16, 17..32) and GQA group sizes 1 / 2 / 4."""
+    import ctypes as C
+    from oracle import weights as OW
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.language_model import LMConfig, Qwen3MI355X
+    heads = 16
+    cfg = OW.lm_config(vocab=5003, layers=2, heads=heads, kv_heads=heads // grp)
+    wL = OW.init_lm(cfg, 1)
+    lm = Qwen3MI355X(LMConfig(cfg), DEV).load_state_dict_hf(wL)
+    L_ = _lib.lib()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Hkv, HD, Lmax = cfg["kv_heads"], cfg["head_dim"], slot + 24
+    g = torch.Generator(device="cpu"); g.manual_seed(B * 1000 + slot)
+    kc0 = (0.5 * torch.randn((cfg["layers"], B, Hkv, Lmax, HD), generator=g)).to(BF16).to(DEV)
+    vc0 = (0.5 * torch.randn((cfg["layers"], B, Hkv, Lmax, HD), generator=g)).to(BF16).to(DEV)
+    kmask = torch.zeros((B, Lmax), dtype=torch.int32)
+    pos = torch.zeros(B, dtype=torch.int32)
+    for b in range(B):
+        pad = (b * 5) % 17 if b else 0                     # left padding, ragged
+        kmask[b, pad:slot + 1] = 1
+        pos[b] = slot - pad
+    kmask, pos = kmask.to(DEV), pos.to(DEV)
+    ids = torch.randint(0, cfg["vocab"], (B,), generator=g).to(DEV)
+    slot_dev = torch.tensor([slot], dtype=torch.int32, device=DEV)
+    ws = torch.empty(L_.ta_lm_decode_workspace_bytes(C.byref(lm._w), B), dtype=torch.uint8, device=DEV)
+    res = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["TA355_DECODE_FUSED"] = mode
+            L_.ta_gemm_reload_knobs()
+            kc, vc = kc0.clone(), vc0.clone()
+            logits = torch.zeros((B, lm.vocab_pad), dtype=F32, device=DEV)
+            _lib.check(L_.ta_lm_decode_step(C.byref(lm._w), ptr(ids), ptr(pos), ptr(kmask), ptr(slot_dev), B, ptr(kc), ptr(vc), Lmax,
+                                            ptr(logits), None, ptr(ws), ws.numel(), st), "ta_lm_decode_step")
+            torch.cuda.synchronize()
+            res[mode] = (logits[:, :cfg["vocab"]].clone(), kc, vc)
+    finally:
+        os.environ.pop("TA355_DECODE_FUSED", None)
+        L_.ta_gemm_reload_knobs()
+    (l0, k0, v0), (l1, k1, v1) = res["0"], res["1"]
+    assert torch.isfinite(l1).all()
+    # untouched cache slots stay bit-identical; the appended rows agree (layer 0 exactly up to a bf16 ulp of the norm's rounding)
+    keep = torch.ones(Lmax, dtype=torch.bool, device=DEV); keep[slot] = False
+    assert torch.equal(k1[:, :, :, keep], kc0[:, :, :, keep]) and torch.equal(v1[:, :, :, keep], vc0[:, :, :, keep])
+    for a, b_ in ((k0, k1), (v0, v1)):
+        d = (a[:, :, :, slot].float() - b_[:, :, :, slot].float()).abs()
+        assert float(d[0].max()) <= 0.02 * float(a[0, :, :, slot].float().abs().max()) + 1e-3
+        assert float(d.max()) <= 0.05 * float(a[:, :, :, slot].float().abs().max()) + 1e-3
+    cos = torch.nn.functional.cosine_similarity(l0.flatten(), l1.flatten(), dim=0)
+    scale = float(l0.abs().max())
+    assert float(cos) > 0.9999 and float((l0 - l1).abs().max()) < 0.03 * scale, (float(cos), float((l0 - l1).abs().max()), scale)
+    assert float((l0.argmax(-1) == l1.argmax(-1)).float().mean()) >= 0.9

@@ -22,7 +22,7 @@ HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
 SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
-           "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "api.hip"]
+           "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "decode_fused.hip", "api.hip"]
 
 
 class Ta355Error(RuntimeError):

@@ -1345,7 +1345,8 @@ static GemmKnobs& knobs() {
   static GemmKnobs k = [] { GemmKnobs x; x.load(); return x; }();
   return k;
 }
-extern "C" int ta_gemm_reload_knobs(void) { knobs().load(); return TA_OK; }
+void ta_i_reload_decode_knobs();   // generate.hip: TA355_DECODE_FUSED
+extern "C" int ta_gemm_reload_knobs(void) { knobs().load(); ta_i_reload_decode_knobs(); return TA_OK; }
 
 static int pick_variant(int M, int N, int K, int splits) {
   const GemmKnobs& kn = knobs();

@@ -8,7 +8,17 @@
 // Everything a step depends on that changes from token to token (cache slot, RoPE position, key mask, token ids,
 // finished flags) lives in DEVICE memory and is advanced by greedy_advance_kernel, so the launch sequence of a step
 // is identical every time: no host round trip inside the loop, and the step is hipGraph-capturable.
+#include <cstdlib>
 #include "host_util.h"
+#include "internal.h"
+
+static bool read_decode_fused() { const char* e = getenv("TA355_DECODE_FUSED"); return !(e && *e == '0'); }
+static bool read_decode_prefetch() { const char* e = getenv("TA355_DECODE_PREFETCH"); return !(e && *e == '0'); }
+static int read_decode_pf_wgs() { const char* e = getenv("TA355_DECODE_PF_WGS"); return e && *e ? atoi(e) : 0; }   // 0 = decode_fused.hip's default (96)
+static bool g_decode_fused = read_decode_fused();                 // read at load; ta_gemm_reload_knobs() re-reads them (tests, A/B scripts)
+static bool g_decode_prefetch = read_decode_prefetch();
+static int g_decode_pf_wgs = read_decode_pf_wgs();
+void ta_i_reload_decode_knobs() { g_decode_fused = read_decode_fused(); g_decode_prefetch = read_decode_prefetch(); g_decode_pf_wgs = read_decode_pf_wgs(); }
 
 namespace {
 constexpr int HD = 128;
@@ -324,9 +334,10 @@ DecodeWs decode_ws(const ta_lm_weights* w, int B, void* base) {
   const int D = w->hidden, F = w->ffn, bq = w->heads * HD, NQKV = (w->heads + 2 * w->kv_heads) * HD;
   Carver c(base);
   DecodeWs s;
-  s.x = c.take<float>((size_t)B * D); s.x1 = c.take<float>((size_t)B * D); s.r = c.take<float>((size_t)B);
+  const size_t Bp = B < 32 ? 32 : B;                 // the fused step's blocked activations always hold 32 rows
+  s.x = c.take<float>(Bp * D); s.x1 = c.take<float>(Bp * D); s.r = c.take<float>((size_t)B);
   s.xn = c.take<bf16_t>((size_t)B * D); s.qkv0 = c.take<bf16_t>((size_t)B * NQKV); s.q = c.take<bf16_t>((size_t)B * bq);
-  s.ao = c.take<bf16_t>((size_t)B * bq); s.gu = c.take<bf16_t>((size_t)B * 2 * F); s.act = c.take<bf16_t>((size_t)B * F);
+  s.ao = c.take<bf16_t>(Bp * bq); s.gu = c.take<bf16_t>((size_t)B * 2 * F); s.act = c.take<bf16_t>(Bp * F);
   s.xa = c.take<bf16_t>((size_t)B * 64); s.hn = c.take<bf16_t>((size_t)B * D);
   s.bytes = c.total();
   return s;
@@ -369,11 +380,35 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
     if (small) return linear_small_m(x, (const bf16_t*)Wm, y, B, N, K, res, out_bf16, a2, w2, st);
     return gemm_opt(x, Wm, y, B, N, K, nullptr, res, 0, out_bf16 ? 1 : 0, g ? opts_kext(a2, w2) : opts_none(), st);
   };
-  RC(ta_embed_scatter(ids, nullptr, w->embed_f32, nullptr, s.x, nullptr, B, D, w->vocab, st));
+  // round 4: five launches per layer instead of nine (csrc/decode_fused.hip) when no adapter is attached and the shapes fit;
+  // TA355_DECODE_FUSED=0 keeps the round-3 sequence (the A/B of profiles/r04_decode_*)
+  const bool fused = g_decode_fused && !lora && ta_i_dec_fused_serves(B, D, F, bq, Hq, Hkv, Lmax);
+  if (fused) RC(ta_i_dec_embed(ids, w->embed_f32, s.x, B, D, w->vocab, st));
+  else RC(ta_embed_scatter(ids, nullptr, w->embed_f32, nullptr, s.x, nullptr, B, D, w->vocab, st));
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_lm_layer& Lw = w->layers[l];
     bf16_t* kc = (bf16_t*)kcache + (size_t)l * layer_elems;
     bf16_t* vc = (bf16_t*)vcache + (size_t)l * layer_elems;
+    if (fused) {
+      // every kernel also fetches what the next one streams (weights / this layer's cache rows): TA355_DECODE_PREFETCH=0 turns it off
+      const int pw = g_decode_pf_wgs;
+      const ta_i_dec_prefetch p_kv = {kc, vc, 0, slot_dev, (long)Lmax * HD * 2, B * Hkv, pw};
+      const ta_i_dec_prefetch p_o = {Lw.wo, nullptr, (long)D * bq * 2, nullptr, 0, 0, pw};
+      const ta_i_dec_prefetch p_gu = {Lw.wgu, nullptr, (long)2 * F * D * 2, nullptr, 0, 0, pw};
+      const ta_i_dec_prefetch p_d = {Lw.wd, nullptr, (long)D * F * 2, nullptr, 0, 0, pw};
+      const bool last = l + 1 == w->n_layers;
+      const long head_bytes = (long)w->vocab_pad * D * 2;              // (the first 16 MB of the LM head behind the last layer)
+      const ta_i_dec_prefetch p_next = {last ? w->embed_bf16 : w->layers[l + 1].wqkv, nullptr,
+                                        last ? (head_bytes < ((long)16 << 20) ? head_bytes : (long)16 << 20) : (long)NQKV * D * 2, nullptr, 0, 0, pw};
+      const bool pfon = g_decode_prefetch;
+      RC(ta_i_dec_norm_linear(s.x, Lw.ln_in_w, w->eps, Lw.wqkv, s.qkv0, B, NQKV, D, false, pfon ? &p_kv : nullptr, st));
+      RC(ta_i_dec_attn(s.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, slot_dev, kmask, kc, vc, s.ao, B, Hq, Hkv, Lmax,
+                       w->eps, scale, pfon ? &p_o : nullptr, st));
+      RC(ta_i_dec_linear_res(s.ao, Lw.wo, s.x1, s.x, B, D, bq, pfon ? &p_gu : nullptr, st));
+      RC(ta_i_dec_norm_linear(s.x1, Lw.ln_post_w, w->eps, Lw.wgu, s.act, B, F, D, true, pfon ? &p_d : nullptr, st));
+      RC(ta_i_dec_linear_res(s.act, Lw.wd, s.x, s.x1, B, D, F, pfon ? &p_next : nullptr, st));
+      continue;
+    }
     RC(ta_rmsnorm_fwd(s.x, Lw.ln_in_w, s.xn, nullptr, s.r, B, D, w->eps, 0, st));
     RC(linear(s.xn, Lw.wqkv, s.qkv0, NQKV, D, nullptr, true, (lgm & 1) ? &imgs[l].g[0] : nullptr));
     TA_LAUNCH(lm_qkv_post_decode_kernel, dim3(Hq + 2 * Hkv, B), dim3(64), 0, st, s.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos,
@@ -387,7 +422,8 @@ extern "C" int ta_lm_decode_step(const ta_lm_weights* w, const long* ids, const 
     RC(ta_swiglu_fwd(s.gu, s.act, B, F, st));
     RC(linear(s.act, Lw.wd, s.x, D, F, s.x1, false, (lgm & 8) ? &imgs[l].g[3] : nullptr));
   }
-  RC(ta_rmsnorm_fwd(s.x, w->norm_w, s.hn, nullptr, s.r, B, D, w->eps, 0, st));
+  if (fused) RC(ta_i_dec_final_norm(s.x, w->norm_w, s.hn, B, D, w->eps, st));
+  else RC(ta_rmsnorm_fwd(s.x, w->norm_w, s.hn, nullptr, s.r, B, D, w->eps, 0, st));
   RC(linear(s.hn, w->embed_bf16, logits, w->vocab_pad, D, nullptr, false, nullptr));
   return TA_OK;
 }

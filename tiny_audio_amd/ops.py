@@ -36,7 +36,7 @@ def _req(t, dtype=None):
 # The GEMM launcher reads its environment knobs once (csrc/gemm.hip GemmKnobs); tests and A/B scripts switch them between launches,
 # so the wrapper re-reads them whenever one of the per-launch knobs of rounds 1-3 has changed since the previous call.
 _KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GEMM_DEBUG", "TA355_GROUP_M", "TA355_EPI_WIDE", "TA355_GELU_LUT", "TA355_GEMM_RES_INIT",
-              "TA355_GEMM_PERSIST", "TA355_GEMM_M32", "TA355_V7_MASK")
+              "TA355_GEMM_PERSIST", "TA355_GEMM_M32", "TA355_V7_MASK", "TA355_DECODE_FUSED")
 _knob_state = None
 
 
