@@ -213,12 +213,20 @@ __device__ __forceinline__ void fft25(cpx* y) {
 #define LF_PWS 201                          // power row stride (odd: the mel stage's reads spread over the banks)
 // LFT frames per workgroup (4 waves), LF_G frame pairs per wave at once.  <64, 4> fills every lane of stage B but needs
 // 150 KB of LDS (one workgroup, i.e. one wave per SIMD, per CU); <32, 2> needs 78 KB: two workgroups per CU.
-template <int LFT, int LF_G>
+// MFMA (round 4): the two sub-transforms as real matrix products on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) instead of register
+// FFTs on 25 / 16 lanes per frame pair.  Stage A: [Re Y; Im Y] (32 x cols) = DFT16_A (32 x 32) [zr; zi], columns = (pair, n2) -- the
+// two pairs of an iteration are 50 columns = 4 column blocks; the B operand is ONE windowed sample per lane per k-step, straight from
+// the span.  Twiddle in registers (a lane holds Re and Im of the same (k1, column)), Y' to the wave's scratch as [pair][Re|Im][n2][k1]
+// so that stage B's B operand (columns = k1, k = (Yr n2 | Yi n2)) is 16 consecutive floats per lane group.  Stage B: 4 row blocks
+// (Re / Im x k2 < 16 / k2 >= 16) x 13 k-steps per pair; Z lands in the scratch in the interleaved [k][re, im] form the combine reads.
+// Per frame: 21 + 26 MFMAs of 32 cycles on the CU's four matrix cores (~310 cycles) against ~1 150 cycles of partially filled VALU
+// waves; the mel stage and everything around it are unchanged.
+template <int LFT, int LF_G, bool MFMA = false>
 __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict__ wav, int Ls, const float* __restrict__ dft,
                                                          const float* __restrict__ window, const float* __restrict__ melfb,
                                                          int n_mels, float* __restrict__ out, int* __restrict__ clip_max, int T, int dbg,
                                                          const int* __restrict__ mrange_g, int* __restrict__ arrived,
-                                                         const long* __restrict__ lens, int* __restrict__ mask) {
+                                                         const long* __restrict__ lens, int* __restrict__ mask, int nblk, int ntiles) {
   constexpr int LF_SPAN = (LFT - 1) * HOP + NFFT, LF_SCR = LF_G * NFFT * 2, LF_MELS = LFT + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* span = lds;                              // [LF_SPAN]            (later: melbuf [n_mels][LF_MELS])
@@ -227,39 +235,171 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   float* win = pw + LFT * LF_PWS;                  // [NFFT]
   float* tw = win + NFFT;                         // [NFFT][2] = W400^j
   int* mrange = (int*)(tw + 2 * NFFT);            // [n_mels][2] first / end bin of every mel filter
-  const int b = blockIdx.y, t0 = blockIdx.x * LFT, tid = threadIdx.x;
-  const float* w = wav + (long)b * Ls;
-  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-  if (dbg & 4) ts[0] = __builtin_amdgcn_s_memtime();
-  // the span in batches of 8 independent loads per thread (a load -> LDS store loop serialises on the HBM latency)
-  for (int j0 = tid; j0 < LF_SPAN; j0 += 256 * 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int j = j0 + u * 256;
-      int sidx = t0 * HOP + j - NFFT / 2;         // index into the (virtually) reflect-padded signal
-      if (sidx < 0) sidx = -sidx;
-      if (sidx >= Ls) sidx = 2 * (Ls - 1) - sidx;
-      v[u] = (j < LF_SPAN && sidx >= 0 && sidx < Ls) ? w[sidx] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256; if (j < LF_SPAN) span[j] = v[u]; }
-  }
-  if (dbg & 4) { __syncthreads(); ts[1] = __builtin_amdgcn_s_memtime(); }
+  // round 4: a workgroup is PERSISTENT over tiles (tile = LFT frames of one clip; 1-D grid of about two workgroups per CU) and
+  // requests the NEXT tile's span -- six 16-byte loads per thread, one round trip -- before it transforms the current one.  Measured
+  // (rocprofv3, profiles/r04_za_logmel_kernel_times.txt): the kernel took 48.7 us with neither the transform nor the mel stage in it
+  // (68.2 with both): a workgroup that lives for one tile spends its life in four serialized round trips (three span batches, the
+  // tables) and the store drain, two resident per CU, two rounds.  The legacy 2-D launch (`arrived` rendezvous) is one tile per group.
+  const int tid = threadIdx.x;
+  const bool legacy = gridDim.y > 1 || ntiles <= 0;
+  // a persistent workgroup takes CONSECUTIVE tiles (the same clip, mostly): its clip maximum is then ONE device-scope atomic at the
+  // end -- the kernel spent 25 of its 65 us waiting on 4 096 atomicMax to 32 addresses, one per wave and tile, each a memory-side
+  // round trip that the next barrier waited for (profiles/r04_zc_logmel_floor.txt: 41.1 us without transform and mel taps, 16.3
+  // without the mel stage and its atomic)
+  const int per = legacy ? 1 : (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile0 = legacy ? (int)(blockIdx.y * gridDim.x + blockIdx.x) : (int)blockIdx.x * per;
+  constexpr int tstride = 1;
+  const int tend = legacy ? tile0 + 1 : (tile0 + per < ntiles ? tile0 + per : ntiles);
+  if (legacy) nblk = gridDim.x;
+  float run_max = -INFINITY;                       // the workgroup's maximum over the tiles of clip run_b so far
+  int run_b = -1;
+  constexpr int PF = (LF_SPAN / 4 + 255) / 256;
+  float4 pre[PF];
+  // a tile whose span lies inside the clip and on a 16-byte boundary (t0 * 160 - 200 is a multiple of 8 samples) is loaded as float4
+  const bool al = (Ls % 4 == 0) && ((((size_t)wav) & 15) == 0);
+  auto fast = [&](int tile) { const int s0 = (tile % nblk) * LFT * HOP - NFFT / 2; return al && s0 >= 0 && s0 + LF_SPAN <= Ls; };
+#define LM_REQUEST(tile_)                                                                                             \
+  do {                                                                                                                \
+    const float* src_ = wav + (long)((tile_) / nblk) * Ls + ((tile_) % nblk) * LFT * HOP - NFFT / 2;                  \
+    _Pragma("unroll") for (int u = 0; u < PF; ++u) {                                                                  \
+      const int q = tid + u * 256;                                                                                    \
+      pre[u] = q < LF_SPAN / 4 ? *(const float4*)(src_ + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);                    \
+    }                                                                                                                 \
+  } while (0)
+  if (tile0 < tend && fast(tile0)) LM_REQUEST(tile0);
   for (int j = tid; j < NFFT; j += 256) {
     win[j] = window[j];
     // W400^j = cos(2 pi j / 400) - i sin(2 pi j / 400) from row n = 1 of the host's table (columns k <= 200; mirrored above)
-    const int jj = j <= 200 ? j : NFFT - j;
+    // (MFMA form: entry j = n2 * 16 + k1 holds W400^(n2 k1), so a lane's four k1 are 32 contiguous bytes)
+    const int je = MFMA ? (j >> 4) * (j & 15) : j;
+    const int jj = je <= 200 ? je : NFFT - je;
     const float c = dft[2 * NBIN + jj], sn = dft[2 * NBIN + NBIN + jj];
-    tw[2 * j] = c; tw[2 * j + 1] = j <= 200 ? -sn : sn;
+    tw[2 * j] = c; tw[2 * j + 1] = je <= 200 ? -sn : sn;
   }
   for (int i = tid; i < 2 * n_mels; i += 256) mrange[i] = mrange_g[i];     // per-filter bin ranges (logmel_init_kernel)
-  __syncthreads();
-  if (dbg & 4) ts[2] = __builtin_amdgcn_s_memtime();
   const int wave = tid >> 6, lane = tid & 63;
   float* my = scr + wave * LF_SCR;
+  [[maybe_unused]] const int li = lane & 15, lg = lane >> 4;
+  [[maybe_unused]] float a16[2][8], a25[4][13];
+  if constexpr (MFMA) {
+    static_assert(LF_G == 2, "the MFMA form works on two frame pairs (50 columns = 4 column blocks) at a time");
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) a16[rb][ks] = DFT16_A[rb][4 * ks + lg][li];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < 13; ++ks) a25[rb][ks] = DFT25_A[rb][4 * ks + lg][li];
+  }
+  for (int tile = tile0; tile < tend; tile += tstride) {
+  const int b = tile / nblk, t0 = (tile % nblk) * LFT;
+  const float* w = wav + (long)b * Ls;
+  __syncthreads();                                                // the previous tile's write-out is done with melbuf (= span)
+  if (fast(tile)) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) { const int q = tid + u * 256; if (q < LF_SPAN / 4) *(float4*)(span + 4 * q) = pre[u]; }
+  } else {
+    // first / last tile of a clip (reflect padding, zero fill) or an unaligned clip: scalar, in batches of 8 independent loads
+    for (int j0 = tid; j0 < LF_SPAN; j0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * 256;
+        int sidx = t0 * HOP + j - NFFT / 2;         // index into the (virtually) reflect-padded signal
+        if (sidx < 0) sidx = -sidx;
+        if (sidx >= Ls) sidx = 2 * (Ls - 1) - sidx;
+        v[u] = (j < LF_SPAN && sidx >= 0 && sidx < Ls) ? w[sidx] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int j = j0 + u * 256; if (j < LF_SPAN) span[j] = v[u]; }
+    }
+  }
+  __syncthreads();
+  if (tile + tstride < tend && fast(tile + tstride)) LM_REQUEST(tile + tstride);     // in flight under this tile's transform
   for (int it = 0; it < ((dbg & 1) ? 0 : LFT / 2 / 4 / LF_G); ++it) {            // LFT / 2 pairs per workgroup, a quarter per wave, LF_G at a time
     const int pair0 = wave * (LFT / 8) + it * LF_G;
+    if constexpr (MFMA) {
+      // ---- stage A: two column blocks at a time (four independent accumulator chains).  Per lane and column block everything that
+      // depends on the column is ONE base offset into the span and one into the window; the k-steps are immediate offsets from them.
+#pragma unroll
+      for (int cb2 = 0; cb2 < 4; cb2 += 2) {
+        lm_f32x4 acc[2][2];
+        const float* sp[2]; const float* wp[2]; float ma[2], mb[2]; int n2v[2], pv[2]; bool okc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          acc[q][0] = (lm_f32x4){0.f, 0.f, 0.f, 0.f}; acc[q][1] = (lm_f32x4){0.f, 0.f, 0.f, 0.f};
+          const int c = (cb2 + q) * 16 + li;
+          okc[q] = c < 50;
+          pv[q] = c >= 25 ? 1 : 0;
+          n2v[q] = okc[q] ? c - 25 * pv[q] : 0;
+          const int fa = 2 * (pair0 + pv[q]);
+          sp[q] = span + fa * HOP + 25 * lg + n2v[q];
+          wp[q] = win + 25 * lg + n2v[q];
+          ma[q] = (okc[q] && t0 + fa < T) ? 1.f : 0.f;                          // frame a valid (real part)
+          mb[q] = (okc[q] && t0 + fa + 1 < T) ? 1.f : 0.f;                      // frame b valid (imaginary part)
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            // k = 4 ks + lg: k < 16 -> zr[n1 = k] (frame a), else zi[n1 = k - 16] (frame b); sample 25 n1 + n2 of the frame
+            const float wv = wp[q][100 * (ks & 3)] * (ks < 4 ? ma[q] : mb[q]);
+            const float b = sp[q][100 * (ks & 3) + (ks < 4 ? 0 : HOP)] * wv;
+            acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16[0][ks], b, acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16[1][ks], b, acc[q][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (okc[q]) {
+            const float4 t0v = *(const float4*)(tw + (n2v[q] * 16 + 4 * lg) * 2), t1v = *(const float4*)(tw + (n2v[q] * 16 + 4 * lg) * 2 + 4);
+            const float tr[4] = {t0v.x, t0v.z, t1v.x, t1v.z}, ti[4] = {t0v.y, t0v.w, t1v.y, t1v.w};
+            float4 yr, yi;
+            float* pr = &yr.x; float* pi = &yi.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              pr[j] = acc[q][0][j] * tr[j] - acc[q][1][j] * ti[j];
+              pi[j] = acc[q][0][j] * ti[j] + acc[q][1][j] * tr[j];
+            }
+            float* dst = my + ((pv[q] * 2) * 25 + n2v[q]) * 16 + 4 * lg;
+            *(float4*)dst = yr;
+            *(float4*)(dst + 25 * 16) = yi;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- stage B: both pairs interleaved (eight accumulator chains)
+      lm_f32x4 z[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) z[p][rb] = (lm_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 13; ++ks) {
+        const int k = 4 * ks + lg;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const float b = k < 50 ? my[p * 800 + k * 16 + li] : 0.f;
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb) z[p][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a25[rb][ks], b, z[p][rb], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();                            // every Y' has been read: Z takes its place
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k2 = hb * 16 + 4 * lg + j;
+            if (k2 < 25) *(float2*)(my + (p * NFFT + li + 16 * k2) * 2) = make_float2(z[p][hb][j], z[p][hb + 2][j]);
+          }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
     // ---- stage A
 #pragma unroll 1
     for (int pass = 0; pass < (LF_G * 25 + 63) / 64; ++pass) {
@@ -305,6 +445,7 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    }   // (register FFT form)
     // ---- combine: powers of the two real frames of every pair
     for (int id = lane; id < LF_G * NBIN; id += 64) {
       const int g = id / NBIN, k = id - g * NBIN;
@@ -320,14 +461,13 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
     __builtin_amdgcn_wave_barrier();                              // the next iteration overwrites the scratch
   }
   __syncthreads();
-  if (dbg & 4) ts[3] = __builtin_amdgcn_s_memtime();
   // ---- mel + log10: thread = (mel bin m, group of frames), every filter over its own bins only
   float* melbuf = span;                                           // [n_mels][LF_MELS]
   float lmax = -INFINITY;
   const int fgroups = 256 / n_mels;
   const int m = tid % n_mels, fg = tid / n_mels, nf = LFT / fgroups;
   const int klo = mrange[2 * m], khi = mrange[2 * m + 1];
-  for (int fb = 0; fb < nf; fb += 16) {
+  for (int fb = 0; fb < ((dbg & 16) ? 0 : nf); fb += 16) {
     float am[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) am[q] = 0.f;
@@ -345,9 +485,19 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
     }
   }
   lmax = wave_max(lmax);
-  if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
+  float* wred = (float*)(mrange + 2 * n_mels) + 1;                // [4] behind the mel ranges and the rendezvous float (sized by the host)
+  if ((tid & 63) == 0) wred[wave] = lmax;
   __syncthreads();
-  if (dbg & 4) ts[4] = __builtin_amdgcn_s_memtime();
+  const float wm = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  if (run_b != b) {                                               // (uniform) a new clip: publish the previous one's maximum
+    if (tid == 0 && run_b >= 0 && run_max > -INFINITY) atomicMax(clip_max + run_b, f2ord(run_max));
+    run_b = b; run_max = -INFINITY;
+  }
+  run_max = fmaxf(run_max, wm);
+  if (arrived || tile + 1 >= tend) {                              // the rendezvous form needs it before the arrival; else: the last tile
+    if (tid == 0 && run_max > -INFINITY) atomicMax(clip_max + b, f2ord(run_max));
+    run_max = -INFINITY;
+  }
   // Single pass (round 3 experiment, `arrived` != NULL, opt-in: it measured slower): the tile stays in LDS until every workgroup of the clip has contributed its
   // maximum -- an arrival counter per clip, released after this workgroup's atomicMax, polled by one lane -- and is written ONCE
   // with the (max - 8) floor and the (x + 4) / 4 map applied: no second kernel re-reading and re-writing the 512 KB per clip.
@@ -358,25 +508,20 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
     float& fl_s = *(float*)(mrange + 2 * n_mels);             // one float behind the mel ranges (sized by the host)
     if (tid == 0) {
       __hip_atomic_fetch_add(arrived + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const int need = gridDim.x;
+      const int need = nblk;
       while (__hip_atomic_load(arrived + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
       fl_s = ord2f(__hip_atomic_load(clip_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - 8.0f;
     }
     __syncthreads();
     floorv = fl_s; add = 4.0f; mul = 0.25f;
-    if (mask && blockIdx.x == 0)
+    if (mask && t0 == 0)
       for (int t = tid; t < T; t += 256) mask[(long)b * T + t] = ((long)t * HOP < lens[b]) ? 1 : 0;
   }
-  for (int i = tid; i < n_mels * LFT; i += 256) {                 // one mel row = LFT consecutive frames per store
+  for (int i = tid; i < ((dbg & 8) ? 0 : n_mels * LFT); i += 256) {                 // one mel row = LFT consecutive frames per store
     const int r = i / LFT, f = i - r * LFT;
     if (t0 + f < T) out[((long)b * n_mels + r) * T + t0 + f] = (fmaxf(melbuf[r * LF_MELS + f], floorv) + add) * mul;
   }
-  if (dbg & 4) {                                                  // experiment: phase stamps of workgroup (5, 3) into the output
-    __syncthreads();
-    ts[5] = __builtin_amdgcn_s_memtime();
-    if (tid == 0 && blockIdx.x == 5 && blockIdx.y == 3)
-      for (int i = 0; i < 6; ++i) out[i] = (float)(ts[i] - ts[0]);
-  }
+  }   // tile loop
 }
 
 // {first, end} bin of every mel filter (its non-zero taps): the FFT kernel applies a filter over its own ~4 (low) to ~13 (high) bins
@@ -434,15 +579,19 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
   } else {
     static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
     static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
+    // round 4 experiment, OPT-IN: the sub-transforms on the f32 matrix cores.  Measured 76.4 us per launch against 68.2 for the
+    // register FFT (profiles/r04_za_*): the transform was never the long phase of this kernel (17 of 68 us), see the persistent loop
+    static const bool mfma = [] { const char* e = getenv("TA355_LOGMEL_MFMA"); return e && *e == '1'; }();
     // TA355_LOGMEL_ONEPASS=1 (experiment; measured SLOWER, profiles/r03_f_logmel_onepass.txt: 113.7 us against 80.9 for 32 clips):
     // the clip's workgroups rendezvous on an arrival counter and write the tile once from LDS instead of the second pass -- but a
     // workgroup then holds its CU slot until the slowest of its clip's 32 arrives, and the second wave of clips starts that much later
     static const bool onepass_off = [] { const char* e = getenv("TA355_LOGMEL_ONEPASS"); return !(e && *e == '1'); }();
-    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 16; };
+    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 32; };
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
+      (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
       attr = true;
     }
     static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
@@ -453,10 +602,19 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
     // as long as a clip is a small part of the resident set; very long clips (> ~40 s at 256 CUs) keep the two-pass form
     two_pass = onepass_off || dbg != 0 || nblk * 4 > resident;
     int* arrived = two_pass ? nullptr : clip_ws + B;
+    // two-pass form: persistent workgroups over the tiles of all clips (TA355_LOGMEL_PERSIST=0: one workgroup per tile as in rounds 2-3);
+    // the rendezvous form keeps the 2-D launch (a clip's workgroups must be resident together)
+    static const bool persist_env = [] { const char* e = getenv("TA355_LOGMEL_PERSIST"); return !(e && *e == '0'); }();
+    const bool persist = persist_env && two_pass;
+    const int ntiles = nblk * B;
+    const dim3 grid = persist ? dim3(ntiles < resident ? ntiles : resident) : dim3(nblk, B);
+    const int nt_arg = persist ? ntiles : 0;
     if (wide)
-      TA_LAUNCH((logmel_fft_kernel<64, 4>), dim3(nblk, B), dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask);
+      TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
+    else if (mfma)
+      TA_LAUNCH((logmel_fft_kernel<32, 2, true>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
     else
-      TA_LAUNCH((logmel_fft_kernel<32, 2>), dim3(nblk, B), dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask);
+      TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
   }
   if (two_pass) {
     int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
