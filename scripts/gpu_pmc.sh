@@ -18,7 +18,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_C
   python - "$OUT/pass${i}_counter_collection.csv" <<'PY'
 import csv, sys
 p = sys.argv[1]
-keep = ("gemm_nt", "attn_", "lora_", "linear_small")
+keep = ("gemm_nt", "attn_", "lora_", "linear_small", "dec_", "logmel_fft")
 with open(p) as f:
     r = csv.reader(f); hdr = next(r); k = hdr.index("Kernel_Name")
     rows = [row for row in r if any(s in row[k] for s in keep)]

@@ -12,7 +12,7 @@ for f in sorted(glob.glob(os.path.join(src, "*counter_collection.csv"))):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             n = r["Kernel_Name"]
-            if "gemm_nt" not in n and "attn_" not in n and "lora_" not in n and "linear_small" not in n:
+            if not any(t in n for t in ("gemm_nt", "attn_", "lora_", "linear_small", "dec_", "logmel_fft")):
                 continue
             m = re.match(r"(?:void )?([\w:]+(?:<[^>(]*>)?)", n)
             key = (m.group(1) if m else n[:50], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
