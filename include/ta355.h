@@ -302,6 +302,11 @@ int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out, hipStream
  * no_repeat_ngram_size 0 make it a no-op; L + max_new <= 8192. */
 int ta_logits_process(float* logits, long ld, int V, const long* prompt_ids, int L, const long* out_seq, int max_new,
                       const int* step_dev, int B, float repetition_penalty, int no_repeat_ngram_size, hipStream_t st);
+/* HF MinNewTokensLengthLogitsProcessor (generation_config.min_new_tokens: tiny_audio/asr_config.py:83, forwarded to
+ * language_model.generate at tiny_audio/asr_modeling.py:631-637): while *step_dev (tokens generated so far, device memory) is below
+ * min_new, logits[b, ids[e]] = -inf for every eos id.  Call between ta_logits_process and ta_argmax_f32. */
+int ta_logits_suppress_until(float* logits, long ld, int V, const long* ids, int n_ids, int min_new, const int* step_dev, int B,
+                             hipStream_t st);
 int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad_id, int* finished, long* next_ids,
                       long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax, int B,
                       int* n_unfinished, hipStream_t st);

@@ -62,7 +62,7 @@ def apply_logits_processors(scores, seq, repetition_penalty=1.0, no_repeat_ngram
 
 
 def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False, repetition_penalty=1.0,
-                    no_repeat_ngram_size=0, processors_see_prompt=True):
+                    no_repeat_ngram_size=0, processors_see_prompt=True, min_new_tokens=0):
     """-> generated token ids [B, n_new] (prompt stripped), n_new <= max_new_tokens.  The prompt must be unpadded
     (attention_mask all ones), which is what ASRModel.generate builds.  ``return_margins`` also returns the
     top-1 minus top-2 logit gap of every decision (how robust the argmax is to bf16 rounding)."""
@@ -83,6 +83,11 @@ def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, ret
             head = [np.asarray(batch["input_ids"], np.int64)] if processors_see_prompt else [np.zeros((B, 0), np.int64)]
             seq = np.concatenate(head + [o[:, None] for o in out], axis=1)
             last = apply_logits_processors(last, seq, repetition_penalty, no_repeat_ngram_size)
+        if len(out) < min_new_tokens and len(eos_ids):
+            # HF MinNewTokensLengthLogitsProcessor (TF:generation/logits_process.py; generation_config.min_new_tokens,
+            # tiny_audio/asr_config.py:83): every eos id scores -inf until min_new_tokens tokens have been generated
+            last = last.copy()
+            last[:, np.asarray(list(eos_ids), dtype=np.int64)] = -np.inf
         nxt = last.argmax(-1)
         srt = np.sort(last, axis=-1)
         margins.append(srt[:, -1] - srt[:, -2])

@@ -451,9 +451,13 @@ def gen_generate():
     eos = next(int(tok) for tok in a_out[0] if first(a_out[0], tok) >= 2 and first(a_out[1], tok) > first(a_out[0], tok))
     model.generation_config.eos_token_id = [eos, SMALL["pad_id"]]
     b_out = model.generate(**kw, max_new_tokens=12).numpy()
+    # round 4: generation_config.min_new_tokens (tiny_audio/asr_config.py:83): the same eos may not end clip 0 before min_new tokens exist
+    min_new = first(a_out[0], eos) + 3
+    c_out = model.generate(**kw, max_new_tokens=12, min_new_tokens=min_new).numpy()
+    assert c_out.shape[1] > b_out.shape[1] or (c_out[:, :b_out.shape[1]] != b_out).any(), "min_new_tokens must change the output"
     save("generate_small.npz", input_features=feats, audio_attention_mask=amask, input_ids=ids, n_audio=np.array(n_audio),
-         tokens_a=a_out, eos_b=np.array(eos), tokens_b=b_out)
-    print("generate:", a_out.tolist(), eos, b_out.tolist())
+         tokens_a=a_out, eos_b=np.array(eos), tokens_b=b_out, min_new_c=np.array(min_new), tokens_c=c_out)
+    print("generate:", a_out.tolist(), eos, b_out.tolist(), min_new, c_out.tolist())
 
 
 def gen_generate_penalties():

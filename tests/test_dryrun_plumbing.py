@@ -298,6 +298,9 @@ def test_generate_plumbing(dry):
         dry.calls.clear(); m.generate(**kw, max_new_tokens=5, eos_token_id=[])
         assert dry.calls.count("ta_lm_prefill") == 1 and dry.calls.count("ta_lm_decode_step") == 4
         assert dry.calls.count("ta_greedy_advance") == 5 and dry.calls.count("ta_argmax_f32") == 5
+        assert dry.calls.count("ta_logits_suppress_until") == 0
+        dry.calls.clear(); m.generate(**kw, max_new_tokens=5, min_new_tokens=3)          # generation_config.min_new_tokens (round 4)
+        assert dry.calls.count("ta_logits_suppress_until") == dry.calls.count("ta_argmax_f32") >= 1
     with pytest.raises(ValueError, match="input_features required"):
         m.generate(input_ids=ids)
     with pytest.raises(ValueError, match="audio_attention_mask required"):

@@ -503,7 +503,8 @@ def test_mosa_projector_true_width():
 
 
 # ============================================================================ greedy generation (section 8(f) rank 1)
-def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12, processors_see_prompt=True, **processors):
+def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.12, processors_see_prompt=True, min_new_tokens=0,
+                                 **processors):
     """Greedy parity that is robust to bf16 near-ties: feed the HIP path's OWN tokens to the fp32 oracle and require
     every decision to be the oracle's argmax or within `tol` logits of it (bf16 logits carry ~0.03 of rounding);
     pad-after-EOS and the stopping rule are checked exactly."""
@@ -520,6 +521,10 @@ def _check_greedy_against_oracle(tokens, batch, W, cfg, eos_ids, pad_id, tol=0.1
         if processors:
             seq = np.concatenate([np.asarray(batch["input_ids"], np.int64), tokens[:, :t]], axis=1) if processors_see_prompt else tokens[:, :t]
             last = OG.apply_logits_processors(last.astype(np.float32), seq, **processors)
+        if t < min_new_tokens:                                # HF MinNewTokensLengthLogitsProcessor
+            last = last.astype(np.float32).copy()
+            last[:, list(eos_ids)] = -np.inf
+            assert not np.isin(tokens[:, t], list(eos_ids)).any(), "an eos id before min_new_tokens"
         for b in range(B):
             if not unfinished[b]:
                 assert tokens[b, t] == pad_id
@@ -560,8 +565,17 @@ def test_generate_vs_golden_and_oracle(golden):
     assert b.shape[1] <= 12
     if b.shape[1] < 12:                                      # stopped early: every clip must have emitted an eos id
         assert np.isin(b, [eos_b, S["pad_id"]]).any(axis=1).all()
+    # generation_config.min_new_tokens (tiny_audio/asr_config.py:83; round 4): no eos id before min_new tokens exist -- the fixture's
+    # clip 0 would stop at step 6, the reference's run with min_new_tokens = 9 carries on
+    mn = int(g["min_new_c"])
+    c = m.generate(**kw, max_new_tokens=12, eos_token_id=[eos_b, S["pad_id"]], min_new_tokens=mn).cpu().numpy()
+    assert c.shape == g["tokens_c"].shape and not np.isin(c[:, :mn], [eos_b, S["pad_id"]]).any()
+    _check_greedy_against_oracle(c, batch, W, cfg, (eos_b, S["pad_id"]), S["pad_id"], min_new_tokens=mn)
+    assert (c == g["tokens_c"]).mean() > 0.5 and (c[:, :3] == g["tokens_c"][:, :3]).all()
     with pytest.raises(NotImplementedError):
         m.generate(**kw, num_beams=4)
+    with pytest.raises(NotImplementedError):
+        m.generate(**kw, do_sample=True)
     with pytest.raises(ValueError):
         m.generate(input_ids=kw["input_ids"], input_features=kw["input_features"])
 

@@ -237,6 +237,11 @@ def test_greedy_generate(golden):
     b = OG.greedy_generate(batch, W, cfg, max_new_tokens=12, eos_ids=(int(g["eos_b"]), S["pad_id"]), pad_id=S["pad_id"])
     np.testing.assert_array_equal(b, g["tokens_b"])
     assert b.shape[1] == 11 and (b[0, 7:] == S["pad_id"]).all()          # clip 0 finished first and is padded
+    # generation_config.min_new_tokens (tiny_audio/asr_config.py:83 -> HF MinNewTokensLengthLogitsProcessor), token-exact
+    c = OG.greedy_generate(batch, W, cfg, max_new_tokens=12, eos_ids=(int(g["eos_b"]), S["pad_id"]), pad_id=S["pad_id"],
+                           min_new_tokens=int(g["min_new_c"]))
+    np.testing.assert_array_equal(c, g["tokens_c"])
+    assert int(g["min_new_c"]) == 9 and int(g["eos_b"]) not in c[0].tolist()
 
 
 def test_greedy_generate_with_logits_processors(golden):

@@ -320,10 +320,10 @@ class ASRModel(nn.Module):
         if audio_attention_mask is None:
             raise ValueError("audio_attention_mask required for generation")
         max_new = int(self._generation_setting("max_new_tokens", 128, kw))
-        if (int(self._generation_setting("num_beams", 1, kw)) != 1 or bool(self._generation_setting("do_sample", False, kw))
-                or int(self._generation_setting("min_new_tokens", 0, kw)) != 0):
-            raise NotImplementedError("greedy search only (num_beams 1, do_sample False, min_new_tokens 0: the reference's "
-                                      "generation config, asr_config.py:103-111); beam search and sampling are not built")
+        if int(self._generation_setting("num_beams", 1, kw)) != 1 or bool(self._generation_setting("do_sample", False, kw)):
+            raise NotImplementedError("greedy search only (num_beams 1, do_sample False: the reference's generation config, "
+                                      "asr_config.py:103-111); beam search and sampling are not built")
+        min_new = int(self._generation_setting("min_new_tokens", 0, kw) or 0)   # HF MinNewTokensLengthLogitsProcessor (round 4)
         # the reference's other two knobs (asr_config.py:84-86): HF logits processors on the device, in front of the argmax
         rep = float(self._generation_setting("repetition_penalty", 1.0, kw))
         ngram = int(self._generation_setting("no_repeat_ngram_size", 0, kw))
@@ -362,7 +362,8 @@ class ASRModel(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
         return dict(input_ids=ids, src_row=src_row, audio=y.reshape(B * N, -1), attention_mask=attention_mask,
-                    max_new_tokens=max_new, eos_ids=eos_ids, pad_id=pad_id, repetition_penalty=rep, no_repeat_ngram_size=ngram)
+                    max_new_tokens=max_new, eos_ids=eos_ids, pad_id=pad_id, repetition_penalty=rep, no_repeat_ngram_size=ngram,
+                    min_new_tokens=min_new)
 
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,
@@ -370,7 +371,7 @@ class ASRModel(nn.Module):
                  system_prompt: Optional[str] = None, **generate_kwargs) -> torch.Tensor:
         """Transcription token ids [B, n_new] (prompt stripped), as ASRModel.generate of the reference
         (tiny_audio/asr_modeling.py:562-646): audio -> encoder -> projector -> <audio> rows of the prompt embeddings ->
-        greedy search on the LM (num_beams 1, do_sample False, min_new_tokens 0: asr_config.py:103-111), with the
+        greedy search on the LM (num_beams 1, do_sample False: asr_config.py:103-111), with the
         reference's ``repetition_penalty`` / ``no_repeat_ngram_size`` settings as device-side logits processors."""
         was_training = self.training
         self.eval()

@@ -446,6 +446,26 @@ extern "C" int ta_logits_process(float* logits, long ld, int V, const long* prom
   return TA_OK;
 }
 
+// HF MinNewTokensLengthLogitsProcessor (TF:generation/logits_process.py; generation_config.min_new_tokens, tiny_audio/asr_config.py:83,
+// forwarded at tiny_audio/asr_modeling.py:631-637): while fewer than `min_new` tokens have been generated, every eos id scores -inf.
+// The count comes from *step_p in device memory, so the launch arguments never change (hipGraph-capturable).
+__global__ void logits_suppress_kernel(float* __restrict__ logits, long ld, int V, const long* __restrict__ ids, int n_ids, int min_new,
+                                       const int* __restrict__ step_p, int B) {
+  if (*step_p >= min_new) return;
+  for (int i = threadIdx.x; i < B * n_ids; i += blockDim.x) {
+    const long id = ids[i % n_ids];
+    if (id >= 0 && id < V) logits[(long)(i / n_ids) * ld + id] = -INFINITY;
+  }
+}
+extern "C" int ta_logits_suppress_until(float* logits, long ld, int V, const long* ids, int n_ids, int min_new, const int* step_dev, int B,
+                                        hipStream_t st) {
+  if (B <= 0 || n_ids <= 0 || min_new <= 0) return TA_OK;
+  if (!logits || !ids || !step_dev) return TA_ERR_ARG;
+  TA_LAUNCH(logits_suppress_kernel, dim3(1), dim3(256), 0, st, logits, ld, V, ids, n_ids, min_new, step_dev, B);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
 extern "C" int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad_id, int* finished, long* next_ids,
                                  long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax,
                                  int B, int* n_unfinished, hipStream_t st) {
