@@ -579,9 +579,13 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
   } else {
     static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
     static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
-    // round 4 experiment, OPT-IN: the sub-transforms on the f32 matrix cores.  Measured 76.4 us per launch against 68.2 for the
+    // round 4 experiment (TA355_LOGMEL_MFMA=1 in an experiment build): the sub-transforms on the f32 matrix cores.  Measured 76.4 us per launch against 68.2 for the
     // register FFT (profiles/r04_za_*): the transform was never the long phase of this kernel (17 of 68 us), see the persistent loop
+#ifdef TA355_EXPERIMENTS
     static const bool mfma = [] { const char* e = getenv("TA355_LOGMEL_MFMA"); return e && *e == '1'; }();
+#else
+    constexpr bool mfma = false;                     // (the instantiation exists in experiment builds only: TA355_BUILD_EXPERIMENTS=1)
+#endif
     // TA355_LOGMEL_ONEPASS=1 (experiment; measured SLOWER, profiles/r03_f_logmel_onepass.txt: 113.7 us against 80.9 for 32 clips):
     // the clip's workgroups rendezvous on an arrival counter and write the tile once from LDS instead of the second pass -- but a
     // workgroup then holds its CU slot until the slowest of its clip's 32 arrives, and the second wave of clips starts that much later
@@ -591,7 +595,9 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
+#ifdef TA355_EXPERIMENTS
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
+#endif
       attr = true;
     }
     static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
@@ -611,8 +617,10 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
     const int nt_arg = persist ? ntiles : 0;
     if (wide)
       TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
+#ifdef TA355_EXPERIMENTS
     else if (mfma)
       TA_LAUNCH((logmel_fft_kernel<32, 2, true>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
+#endif
     else
       TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
   }
