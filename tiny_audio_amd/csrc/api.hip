@@ -320,6 +320,8 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
 }
 struct LmWs {
   bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB, *dyB2;
+  float* lora_part;            // round 4: per-chunk partial adapter gradients of every layer (two-level reduction, no atomics)
+  long lp_layer, lp_off[8], lp_size[8]; int lp_chunks[8];   // kinds in ta_lm_lora_grads order: la_qkv, lb_qkv, la_o, lb_o, la_gu, lb_gu, la_d, lb_d
   float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
   // trainable LM: transposed bf16 images of one dW product's operands ([rows, Kp], Kp = tokens rounded up to 64) and
   // the split-K slabs of the dW GEMMs
@@ -355,6 +357,19 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dqkv = c.take<bf16_t>((size_t)d.M * d.NQKV);
   s.dyB = c.take<bf16_t>((size_t)d.M * 64);
   s.dyB2 = c.take<bf16_t>((size_t)d.M * 64);
+  s.lora_part = nullptr; s.lp_layer = 0;
+  if (w->lora_rank > 0) {
+    const int r = w->lora_rank, bq = d.nq * d.hd;
+    const int members[4] = {3, 1, 2, 1}, Ng[4] = {d.NQKV, d.D, 2 * d.F, d.D}, ing[4] = {d.D, bq, d.D, d.F};
+    long off = 0;
+    for (int g = 0; g < 4; ++g) {
+      const int chunks = ta_cdiv((int)d.M, ta_i_lora_tn2_rows((int)d.M, Ng[g], ing[g]));
+      s.lp_size[2 * g] = (long)members[g] * r * ing[g]; s.lp_size[2 * g + 1] = (long)Ng[g] * r;      // la_g, lb_g
+      for (int h = 0; h < 2; ++h) { s.lp_chunks[2 * g + h] = chunks; s.lp_off[2 * g + h] = off; off += s.lp_size[2 * g + h] * chunks; }
+    }
+    s.lp_layer = off;
+    s.lora_part = c.take<float>((size_t)off * w->n_layers);
+  }
   const int sp = pick_splits(nl, d.D, w->vocab_pad);
   s.skws = c.take<float>((size_t)ta_gemm_splitk_ws_bytes(nl, d.D, sp) / 4 + 4);
   s.tA = s.tB = nullptr; s.wsk = nullptr;
@@ -610,6 +625,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
            z(g.dlb_o, (size_t)d.D * r) && z(g.dla_gu, (size_t)2 * r * d.D) && z(g.dlb_gu, (size_t)2 * d.F * r) &&
            z(g.dla_d, (size_t)r * d.F) && z(g.dlb_d, (size_t)d.D * r);
   };
+  bool lora_parts = false;
   if (lora) {
     // The per-layer gradients are usually slices of 8 stacked tensors [n_layers, ...]: then 8 memsets clear everything
     // (224 tiny fills cost 0.6 ms per step at 28 layers); otherwise layer by layer.
@@ -624,9 +640,15 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     for (int k = 0; k < 8 && stacked; ++k)
       for (int l = 1; l < NL; ++l)
         if (fld(lora_grads[l], k) != fld(lora_grads[0], k) + (size_t)l * sz[k]) { stacked = false; break; }
+    // round 4: with stacked gradient tensors the adapter-gradient kernels store per-chunk partial sums and ONE kernel at the end adds
+    // them in a fixed order (TA355_LORA_TN_PARTS=0: float atomics as in rounds 1-3) -- deterministic, and no memset of the gradients
+    static const bool parts_env = [] { const char* e = getenv("TA355_LORA_TN_PARTS"); return !(e && *e == '0'); }();
+    lora_parts = stacked && parts_env && s.lora_part && (r % 4 == 0);
+    for (int k = 0; k < 8 && lora_parts; ++k) if (sz[k] != (size_t)s.lp_size[k]) lora_parts = false;
     if (stacked) {
-      for (int k = 0; k < 8; ++k)
-        if (hipMemsetAsync(fld(lora_grads[0], k), 0, sz[k] * NL * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
+      if (!lora_parts || lgm != 15)
+        for (int k = 0; k < 8; ++k)
+          if (hipMemsetAsync(fld(lora_grads[0], k), 0, sz[k] * NL * 4, st) != hipSuccess) return TA_ERR_LAUNCH;
     } else {
       for (int l = 0; l < NL; ++l) if (!zero_lora(lora_grads[l])) return TA_ERR_LAUNCH;
     }
@@ -652,7 +674,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   LoraSide* side = (lora && side_env && lgm == 15) ? lora_side() : nullptr;   // (target subsets change which kernels lie between two groups)
   int side_n = 0;                                    // groups forked so far
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
-                      float* dlb, int members, int b0, int b1) -> int {
+                      float* dlb, int members, int b0, int b1, int layer, int grp) -> int {
     bf16_t* dyB = (side && (side_n & 1)) ? s.dyB2 : s.dyB;
     RC(ta_i_lora_skinny_nt(dy, N, g.bt, dyB, M, members * r, st));
     static const bool dual = [] { const char* e = getenv("TA355_LORA_TN_DUAL"); return !(e && *e == '0'); }();
@@ -662,9 +684,11 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       if (hipEventRecord(side->fork[k], st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork[k], 0) != hipSuccess) return TA_ERR_LAUNCH;
       ts = side->s;
     }
-    if (dual) {                                        // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
+    if (dual || lora_parts) {                          // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
+      float* pb = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp + 1] : nullptr;
+      float* pa = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp] : nullptr;
       RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, dyB, members * r, dla, 1, in, w->lora_scale,
-                              0, 0, 0, M, ts));
+                              0, 0, 0, M, pb, s.lp_size[2 * grp + 1], pa, s.lp_size[2 * grp], ts));
     } else {
       RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, ts));
       RC(ta_i_lora_skinny_tn(x, in, dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, ts));
@@ -733,7 +757,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     const ta_lm_layer& Lw = w->layers[l];
     const LmLayerTape& p = store[l];
     // ---- MLP: x2 = x1 + down(silu(gate) * up)
-    if (lgm & 8) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30));
+    if (lgm & 8) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30, l, 3));
     const ta_lm_layer_wgrads* g = wg ? &wg->layers[l] : nullptr;
     if (g) RC(wgrad(s.dxb, d.D, p.act_s, d.F, g->dwd));
     // Measured (same box, 3 runs each): fusing the SwiGLU backward into this GEMM's epilogue makes the step 0.4 ms SLOWER
@@ -746,13 +770,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       RC(gemm_opt(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, o, st));
     }
     if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
-    if (lgm & 4) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30));
+    if (lgm & 4) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30, l, 2));
     if (g) RC(wgrad(s.dgu, 2 * d.F, p.xn2_s, d.D, g->dwgu));
     RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
     if (g && g->dln_post) RC(ta_rmsnorm_dw(s.dxn, gb, p.x1, lm_res_bf16(), p.r_post, g->dln_post, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
-    if (lgm & 2) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30));
+    if (lgm & 2) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30, l, 1));
     if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue (TA355_ATTN_BWD_FUSED=0:
@@ -790,7 +814,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
                             g ? g->dqn : nullptr, g ? g->dkn : nullptr, B, d.nq, d.nkv, L, st));
     }
     if (g) RC(wgrad(s.dqkv, d.NQKV, p.xn_s, d.D, g->dwqkv));
-    if (lgm & 1) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk));
+    if (lgm & 1) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk, l, 0));
     RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));
     if (g && g->dln_in) RC(ta_rmsnorm_dw(s.dxn, gb, p.x_in, lm_res_bf16(), p.r_in, g->dln_in, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, l == 0));
@@ -800,5 +824,17 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   if (d_audio && src_row) RC(ta_audio_grad_gather(src_row, dx, d_audio, M, d.D, st));
   if (wg && wg->dembed) RC(ta_embed_grad_scatter(ids, src_row, dx, wg->dembed, M, d.D, w->vocab, st));
   if (side && side_n > 0 && hipStreamWaitEvent(st, side->join[(side_n - 1) & 1], 0) != hipSuccess) return TA_ERR_LAUNCH;   // join
+  if (lora_parts) {                                  // second level of the adapter-gradient reduction: every layer, every kind, one launch
+    LoraReduceDesc rd;
+    float* const f0[8] = {lora_grads[0].dla_qkv, lora_grads[0].dlb_qkv, lora_grads[0].dla_o, lora_grads[0].dlb_o,
+                          lora_grads[0].dla_gu, lora_grads[0].dlb_gu, lora_grads[0].dla_d, lora_grads[0].dlb_d};
+    for (int k = 0; k < 8; ++k) {
+      const bool on = (lgm >> (k >> 1)) & 1;
+      rd.out[k] = f0[k]; rd.out_ls[k] = s.lp_size[k]; rd.size[k] = on ? s.lp_size[k] : 0; rd.part_off[k] = s.lp_off[k];
+      rd.chunks[k] = s.lp_chunks[k];
+    }
+    rd.part = s.lora_part; rd.part_ls = s.lp_layer;
+    RC(ta_i_lora_reduce_parts(rd, w->n_layers, st));
+  }
   return TA_OK;
 }

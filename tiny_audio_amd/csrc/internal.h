@@ -18,7 +18,12 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
                         int r, int b0, int b1, hipStream_t st);
 int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float* out0, long so_c0, long so_j0, float post0, int r0,
                          int b00, int b10, const void* X1, int Cn1, const void* Y1, int R1, float* out1, long so_c1, long so_j1,
-                         float post1, int r1, int b01, int b11, int M, hipStream_t st);   // two TN products, one launch
+                         float post1, int r1, int b01, int b11, int M, float* part0, long part_cs0, float* part1, long part_cs1,
+                         hipStream_t st);   // two TN products, one launch; part != NULL: row chunk c stores at part + c * part_cs (no atomics)
+int ta_i_lora_tn2_rows(int M, int Cn0, int Cn1);   // rows per chunk of such a launch (chunks = ceil(M / rows))
+// the second level of the adapter-gradient reduction: 8 gradient kinds x layers in one launch
+struct LoraReduceDesc { float* out[8]; long out_ls[8]; long size[8]; long part_off[8]; int chunks[8]; const float* part; long part_ls; };
+int ta_i_lora_reduce_parts(const LoraReduceDesc& d, int layers, hipStream_t st);
 int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, int R, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T; rows >= R of W are zero
 
 // fused decode-step kernels for batch <= 32 (csrc/decode_fused.hip); TA_ERR_ARG = outside the envelope, take the unfused path

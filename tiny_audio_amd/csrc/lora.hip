@@ -61,10 +61,13 @@ __device__ __forceinline__ lbf16x4 tr_read(const bf16_t* p) {
 }
 typedef __attribute__((ext_vector_type(4))) float lf32x4;
 
-struct LoraTnArgs { const bf16_t* X; int Cn; const bf16_t* Y; int R; float* out; long so_c, so_j; float post; int r, b0, b1, rows, gx, gy; };
+// part != NULL (round 4): row chunk `by` STORES its partial sums at part + by * part_cs (same [c, j] layout as out) and a second kernel
+// adds the chunks in a fixed order -- no float atomics: the result does not depend on the order workgroups finish in, and a workgroup's
+// last instructions are plain stores instead of 256 x R device-scope atomics that its exit waits for
+struct LoraTnArgs { const bf16_t* X; int Cn; const bf16_t* Y; int R; float* out; long so_c, so_j; float post; int r, b0, b1, rows, gx, gy; float* part; long part_cs; };
 __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_t* __restrict__ X, int Cn, const bf16_t* __restrict__ Y,
                                              int R, float* __restrict__ out, long so_c, long so_j, int M, float post, int r, int b0,
-                                             int b1, int rows_per_chunk, int bx, int by) {
+                                             int b1, int rows_per_chunk, int bx, int by, float* __restrict__ part = nullptr, long part_cs = 0) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
   const int c0 = bx * 256;
   const int m_begin = by * rows_per_chunk, m_end = min(M, m_begin + rows_per_chunk);
@@ -146,7 +149,11 @@ __device__ __forceinline__ void lora_tn_body(bf16_t* sx, bf16_t* sy, const bf16_
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int j = jb * 16 + g * 4 + q;
-          if (j >= jlo && j < jhi) unsafeAtomicAdd(out + (long)c * so_c + (long)(j - jlo) * so_j, acc[jb][cb][q] * post);
+          if (j >= jlo && j < jhi) {
+            const long o = (long)c * so_c + (long)(j - jlo) * so_j;
+            if (part) part[(long)by * part_cs + o] = acc[jb][cb][q] * post;
+            else unsafeAtomicAdd(out + o, acc[jb][cb][q] * post);
+          }
         }
       }
   }
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void lora_tn_dual_kernel(const LoraTnArgs p0, 
   const bool second = b >= n0;
   const LoraTnArgs& p = second ? p1 : p0;
   if (second) b -= n0;
-  lora_tn_body(sx, sy, p.X, p.Cn, p.Y, p.R, p.out, p.so_c, p.so_j, M, p.post, p.r, p.b0, p.b1, p.rows, b % p.gx, b / p.gx);
+  lora_tn_body(sx, sy, p.X, p.Cn, p.Y, p.R, p.out, p.so_c, p.so_j, M, p.post, p.r, p.b0, p.b1, p.rows, b % p.gx, b / p.gx, p.part, p.part_cs);
 }
 
 // out[M, 64] (bf16) = X[M, K] W[64, K]^T : the rank-space projections xa = x (sAcat)^T and dyB = dy Bext.
@@ -295,14 +302,46 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
+// rows per workgroup of a pair launched with partial buffers: about TA355_LORA_TN_WGS (default 384) workgroups over both problems
+int ta_i_lora_tn2_rows(int M, int Cn0, int Cn1) {
+  static const int wgs_env = [] { const char* e = getenv("TA355_LORA_TN_WGS"); return e && *e && atoi(e) > 0 ? atoi(e) : 384; }();
+  const long gx = ta_cdiv(Cn0, 256) + ta_cdiv(Cn1, 256);
+  const long want = ((long)M * gx + wgs_env - 1) / wgs_env;
+  return (int)(((want < 32 ? 32 : want) + 31) / 32 * 32);
+}
+// out[layer][kind][e] = sum over the chunks of part[layer][kind][chunk][e], chunk 0 first: ONE launch for every adapter gradient of
+// the step (grid: element blocks x 8 kinds x layers)
+__global__ __launch_bounds__(256) void lora_reduce_parts_kernel(LoraReduceDesc d) {
+  const int k = blockIdx.y, l = blockIdx.z;
+  const long n = d.size[k];
+  const float* p = d.part + (long)l * d.part_ls + d.part_off[k];
+  float* o = d.out[k] + (long)l * d.out_ls[k];
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 1024) {
+    float4 a = *(const float4*)(p + e);
+    for (int c = 1; c < d.chunks[k]; ++c) {
+      const float4 b = *(const float4*)(p + (long)c * n + e);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(o + e) = a;
+  }
+}
+int ta_i_lora_reduce_parts(const LoraReduceDesc& d, int layers, hipStream_t st) {
+  long mx = 0;
+  for (int k = 0; k < 8; ++k) { if (d.size[k] % 4) return TA_ERR_ARG; mx = d.size[k] > mx ? d.size[k] : mx; }
+  if (layers <= 0 || mx <= 0) return TA_OK;
+  TA_LAUNCH(lora_reduce_parts_kernel, dim3((unsigned)ta_cdiv(mx, 1024), 8, layers), dim3(256), 0, st, d);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
 // both adapter gradients of one group in one launch: problem 0 = (X0, Y0, ...), problem 1 likewise (same M)
 int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float* out0, long so_c0, long so_j0, float post0, int r0,
                          int b00, int b10, const void* X1, int Cn1, const void* Y1, int R1, float* out1, long so_c1, long so_j1,
-                         float post1, int r1, int b01, int b11, int M, hipStream_t st) {
+                         float post1, int r1, int b01, int b11, int M, float* part0, long part_cs0, float* part1, long part_cs1,
+                         hipStream_t st) {
   if (R0 > 64 || R0 <= 0 || R1 > 64 || R1 <= 0 || (Cn0 % 8) || (Cn1 % 8)) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  LoraTnArgs p0 = {(const bf16_t*)X0, Cn0, (const bf16_t*)Y0, R0, out0, so_c0, so_j0, post0, r0, b00, b10, lora_tn_rows(M, Cn0), 0, 0};
-  LoraTnArgs p1 = {(const bf16_t*)X1, Cn1, (const bf16_t*)Y1, R1, out1, so_c1, so_j1, post1, r1, b01, b11, lora_tn_rows(M, Cn1), 0, 0};
+  LoraTnArgs p0 = {(const bf16_t*)X0, Cn0, (const bf16_t*)Y0, R0, out0, so_c0, so_j0, post0, r0, b00, b10, lora_tn_rows(M, Cn0), 0, 0, part0, part_cs0};
+  LoraTnArgs p1 = {(const bf16_t*)X1, Cn1, (const bf16_t*)Y1, R1, out1, so_c1, so_j1, post1, r1, b01, b11, lora_tn_rows(M, Cn1), 0, 0, part1, part_cs1};
   p0.gx = ta_cdiv(Cn0, 256); p1.gx = ta_cdiv(Cn1, 256);
   // Rows per workgroup of the pair (round 3): as many as leave about ONE workgroup per CU over both problems.  Every workgroup ends
   // with 256 x R float atomics on addresses shared with the other row chunks of its column strip, and a rows-per-workgroup sweep of
@@ -311,7 +350,8 @@ int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float*
   // TA355_LORA_TN_ROWS = a fixed row count as before.
   static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
   static const int wgs_env = [] { const char* e = getenv("TA355_LORA_TN_WGS"); return e && *e ? atoi(e) : 384; }();
-  if (rows_env <= 0 && wgs_env > 0) {
+  if (part0 || part1) p0.rows = p1.rows = ta_i_lora_tn2_rows(M, Cn0, Cn1);       // (the caller sized the partial buffers with it)
+  else if (rows_env <= 0 && wgs_env > 0) {
     const long want = ((long)M * (p0.gx + p1.gx) + wgs_env - 1) / wgs_env;
     const int rows = (int)((want < 32 ? 32 : want) + 31) / 32 * 32;
     p0.rows = p1.rows = rows;
