@@ -302,6 +302,14 @@ int ta_argmax_f32(const float* x, long ld, int n, int rows, long* out, hipStream
  * no_repeat_ngram_size 0 make it a no-op; L + max_new <= 8192. */
 int ta_logits_process(float* logits, long ld, int V, const long* prompt_ids, int L, const long* out_seq, int max_new,
                       const int* step_dev, int B, float repetition_penalty, int no_repeat_ngram_size, hipStream_t st);
+/* Sampling (generation_config.do_sample / temperature / top_k / top_p: tiny_audio/asr_config.py:78-81, forwarded to HF at
+ * tiny_audio/asr_modeling.py:631-637).  ta_logits_warp applies HF's warpers in HF's order, in place on logits f32 [B, ld] (columns
+ * < V): TemperatureLogitsWarper (scores / T), TopKLogitsWarper (below the k-th largest -> -inf; 0 = off), TopPLogitsWarper (ascending
+ * cumulative probability <= 1 - top_p -> -inf, the largest always kept; 1 = off).  ta_sample_f32 draws out[b] ~ softmax(logits[b, :V])
+ * with a Philox4x32-10 uniform keyed by (seed, *step_dev, b): reproducible per seed, independent of launch geometry.  Call both
+ * between the logits processors and ta_greedy_advance (ta_sample_f32 takes the place of ta_argmax_f32). */
+int ta_logits_warp(float* logits, long ld, int V, int B, float temperature, int top_k, float top_p, hipStream_t st);
+int ta_sample_f32(const float* logits, long ld, int V, int B, unsigned long long seed, const int* step_dev, long* out, hipStream_t st);
 /* HF MinNewTokensLengthLogitsProcessor (generation_config.min_new_tokens: tiny_audio/asr_config.py:83, forwarded to
  * language_model.generate at tiny_audio/asr_modeling.py:631-637): while *step_dev (tokens generated so far, device memory) is below
  * min_new, logits[b, ids[e]] = -inf for every eos id.  Call between ta_logits_process and ta_argmax_f32. */

@@ -61,6 +61,32 @@ def apply_logits_processors(scores, seq, repetition_penalty=1.0, no_repeat_ngram
     return scores
 
 
+def warp_logits(scores, temperature=1.0, top_k=0, top_p=1.0):
+    """HF's sampling warpers in HF's order (TF:generation/logits_process.py TemperatureLogitsWarper, TopKLogitsWarper,
+    TopPLogitsWarper; reached with generation_config.do_sample, tiny_audio/asr_config.py:78-81): scores / T; everything below the
+    k-th largest score -> -inf (ties at the k-th value stay); ascending sort, softmax, cumulative sum, cumulative <= 1 - top_p -> -inf
+    except the last (largest) entry.  float32 throughout, as torch does it."""
+    x = np.asarray(scores, np.float32).copy()
+    if temperature != 1.0:
+        x = (x / np.float32(temperature)).astype(np.float32)
+    V = x.shape[-1]
+    if 0 < top_k < V:
+        kth = np.sort(x, axis=-1)[:, V - top_k][:, None]
+        x = np.where(x < kth, np.float32(-np.inf), x)
+    if top_p < 1.0:
+        order = np.argsort(x, axis=-1, kind="stable")
+        srt = np.take_along_axis(x, order, axis=-1)
+        e = np.exp(srt - srt[:, -1:], dtype=np.float32)
+        probs = (e / e.sum(-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+        cum = np.cumsum(probs, axis=-1, dtype=np.float32)
+        rm_sorted = cum <= np.float32(1.0 - top_p)
+        rm_sorted[:, -1] = False
+        rm = np.zeros_like(rm_sorted)
+        np.put_along_axis(rm, order, rm_sorted, axis=-1)
+        x = np.where(rm, np.float32(-np.inf), x)
+    return x
+
+
 def greedy_generate(batch, W, cfg, max_new_tokens=128, eos_ids=(), pad_id=0, return_margins=False, repetition_penalty=1.0,
                     no_repeat_ngram_size=0, processors_see_prompt=True, min_new_tokens=0):
     """-> generated token ids [B, n_new] (prompt stripped), n_new <= max_new_tokens.  The prompt must be unpadded

@@ -509,6 +509,30 @@ def gen_generate_penalties():
     print("generate penalties:", {k: v.tolist() for k, v in out.items()})
 
 
+def gen_sampling_warpers():
+    """HF's own sampling warpers (the transformers the reference runs on: TemperatureLogitsWarper, TopKLogitsWarper,
+    TopPLogitsWarper, in the order GenerationMixin applies them under generation_config.do_sample, tiny_audio/asr_config.py:78-81)
+    on seeded random scores with ties: the -inf masks and the scaled values pin oracle.generate.warp_logits."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    rng = np.random.RandomState(77)
+    x = (3.0 * rng.standard_normal((6, 1003))).astype(np.float32)
+    x[1, 10:40] = x[1, 5]                      # a plateau of ties
+    x[2] = np.round(x[2])                      # many ties
+    x[3, 500] = 40.0                           # one dominant token
+    out = {"scores": x}
+    for i, (T, k, p) in enumerate(((1.0, 50, 1.0), (0.7, 0, 0.9), (1.3, 40, 0.95), (1.0, 0, 0.5), (0.5, 5, 0.3), (2.0, 1, 1.0))):
+        s_ = t(x)
+        if T != 1.0:
+            s_ = TemperatureLogitsWarper(T)(None, s_)
+        if k:
+            s_ = TopKLogitsWarper(k)(None, s_)
+        if p < 1.0:
+            s_ = TopPLogitsWarper(p)(None, s_)
+        out[f"cfg{i}"] = np.array([T, k, p], np.float64)
+        out[f"warped{i}"] = s_.numpy()
+    save("sampling_warpers.npz", **out)
+
+
 # ----------------------------------------------------------------------------- 6c. checkpoint written by the reference (section 8(f) rank 3)
 def gen_ckpt():
     """What ASRModel.save_pretrained stores for the trainable part: state_dict() -> model.safetensors (HF writes it with
@@ -563,7 +587,7 @@ def gen_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "train_moe", "fullft", "generate", "generate_penalties", "ckpt", "text", "known"]
+    which = sys.argv[1:] or ["logmel", "encoder", "projectors", "qformer", "mosa", "lm", "lora", "asr", "train_moe", "fullft", "generate", "sampling", "generate_penalties", "ckpt", "text", "known"]
     for w in which:
         {"logmel": gen_logmel, "encoder": gen_encoder, "projectors": gen_projectors, "lm": gen_lm, "lora": gen_lora,
-         "asr": gen_asr, "train_moe": gen_train_moe, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "generate_penalties": gen_generate_penalties, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()
+         "asr": gen_asr, "train_moe": gen_train_moe, "fullft": gen_fullft, "qformer": gen_qformer, "mosa": gen_mosa, "generate": gen_generate, "sampling": gen_sampling_warpers, "generate_penalties": gen_generate_penalties, "ckpt": gen_ckpt, "text": gen_text_post, "known": gen_known_answers}[w]()

@@ -308,7 +308,9 @@ def test_generate_plumbing(dry):
     with pytest.raises(ValueError, match="input_ids required"):
         m.generate(input_features=torch.zeros(2, 128, 100), audio_attention_mask=torch.ones(2, 100, dtype=torch.int64))
     with pytest.raises(NotImplementedError):
-        m.generate(**kw, do_sample=True)
+        m.generate(**kw, num_beams=3)
+    dry.calls.clear(); m.generate(**kw, max_new_tokens=3, do_sample=True, top_k=5, seed=1, eos_token_id=[])     # sampling (round 4)
+    assert dry.calls.count("ta_logits_warp") == dry.calls.count("ta_sample_f32") == 3 and dry.calls.count("ta_argmax_f32") == 0
     # streaming (asr_modeling.py:648-760): one clip, one token per step, same launches as generate
     one = dict(input_ids=ids[:1], input_features=torch.zeros(1, 128, 100), audio_attention_mask=torch.ones(1, 100, dtype=torch.int64))
     dry.calls.clear()

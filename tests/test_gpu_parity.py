@@ -574,8 +574,6 @@ def test_generate_vs_golden_and_oracle(golden):
     assert (c == g["tokens_c"]).mean() > 0.5 and (c[:, :3] == g["tokens_c"][:, :3]).all()
     with pytest.raises(NotImplementedError):
         m.generate(**kw, num_beams=4)
-    with pytest.raises(NotImplementedError):
-        m.generate(**kw, do_sample=True)
     with pytest.raises(ValueError):
         m.generate(input_ids=kw["input_ids"], input_features=kw["input_features"])
 

@@ -379,3 +379,98 @@ def test_lora_adapter_gradients_are_bit_reproducible():
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert sum(float(x.abs().sum()) for x in a) > 0
+
+
+# ============================================================================ sampling (generation_config.do_sample)
+def _lib_bits():
+    import ctypes as C
+    from tiny_audio_amd import _lib
+    return _lib, _lib.lib(), (lambda t: None if t is None else C.c_void_p(t.data_ptr())), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.gpu
+def test_logits_warp_vs_oracle(golden):
+    """ta_logits_warp (temperature, top-k, top-p by bisection on the ordered-integer image of the scores) against the numpy restatement
+    of HF's warpers, which tests/test_oracle_golden.py pins on HF's own outputs: same scaled values, same survivors -- except that
+    the device keeps ALL scores equal to the smallest surviving one where HF's sort keeps an arbitrary subset of them."""
+    import numpy as np
+    from oracle import generate as OG
+    _lib, L_, ptr, st = _lib_bits()
+    g = golden("sampling_warpers.npz")
+    x = g["scores"]
+    B, V = x.shape
+    ld = 1024
+    for i in range(6):
+        T, k, p = (float(v) for v in g[f"cfg{i}"])
+        buf = torch.full((B, ld), 7.0, dtype=F32, device=DEV)                 # columns >= V must stay untouched
+        buf[:, :V] = torch.from_numpy(x).to(DEV)
+        _lib.check(L_.ta_logits_warp(ptr(buf), ld, V, B, T, int(k), p, st), "ta_logits_warp")
+        got = buf.cpu().numpy()
+        assert (got[:, V:] == 7.0).all()
+        ref = OG.warp_logits(x, T, int(k), p)
+        for r in range(B):
+            kg, kr = np.isfinite(got[r, :V]), np.isfinite(ref[r])
+            assert (kg | ~kr).all(), (i, r)                                    # every HF survivor survives
+            extra = np.nonzero(kg & ~kr)[0]
+            if extra.size:
+                assert np.all(x[r][extra] == x[r][kr].min()), (i, r)           # ... plus, at most, its ties
+            np.testing.assert_allclose(got[r, :V][kr], ref[r][kr], rtol=2e-7, atol=0)
+
+
+@pytest.mark.gpu
+def test_sample_rows_distribution_and_reproducibility():
+    """ta_sample_f32: one multinomial draw per row from softmax(logits), Philox-keyed by (seed, step, row): 16 384 rows of the same
+    filtered scores reproduce the probabilities (chi-square over the 6 surviving tokens), never pick a -inf token, the same seed and
+    step give the same draws and another step or seed different ones."""
+    import numpy as np
+    _lib, L_, ptr, st = _lib_bits()
+    V, ld, N = 50, 64, 16384
+    rng = np.random.RandomState(3)
+    row = np.full(V, -np.inf, np.float32)
+    keep = np.array([3, 4, 17, 30, 31, 49])
+    row[keep] = rng.standard_normal(6).astype(np.float32) * 1.5
+    logits = torch.from_numpy(np.tile(np.pad(row, (0, ld - V), constant_values=9.0), (N, 1))).to(DEV)
+    out = torch.zeros(N, dtype=torch.int64, device=DEV)
+    step = torch.tensor([5], dtype=torch.int32, device=DEV)
+
+    def draw(seed, stp):
+        step.fill_(stp)
+        _lib.check(L_.ta_sample_f32(ptr(logits), ld, V, N, seed, ptr(step), ptr(out), st), "ta_sample_f32")
+        return out.cpu().numpy().copy()
+    a, b, c, d = draw(1234, 5), draw(1234, 5), draw(1234, 6), draw(99, 5)
+    assert np.array_equal(a, b) and (a != c).mean() > 0.3 and (a != d).mean() > 0.3
+    assert np.isin(a, keep).all()
+    pr = np.exp(row[keep] - row[keep].max()); pr /= pr.sum()
+    cnt = np.array([(a == k).sum() for k in keep])
+    chi2 = float(((cnt - N * pr) ** 2 / (N * pr)).sum())
+    assert chi2 < 25.0, (chi2, cnt.tolist(), (N * pr).round(1).tolist())      # 5 degrees of freedom: P(chi2 > 25) ~ 1e-4
+
+
+@pytest.mark.gpu
+def test_generate_do_sample(golden):
+    """ASRModel.generate(do_sample=True, ...): top_k = 1 is greedy search token for token; a seed reproduces its tokens, another seed
+    gives other tokens; invalid settings are refused (the kernels behind it are checked in the two tests above)."""
+    import numpy as np
+    from oracle import weights as OW
+    from tests.golden import recipe as R
+    from tests.test_gpu_parity import build_model
+    g = golden("generate_small.npz")
+    S = R.SMALL
+    E, D, H = S["enc"]["hidden"], S["lm"]["hidden"], S["proj_hidden"]
+    wE, wL, wP = OW.init_encoder(S["enc"], 0), R.gen_lm_weights(), OW.init_mlp_projector(E, D, H)
+    m = build_model(S["enc"], S["lm"], H, wE, wL, wP, audio_token_id=S["audio_token_id"], pad_token_id=S["pad_id"], eos_token_id=S["eos_id"])
+    kw = dict(input_ids=torch.from_numpy(g["input_ids"]), input_features=torch.from_numpy(g["input_features"]),
+              audio_attention_mask=torch.from_numpy(g["audio_attention_mask"]), attention_mask=torch.ones(g["input_ids"].shape, dtype=torch.int64),
+              max_new_tokens=10, eos_token_id=[])
+    greedy = m.generate(**kw).cpu().numpy()
+    k1 = m.generate(**kw, do_sample=True, top_k=1, seed=7).cpu().numpy()
+    np.testing.assert_array_equal(k1, greedy)
+    a = m.generate(**kw, do_sample=True, temperature=1.5, top_k=8, top_p=0.95, seed=11).cpu().numpy()
+    b = m.generate(**kw, do_sample=True, temperature=1.5, top_k=8, top_p=0.95, seed=11).cpu().numpy()
+    c = m.generate(**kw, do_sample=True, temperature=1.5, top_k=8, top_p=0.95, seed=12).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == greedy.shape and (a != c).any() and (a != greedy).any()
+    with pytest.raises(ValueError):
+        m.generate(**kw, do_sample=True, temperature=0.0)
+    with pytest.raises(NotImplementedError):
+        m.generate(**kw, num_beams=2)

@@ -244,6 +244,27 @@ def test_greedy_generate(golden):
     assert int(g["min_new_c"]) == 9 and int(g["eos_b"]) not in c[0].tolist()
 
 
+def test_sampling_warpers_vs_hf(golden):
+    """generation_config.do_sample (tiny_audio/asr_config.py:78-81): oracle.generate.warp_logits against HF's own TemperatureLogitsWarper /
+    TopKLogitsWarper / TopPLogitsWarper outputs (fixture of make_golden.py:gen_sampling_warpers).  Exact, except WHICH of several
+    equal scores at the top-p boundary survive: that is torch.sort's order among ties, not a property of the algorithm."""
+    from oracle import generate as OG
+    g = golden("sampling_warpers.npz")
+    x = g["scores"]
+    for i in range(6):
+        T, k, p = (float(v) for v in g[f"cfg{i}"])
+        w, ref = OG.warp_logits(x, T, int(k), p), g[f"warped{i}"]
+        for r in range(x.shape[0]):
+            kw_, kr = np.isfinite(w[r]), np.isfinite(ref[r])
+            assert kw_.sum() == kr.sum(), (i, r)
+            diff = np.nonzero(kw_ != kr)[0]
+            if diff.size:                                        # only among scores equal to the smallest surviving one
+                assert np.all(ref[r][diff][np.isfinite(ref[r][diff])] == ref[r][kr].min()) and np.all(x[r][diff] == x[r][diff][0]), (i, r)
+            both = kw_ & kr
+            np.testing.assert_array_equal(w[r][both], ref[r][both])
+    assert np.isfinite(g["warped5"]).sum(-1).tolist() == [1, 1, 4, 1, 1, 1]          # top_k = 1 keeps ties
+
+
 def test_greedy_generate_with_logits_processors(golden):
     """The reference's two non-default generation knobs (tiny_audio/asr_config.py:84-86 -> HF RepetitionPenaltyLogitsProcessor /
     NoRepeatNGramLogitsProcessor over prompt ids + generated tokens): token-exact against the reference's own generate."""

@@ -320,9 +320,23 @@ class ASRModel(nn.Module):
         if audio_attention_mask is None:
             raise ValueError("audio_attention_mask required for generation")
         max_new = int(self._generation_setting("max_new_tokens", 128, kw))
-        if int(self._generation_setting("num_beams", 1, kw)) != 1 or bool(self._generation_setting("do_sample", False, kw)):
-            raise NotImplementedError("greedy search only (num_beams 1, do_sample False: the reference's generation config, "
-                                      "asr_config.py:103-111); beam search and sampling are not built")
+        if int(self._generation_setting("num_beams", 1, kw)) != 1:
+            raise NotImplementedError("num_beams 1 only (the reference's generation config, asr_config.py:103-111); beam search is not built")
+        # do_sample / temperature / top_k / top_p (asr_config.py:78-81; round 4): HF's warpers on the device, one multinomial draw per
+        # clip and step from a Philox stream keyed by ``seed`` (a generate() keyword here; default: torch's initial seed)
+        sampling = None
+        if bool(self._generation_setting("do_sample", False, kw)):
+            temp = self._generation_setting("temperature", None, kw)
+            top_k = self._generation_setting("top_k", None, kw)
+            top_p = self._generation_setting("top_p", None, kw)
+            seed = kw.pop("seed", None)
+            sampling = (1.0 if temp is None else float(temp), 0 if top_k is None else int(top_k), 1.0 if top_p is None else float(top_p),
+                        int(torch.initial_seed()) if seed is None else int(seed))
+            if not sampling[0] > 0 or sampling[1] < 0 or not 0 < sampling[2] <= 1:
+                raise ValueError("temperature must be > 0, top_k >= 0, 0 < top_p <= 1")
+        else:
+            for k_ in ("temperature", "top_k", "top_p", "seed"):
+                kw.pop(k_, None)
         min_new = int(self._generation_setting("min_new_tokens", 0, kw) or 0)   # HF MinNewTokensLengthLogitsProcessor (round 4)
         # the reference's other two knobs (asr_config.py:84-86): HF logits processors on the device, in front of the argmax
         rep = float(self._generation_setting("repetition_penalty", 1.0, kw))
@@ -363,7 +377,7 @@ class ASRModel(nn.Module):
         src_row = ops.audio_index(ids, counts, N, self.audio_token_id)
         return dict(input_ids=ids, src_row=src_row, audio=y.reshape(B * N, -1), attention_mask=attention_mask,
                     max_new_tokens=max_new, eos_ids=eos_ids, pad_id=pad_id, repetition_penalty=rep, no_repeat_ngram_size=ngram,
-                    min_new_tokens=min_new)
+                    min_new_tokens=min_new, sampling=sampling)
 
     @torch.no_grad()
     def generate(self, input_ids: Optional[torch.Tensor] = None, input_features: Optional[torch.Tensor] = None,

@@ -466,6 +466,154 @@ extern "C" int ta_logits_suppress_until(float* logits, long ld, int V, const lon
   return TA_OK;
 }
 
+// ---- sampling (generation_config.do_sample / temperature / top_k / top_p: tiny_audio/asr_config.py:78-81, forwarded to HF at
+// tiny_audio/asr_modeling.py:631-637).  HF order (TF:generation/utils.py _get_logits_processor + _sample): the processors above, then the
+// warpers TemperatureLogitsWarper (scores / T), TopKLogitsWarper (scores below the k-th largest -> -inf, ties kept), TopPLogitsWarper
+// (ascending cumulative probability <= 1 - top_p -> -inf, the largest always kept), then softmax + multinomial.
+// One 1024-thread workgroup per row.  The two thresholds are found by bisection on the order-preserving integer image of the floats
+// (<= 32 counting / mass passes over the row each; the row stays in L2), so no sort is needed and ties behave as in HF.
+__device__ __forceinline__ int w_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {      // red: [17] floats of LDS
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  return t;
+}
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
+  return t;
+}
+__global__ __launch_bounds__(1024) void logits_warp_kernel(float* __restrict__ logits, long ld, int V, float temperature, int top_k,
+                                                           float top_p) {
+  __shared__ float red[17];
+  float* row = logits + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int j = tid; j < V; j += 1024) {
+    float v = row[j];
+    if (temperature != 1.0f) { v = v / temperature; row[j] = v; }
+    if (v > -INFINITY) { mx = fmaxf(mx, v); mn = fminf(mn, v); }
+  }
+  mx = block_max_1024(mx, red);
+  mn = -block_max_1024(-mn, red);
+  if (!(mx > -INFINITY)) return;                                  // an all -inf row: nothing to do
+  if (top_k > 0 && top_k < V) {
+    // the k-th largest value: the largest ordered integer o with count(x >= o) >= k
+    long lo = w_f2ord(mn), hi = w_f2ord(mx);
+    while (lo < hi) {
+      const long mid = lo + (hi - lo + 1) / 2;
+      float c = 0.f;
+      for (int j = tid; j < V; j += 1024) c += (w_f2ord(row[j]) >= mid && row[j] > -INFINITY) ? 1.f : 0.f;
+      c = block_sum_1024(c, red);
+      if (c >= (float)top_k) lo = mid; else hi = mid - 1;
+    }
+    __syncthreads();
+    for (int j = tid; j < V; j += 1024) if (w_f2ord(row[j]) < lo) row[j] = -INFINITY;
+    __syncthreads();
+    mn = INFINITY;
+    for (int j = tid; j < V; j += 1024) { const float v = row[j]; if (v > -INFINITY) mn = fminf(mn, v); }
+    mn = -block_max_1024(-mn, red);
+  }
+  if (top_p < 1.0f) {
+    float z = 0.f;
+    for (int j = tid; j < V; j += 1024) z += __expf(row[j] - mx);
+    z = block_sum_1024(z, red);
+    // smallest ordered integer o with mass(x <= o) > 1 - top_p: everything below it is removed (the maximum has mass 1: always kept)
+    const float cut = (1.0f - top_p) * z;
+    long lo = w_f2ord(mn), hi = w_f2ord(mx);
+    while (lo < hi) {
+      const long mid = lo + (hi - lo) / 2;
+      float m = 0.f;
+      for (int j = tid; j < V; j += 1024) { const float v = row[j]; m += (v > -INFINITY && w_f2ord(v) <= mid) ? __expf(v - mx) : 0.f; }
+      m = block_sum_1024(m, red);
+      if (m > cut) hi = mid; else lo = mid + 1;
+    }
+    __syncthreads();
+    for (int j = tid; j < V; j += 1024) if (w_f2ord(row[j]) < hi) row[j] = -INFINITY;
+  }
+}
+extern "C" int ta_logits_warp(float* logits, long ld, int V, int B, float temperature, int top_k, float top_p, hipStream_t st) {
+  if (B <= 0) return TA_OK;
+  if (!logits || V <= 0 || !(temperature > 0.f) || top_k < 0 || !(top_p > 0.f) || top_p > 1.0f) return TA_ERR_ARG;
+  if (temperature == 1.0f && (top_k == 0 || top_k >= V) && top_p >= 1.0f) return TA_OK;
+  TA_LAUNCH(logits_warp_kernel, dim3(B), dim3(1024), 0, st, logits, ld, V, temperature, top_k, top_p);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// Philox4x32-10 (Salmon et al. 2011): counter (step, row, 0, 0), key = the 64-bit seed -> one uniform in [0, 1) per row and step
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned step, unsigned row) {
+  unsigned c0 = step, c1 = row, c2 = 0u, c3 = 0u, k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+// out[b] ~ softmax(logits[b, :V]) (multinomial, one draw): inverse CDF in INDEX order -- thread t owns the contiguous chunk
+// [t * per, (t + 1) * per), an exclusive scan of the chunk masses finds the chunk, its owner walks it.
+__global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restrict__ logits, long ld, int V, unsigned long long seed,
+                                                           const int* __restrict__ step_p, long* __restrict__ out) {
+  __shared__ float red[17];
+  __shared__ float part[1024];
+  __shared__ int pick;
+  const float* row = logits + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, per = (V + 1023) / 1024, j0 = tid * per, j1 = min(V, j0 + per);
+  float mx = -INFINITY;
+  for (int j = tid; j < V; j += 1024) mx = fmaxf(mx, row[j]);
+  mx = block_max_1024(mx, red);
+  float s = 0.f;
+  int last = -1;                                                 // last index of this chunk with a non-zero probability
+  for (int j = j0; j < j1; ++j) { const float p = __expf(row[j] - mx); s += p; if (p > 0.f) last = j; }
+  part[tid] = s;
+  if (tid == 0) pick = -1;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                            // inclusive scan of the chunk masses
+    const float v = tid >= o ? part[tid - o] : 0.f;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const float total = part[1023];
+  const float u = philox_uniform(seed, (unsigned)*step_p, blockIdx.x) * total;
+  const float before = part[tid] - s;
+  if (s > 0.f && before <= u && (u < part[tid] || tid == 1023)) {
+    float c = before; int choice = last;
+    for (int j = j0; j < j1; ++j) { const float p = __expf(row[j] - mx); c += p; if (p > 0.f && u < c) { choice = j; break; } }
+    pick = choice;
+  }
+  __syncthreads();
+  if (pick < 0) {                                                 // rounding left the draw behind the last mass: the last token that has any
+    int cand = last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o, 64));
+    if ((tid & 63) == 0) atomicMax(&pick, cand);
+    __syncthreads();
+  }
+  if (tid == 0) out[blockIdx.x] = pick < 0 ? 0 : pick;
+}
+extern "C" int ta_sample_f32(const float* logits, long ld, int V, int B, unsigned long long seed, const int* step_dev, long* out,
+                             hipStream_t st) {
+  if (B <= 0) return TA_OK;
+  if (!logits || V <= 0 || !step_dev || !out) return TA_ERR_ARG;
+  TA_LAUNCH(sample_rows_kernel, dim3(B), dim3(1024), 0, st, logits, ld, V, seed, step_dev, out);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
 extern "C" int ta_greedy_advance(const long* amax, const long* eos_ids, int n_eos, long pad_id, int* finished, long* next_ids,
                                  long* out_seq, int max_new, int* step_dev, int* slot_dev, int* pos, int* kmask, int Lmax,
                                  int B, int* n_unfinished, hipStream_t st) {

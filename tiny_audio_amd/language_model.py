@@ -508,19 +508,19 @@ class Qwen3MI355X(torch.nn.Module):
     # ------------------------------------------------------------------ greedy decoding
     @torch.no_grad()
     def greedy_decode(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
-                      sync_every=8, use_graph=True, repetition_penalty=1.0, no_repeat_ngram_size=0, min_new_tokens=0):
+                      sync_every=8, use_graph=True, repetition_penalty=1.0, no_repeat_ngram_size=0, min_new_tokens=0, sampling=None):
         """-> int64 [B, n_new]; see ``greedy_decode_iter`` (this drains it, polling the device every ``sync_every``
         steps only)."""
         out = None
         for out in self.greedy_decode_iter(input_ids, src_row, audio, attention_mask, max_new_tokens, eos_ids, pad_id,
-                                           sync_every, use_graph, per_token=False, repetition_penalty=repetition_penalty, min_new_tokens=min_new_tokens,
+                                           sync_every, use_graph, per_token=False, repetition_penalty=repetition_penalty, min_new_tokens=min_new_tokens, sampling=sampling,
                                            no_repeat_ngram_size=no_repeat_ngram_size):
             pass
         return out
 
     def greedy_decode_iter(self, input_ids, src_row, audio, attention_mask=None, max_new_tokens=128, eos_ids=(), pad_id=0,
                            sync_every=8, use_graph=True, per_token=True, repetition_penalty=1.0, no_repeat_ngram_size=0, min_new_tokens=0,
-                           processors_see_prompt=True):
+                           processors_see_prompt=True, sampling=None):
         """HF greedy search with a KV cache (what ``language_model.generate`` does for the reference's generation
         config, tiny_audio/asr_config.py:103-111): prompt pass, then one token per clip per step until every clip has
         emitted an eos id or ``max_new_tokens`` is reached.  -> int64 [B, n_new] (prompt stripped; finished clips are
@@ -585,7 +585,14 @@ class Qwen3MI355X(torch.nn.Module):
             if min_new > 0 and n_eos:               # HF MinNewTokensLengthLogitsProcessor: no eos before min_new_tokens tokens exist
                 _lib.check(L_.ta_logits_suppress_until(ptr(logits), self.vocab_pad, c.vocab_size, ptr(eos), n_eos, min_new, ptr(step_dev), B,
                                                        stream()), "ta_logits_suppress_until")
-            _lib.check(L_.ta_argmax_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, ptr(amax), stream()), "ta_argmax_f32")
+            if sampling is not None:                # do_sample: HF's warpers (temperature, top-k, top-p), then one multinomial draw per clip
+                temp, top_k, top_p, seed = sampling
+                _lib.check(L_.ta_logits_warp(ptr(logits), self.vocab_pad, c.vocab_size, B, float(temp), int(top_k), float(top_p), stream()),
+                           "ta_logits_warp")
+                _lib.check(L_.ta_sample_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step_dev),
+                                            ptr(amax), stream()), "ta_sample_f32")
+            else:
+                _lib.check(L_.ta_argmax_f32(ptr(logits), self.vocab_pad, c.vocab_size, B, ptr(amax), stream()), "ta_argmax_f32")
             _lib.check(L_.ta_greedy_advance(ptr(amax), ptr(eos), n_eos, int(pad_id), ptr(finished), ptr(next_ids), ptr(out_seq),
                                             max_new, ptr(step_dev), ptr(slot_dev), ptr(pos), ptr(kmask), Lmax, B, ptr(alive),
                                             stream()), "ta_greedy_advance")
