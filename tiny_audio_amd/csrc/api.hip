@@ -796,8 +796,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       if (rc == TA_OK) attn_done = true;
       else if (rc != TA_ERR_ARG) return rc;
     }
-    // round 4: Delta = rowsum(dO o O) is computed inside the fused backward from O (TA355_ATTN_DELTA_FUSED=0: the separate pass)
-    static const bool delta_in = [] { const char* e = getenv("TA355_ATTN_DELTA_FUSED"); return !(e && *e == '0'); }();
+    // round 4: Delta = rowsum(dO o O) computed inside the fused backward from O -- OPT-IN (TA355_ATTN_DELTA_FUSED=1).  It removes the
+    // ta_attn_bwd_prep launch (9.5 us) but the O rows each dK / dV workgroup then carries raise the tiled kernel's spill from 20 to
+    // 100 bytes per lane: 87.3 us against 67.2 + 9.5, 40.8 against 40.4 ms per step (profiles/r04_zj_ab_delta_fused_lean.txt).  The
+    // first A/B of this change (r04_k) toggled the path inside ONE binary whose kernel already carried the extra registers on both
+    // sides and so reported a gain: an environment A/B is only valid when the code it toggles is compiled separately (the Delta-in
+    // form is a template parameter since).
+    static const bool delta_in = [] { const char* e = getenv("TA355_ATTN_DELTA_FUSED"); return e && *e == '1'; }();
     const bool fused_path = fuse_post && !(g && (g->dqn || g->dkn));
     if (!attn_done && !(fused_path && delta_in)) RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     if (attn_done) {

@@ -900,7 +900,7 @@ __device__ __forceinline__ void qkv_post_bwd_tile(const char* st, const QkvPostB
 
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
 __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT,
                                                  const bf16_t* __restrict__ dO, long dO_stride,
@@ -932,7 +932,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
   // round 4: Delta = rowsum(dO o O) computed HERE when O is given (token-major with dO's row stride) -- the lane's own dO fragments
   // times the same elements of O, summed over the four lanes of the row -- instead of read from the array ta_attn_bwd_prep wrote
   float delta;
-  if (Otok) {
+  if constexpr (DIN) {
     const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD;
     float part = 0.f;
 #pragma unroll
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
 // ============================================================================ backward: dK, dV
 // grid (key tiles, Hkv, B); loops over the Hq/Hkv query heads of the group and over query tiles.
 //   dV^T[d,key] += dO^T[d,q] P[q,key]      dK^T[d,key] += Q^T[d,q] dS[q,key]
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
 __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
                                                   const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                   const bf16_t* __restrict__ dO, long dO_stride,
@@ -1068,7 +1068,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   static_assert(HD == 128, "the DMA staging of the backward is written for head_dim 128");
   const unsigned lds0 = lds_addr_of(smem);
   float pl = 1.0e30f, pd = 0.f;
-  uint4 po[4];                                         // (Otok) this thread's quarter of an O row: 32 of its 128 elements, raw
+  [[maybe_unused]] uint4 po[DIN ? 4 : 1];              // (DIN) this thread's quarter of an O row: 32 of its 128 elements, raw
   int it = 0;
   auto issue = [&](int hh, int qt, int buf) {
     const int h = hk * grp + hh, q0 = qt * 64;
@@ -1080,9 +1080,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
     pl = 1.0e30f; pd = 0.f;
     if (tid < 64 && q0 + tid < L) {
       pl = LSE[(long)(b * Hq + h) * L + q0 + tid];
-      if (!Otok) pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
+      if constexpr (!DIN) pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
     }
-    if (Otok) {                                        // four threads per query row (tid >> 2), 32 elements each
+    if constexpr (DIN) {                               // four threads per query row (tid >> 2), 32 elements each
       const int qr = min(q0 + (tid >> 2), L - 1);
       const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD + (tid & 3) * 32;
 #pragma unroll
@@ -1097,10 +1097,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       char* dOs = Qs + RowTile<HD>::BYTES;
       float* Ls = (float*)(dOs + RowTile<HD>::BYTES);  // [64] lse * log2e
       float* Ds = Ls + 64;                             // [64] delta
-      if (tid < 64) { Ls[tid] = pl * LOG2E; if (!Otok) Ds[tid] = pd; }
+      if (tid < 64) { Ls[tid] = pl * LOG2E; if constexpr (!DIN) Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (Otok) {                                      // Delta of the tile's 64 queries from the dO tile that has just landed
+      if constexpr (DIN) {                             // Delta of the tile's 64 queries from the dO tile that has just landed
         const int row = tid >> 2, quarter = tid & 3;
         float part = 0.f;
 #pragma unroll
@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
 // One launch for both halves of the backward: blocks [0, n_dkv) run the dK / dV body, the rest the dQ body.  The two
 // are independent (both only read Q, K, V, dO), so a single grid lets the dQ workgroups fill the CUs while the longer
 // dK / dV ones drain, without a second stream or a kernel boundary in between.  The heavier dK / dV blocks go first.
-template <int HD, bool CAUSAL>
+template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
                                                        const bf16_t* __restrict__ K, const bf16_t* __restrict__ KT,
                                                        const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, long dO_stride,
@@ -1208,15 +1208,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
     if (!decode_group(blockIdx.x, gsz, B * Hkv, group, member)) return;
     const int xcd = group & 7, j = group >> 3;
     if (member < nq)
-      attn_bwd_dkv_body<HD, CAUSAL>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
+      attn_bwd_dkv_body<HD, CAUSAL, DIN>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
     else
-      attn_bwd_dq_body<HD, CAUSAL>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
+      attn_bwd_dq_body<HD, CAUSAL, DIN>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
     return;
   }
   if ((int)blockIdx.x < n_dkv)
-    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
+    attn_bwd_dkv_body<HD, CAUSAL, DIN>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
   else
-    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
+    attn_bwd_dq_body<HD, CAUSAL, DIN>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
 }
 
 
@@ -1619,6 +1619,8 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     attr_done = true;
   }
   const int n_dq = grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv), n_dkv = grouped_grid(ta_cdiv(L, 64), B * Hkv);
@@ -1631,9 +1633,16 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   const int n_dkv_arg = interleaved ? -1 : n_dkv;
   const bf16_t* nul = nullptr;
 #define BWD(C_, GRID_, NDKV_)                                                                                                       \
-  TA_LAUNCH((attn_bwd_kernel<HD, C_>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V,      \
-            (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F,   \
-            (const bf16_t*)Otok)
+  do {                                                                                                                              \
+    if (Otok)                                                                                                                       \
+      TA_LAUNCH((attn_bwd_kernel<HD, C_, true>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V, \
+                (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F, \
+                (const bf16_t*)Otok);                                                                                               \
+    else                                                                                                                            \
+      TA_LAUNCH((attn_bwd_kernel<HD, C_, false>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V, \
+                (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F, \
+                (const bf16_t*)nullptr);                                                                                            \
+  } while (0)
   if (split) {                                       // the same bodies as two launches: n_dkv = 0 (all dQ) resp. n_dkv = grid (all dK / dV)
     if (causal) { BWD(true, dim3(n_dq), 0); BWD(true, dim3(n_dkv), n_dkv); }
     else { BWD(false, dim3(n_dq), 0); BWD(false, dim3(n_dkv), n_dkv); }
