@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-logits-full", action="store_true", help="skip the two extra timed legs: materialised outputs.logits, and inputs fed from pinned host memory")
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: all-reduce synchronously on the compute stream")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: per-step GPU times of the timed region (events) in the line")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT a GPU: tiny model on the CPU, every kernel launch a marshalling-only stub, gloo instead "
                          "of RCCL.  Exercises the N > 1 control flow of this script (tests/test_host_logic.py); its numbers mean nothing")
@@ -291,14 +292,29 @@ def run(a):
         for _ in range(n_warm):
             step(**kw)
         trainer.flush()
+        # Python's cyclic collector: a generation-2 pass over the ~10^5 objects of the two frozen models takes 15-55 ms, and the garbage
+        # of model construction trips its threshold a few steps into the run -- one 56-98 ms step in an 8-step window (measured on the
+        # MoE configuration, profiles/r04_zl_moe_step_times_gc.txt: 43.5-47.1 ms per step with it, 42.5 without).  Collect now and move
+        # what exists to the permanent generation, as training scripts do after building the model: the timed steps then measure the
+        # steady state (in a long run such a pass amortises to < 0.1 %).
+        import gc
+        gc.collect()
+        gc.freeze()
         trainer.allreduce_exposed_ms()                            # reset the event list
         barrier()
+        evs = []
         t0 = time.perf_counter()
         for _ in range(n_steps):
+            if a.step_times and dev.type == "cuda":
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(); evs.append(e0)
             step(**kw)
         trainer.flush()                                           # every optimizer update of the K steps is inside the timed region
+        if evs:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record(); evs.append(e1)
         barrier()
         dt = time.perf_counter() - t0
+        if evs:
+            step_ms[:] = [round(evs[i].elapsed_time(evs[i + 1]), 3) for i in range(len(evs) - 1)]
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -306,7 +322,12 @@ def run(a):
         return dt
 
     full = a.logits == "full"
+    step_ms = []
+    dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0) if (a.step_times and dev.type == "cuda") else 0
     dt = timed(a.steps, a.warmup, full_logits=full)
+    step_ms_main = list(step_ms)
+    if a.step_times and dev.type == "cuda":
+        step_ms_main.append({"device_allocs_in_run": torch.cuda.memory_stats().get("num_device_alloc", 0) - dev_allocs0})
     ar_ms = trainer.allreduce_exposed_ms() / max(a.steps, 1) if world > 1 else 0.0
     loss = trainer.last_loss()
     ms = dt / a.steps * 1e3
@@ -429,6 +450,7 @@ def run(a):
                           "algorithmic_gflop_per_clip": round(gf, 1),
                           "step_tflops": round(gf * world * B / (ms * 1e-3) / 1e3, 1)},
                "final_loss": round(loss, 4),
+               **({"step_ms": step_ms_main} if a.step_times else {}),
                "rccl_ranks": rccl_ranks,
                "allreduce": None if world == 1 else {
                    "ms_exposed_per_step": round(ar_ms, 4), "elements": trainer.flat.n + trainer.flat.EXTRA,
