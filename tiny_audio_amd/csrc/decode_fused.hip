@@ -5,19 +5,21 @@
 // with past_key_values; driven by tiny_audio/asr_modeling.py:562-646 through HF greedy search).
 //
 // Why: at batch <= 32 every kernel of the step is a dependent link of a chain, and what a link costs is not its bytes but its fixed
-// latency (dispatch, one HBM round trip, the cross-wave reduction, the drain): the round-3 step ran 9 kernels per layer at 4.9-12 us
-// each = 69 us per layer for 57 MB of weights + cache (profiles/r04_o_decode_kernel_stats_before.md), and its linears covered 64-96 of
-// the 256 CUs.  Here
-//   dec_linear_kernel<NORM, bf16>      RMSNorm(x) folded into q|k|v: every workgroup recomputes the 32 row norms (128 KB of L2 reads)
+// latency (dispatch, one DRAM round trip, the cross-wave reduction, the drain: ~5.5 us with 4-12 MB of weights behind it): the round-3
+// step ran 9 kernels per layer at 4.9-12 us each = 69 us per layer for 57 MB of weights + cache rows
+// (profiles/r04_o_decode_kernel_stats_before.md), and its linears covered 64-96 of the 256 CUs.  Here
+//   dec_linear_kernel<NORM, bf16>      RMSNorm(x) folded into q|k|v: every workgroup recomputes the 32 row norms (32 columns each)
 //   dec_attn_kernel                    per-head q/k RMSNorm + RoPE + cache append + attention, one workgroup per (clip, kv head):
-//                                      K and V rows are read ONCE for the q heads of the group
-//   dec_linear_kernel<PLAIN, f32+res>  o_proj + residual, 4 output columns per workgroup (N = 1024 -> 256 workgroups)
-//   dec_linear_kernel<NORM, SwiGLU>    RMSNorm(x1) + gate|up + SiLU(gate) * up: a workgroup owns 8 gate rows and the 8 up rows
+//                                      K and V rows are read ONCE for the q heads of the group, both streams requested up front
+//   dec_linear_kernel<PLAIN, f32+res>  o_proj + residual, 8 output columns per workgroup
+//   dec_linear_kernel<NORM, SwiGLU>    RMSNorm(x1) + gate|up + SiLU(gate) * up: a workgroup owns 16 gate rows and the same 16 up rows
 //   dec_linear_kernel<PLAIN, f32+res>  down_proj + residual
-// Every workgroup is 8 waves that split K (wave w takes k-steps w, w + 8, ...), MFMA fragments come straight from global memory
-// (both operands are K-major), all loads of a workgroup are in flight before its first MFMA, weights are read with the
+// Every linear workgroup is 8 waves that split K (wave w takes k-steps w, w + 8, ...), MFMA fragments come straight from global
+// memory (both operands are K-major), all loads of a workgroup are in flight before its first MFMA, weights are read with the
 // non-temporal policy (each byte is used once per token), and the partial sums meet in LDS in a fixed order: results do not
-// depend on the launch geometry or on timing.
+// depend on the launch geometry or on timing.  The activations of the step live in a BLOCKED layout (blk_off below), and every
+// kernel carries extra workgroups that touch what the NEXT kernel will stream (DecPf below): DESIGN.md section 3, "Greedy decoding",
+// has the measurements behind both (scripts/probe/dec_probe.hip).
 #include <cstdlib>
 #include "host_util.h"
 #include "internal.h"
