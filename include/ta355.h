@@ -144,6 +144,12 @@ typedef struct {
   const float* const* b2;    /* [D] */
 } ta_moe_weights;
 
+/* bf16 images of all n = E + 1 adapters (routed experts, then the shared one) in two launches: f32 masters w1[i] [H, In], w2[i] [D, H],
+ * b1[i] [H], b2[i] [D] (host arrays of device pointers) -> stacked W1a [n, H, In], W1ta [n, In, H], W2a [n, D, H], W2ta [n, H, D]
+ * (bf16) and B1a [n, H], B2a [n, D] (f32): what ta_moe_weights points into (tiny_audio/projectors.py:257-283 keeps one nn.Linear
+ * pair per expert). */
+int ta_moe_pack_images(const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2, int n, int H, int In,
+                       int D, void* W1a, void* W1ta, void* W2a, void* W2ta, float* B1a, float* B2a, hipStream_t st);
 long ta_moe_tape_bytes(const ta_moe_weights* w, int B, int S);
 long ta_moe_bwd_workspace_bytes(const ta_moe_weights* w, int B, int S);
 /* noise: [T, E] jitter factors (train mode; the reference draws U(1-0.01, 1+0.01)) or NULL; aux: device scalar out. */

@@ -458,6 +458,71 @@ inline bool grouped_enabled() {
 }
 }  // namespace
 
+// ---- bf16 images of all E + 1 adapters in TWO launches (round 4; they were 20 cast / transpose launches + 10 bias copies per step):
+// W1 [H, In] and W2 [D, H] f32 masters of every adapter -> the stacked row-major images W1a [n, H, In], W2a [n, D, H] and their
+// transposes W1ta [n, In, H], W2ta [n, H, D]; biases -> B1a [n, H], B2a [n, D].  64 x 64 tiles through LDS (both images of a tile are
+// written with 16-byte / 8-byte rows).  The master pointers travel by value in the kernel arguments (n <= MOE_MAX_E + 1).
+struct MoePackArgs {
+  const float* w1[MOE_MAX_E + 1]; const float* w2[MOE_MAX_E + 1]; const float* b1[MOE_MAX_E + 1]; const float* b2[MOE_MAX_E + 1];
+  bf16_t *W1a, *W1ta, *W2a, *W2ta; float *B1a, *B2a; int n, H, In, D;
+};
+__global__ __launch_bounds__(256) void moe_pack_w_kernel(MoePackArgs a) {
+  __shared__ float tile[64][65];
+  const int which = blockIdx.y, ad = blockIdx.z;
+  const int R = which == 0 ? a.H : a.D, Cn = which == 0 ? a.In : a.H;      // master [R, Cn]
+  const int tcols = (Cn + 63) / 64, trows = (R + 63) / 64;
+  if ((int)blockIdx.x >= tcols * trows) return;
+  const int r0 = (blockIdx.x / tcols) * 64, c0 = (blockIdx.x % tcols) * 64;
+  const float* src = which == 0 ? a.w1[ad] : a.w2[ad];
+  bf16_t* rm = (which == 0 ? a.W1a : a.W2a) + (long)ad * R * Cn;
+  bf16_t* tr = (which == 0 ? a.W1ta : a.W2ta) + (long)ad * R * Cn;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 16; e += 256) {                       // 64 rows x 16 float4
+    const int r = e >> 4, c4 = (e & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < R && c0 + c4 + 3 < Cn) v = *(const float4*)(src + (long)(r0 + r) * Cn + c0 + c4);
+    else if (r0 + r < R) { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (c0 + c4 + j < Cn) t[j] = src[(long)(r0 + r) * Cn + c0 + c4 + j]; v = make_float4(t[0], t[1], t[2], t[3]); }
+    tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    if (r0 + r < R) {
+      if (c0 + c4 + 3 < Cn) { uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w); *(uint2*)(rm + (long)(r0 + r) * Cn + c0 + c4) = o; }
+      else { const float t[4] = {v.x, v.y, v.z, v.w}; for (int j = 0; j < 4; ++j) if (c0 + c4 + j < Cn) rm[(long)(r0 + r) * Cn + c0 + c4 + j] = f2bf(t[j]); }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 16; e += 256) {                       // transposed: 64 rows (source columns) x 16 groups of 4 source rows
+    const int c = e >> 4, r4 = (e & 15) * 4;
+    if (c0 + c >= Cn) continue;
+    if (r0 + r4 + 3 < R) { uint2 o; o.x = pack2bf(tile[r4][c], tile[r4 + 1][c]); o.y = pack2bf(tile[r4 + 2][c], tile[r4 + 3][c]); *(uint2*)(tr + (long)(c0 + c) * R + r0 + r4) = o; }
+    else for (int j = 0; j < 4; ++j) if (r0 + r4 + j < R) tr[(long)(c0 + c) * R + r0 + r4 + j] = f2bf(tile[r4 + j][c]);
+  }
+}
+__global__ __launch_bounds__(256) void moe_pack_b_kernel(MoePackArgs a) {
+  const int which = blockIdx.y, ad = blockIdx.z, n = which == 0 ? a.H : a.D;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  (which == 0 ? a.B1a : a.B2a)[(long)ad * n + i] = (which == 0 ? a.b1[ad] : a.b2[ad])[i];
+}
+extern "C" int ta_moe_pack_images(const float* const* w1, const float* const* b1, const float* const* w2, const float* const* b2, int n,
+                                  int H, int In, int D, void* W1a, void* W1ta, void* W2a, void* W2ta, float* B1a, float* B2a,
+                                  hipStream_t st) {
+  if (n <= 0) return TA_OK;
+  if (n > MOE_MAX_E + 1 || !w1 || !b1 || !w2 || !b2 || !W1a || !W1ta || !W2a || !W2ta || !B1a || !B2a || H <= 0 || In <= 0 || D <= 0 ||
+      (H % 4) || (In % 4) || (D % 4))
+    return TA_ERR_ARG;
+  MoePackArgs a;
+  for (int i = 0; i < n; ++i) { a.w1[i] = w1[i]; a.w2[i] = w2[i]; a.b1[i] = b1[i]; a.b2[i] = b2[i]; if (!w1[i] || !w2[i] || !b1[i] || !b2[i]) return TA_ERR_ARG; }
+  a.W1a = (bf16_t*)W1a; a.W1ta = (bf16_t*)W1ta; a.W2a = (bf16_t*)W2a; a.W2ta = (bf16_t*)W2ta; a.B1a = B1a; a.B2a = B2a;
+  a.n = n; a.H = H; a.In = In; a.D = D;
+  const int t1 = ta_cdiv(H, 64) * ta_cdiv(In, 64), t2 = ta_cdiv(D, 64) * ta_cdiv(H, 64);
+  TA_LAUNCH(moe_pack_w_kernel, dim3(t1 > t2 ? t1 : t2, 2, n), dim3(256), 0, st, a);
+  TA_LAUNCH(moe_pack_b_kernel, dim3(ta_cdiv(H > D ? H : D, 256), 2, n), dim3(256), 0, st, a);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+namespace {
+}  // namespace (re-opened so that the closing brace below keeps its meaning)
+
 extern "C" long ta_moe_tape_bytes(const ta_moe_weights* w, int B, int S) { return (long)moe_tape(w, B, S, nullptr).bytes; }
 extern "C" long ta_moe_bwd_workspace_bytes(const ta_moe_weights* w, int B, int S) { return (long)moe_ws(w, B, S, nullptr).bytes; }
 

@@ -112,6 +112,8 @@ class MoEAudioProjector(nn.Module):
         self.shared_expert = SimpleAdapter(in_dim, self.hidden_dim, config.llm_dim)
         self._init_weights()
         self.last_aux_loss = torch.tensor(0.0)
+        self._aux_shadow = None          # ASRTrainer (more than one rank / gradient accumulation): shadow gradient segments of the aux share
+        self._grad_direct = None         # ASRTrainer (one micro-batch per step): the flat-buffer segments the backward writes straight into
         self._pack = None
         self._pack_versions = None
 
@@ -152,13 +154,16 @@ class MoEAudioProjector(nn.Module):
             W1a, W1ta = torch.empty((E + 1, H, In), device=dev, dtype=BF16), torch.empty((E + 1, In, H), device=dev, dtype=BF16)
             W2a, W2ta = torch.empty((E + 1, D, H), device=dev, dtype=BF16), torch.empty((E + 1, H, D), device=dev, dtype=BF16)
             B1a, B2a = torch.empty((E + 1, H), device=dev, dtype=F32), torch.empty((E + 1, D), device=dev, dtype=F32)
-            w1, w1t, b1, w2, w2t, b2 = [], [], [], [], [], []
-            for i, a in enumerate(list(self.experts) + [self.shared_expert]):
-                W1, W2 = f32(a.fc1.weight), f32(a.fc2.weight)
-                w1.append(cast_bf16(W1, out=W1a[i])); w1t.append(transpose_to_bf16(W1, out=W1ta[i]))
-                w2.append(cast_bf16(W2, out=W2a[i])); w2t.append(transpose_to_bf16(W2, out=W2ta[i]))
-                B1a[i].copy_(a.fc1.bias.detach()); B2a[i].copy_(a.fc2.bias.detach())
-                b1.append(B1a[i]); b2.append(B2a[i])
+            adapters = list(self.experts) + [self.shared_expert]
+            m_w1, m_b1 = [f32(a.fc1.weight) for a in adapters], [f32(a.fc1.bias) for a in adapters]
+            m_w2, m_b2 = [f32(a.fc2.weight) for a in adapters], [f32(a.fc2.bias) for a in adapters]
+            parr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
+            # every image of every adapter in two launches (ta_moe_pack_images; rounds 1-3: 20 cast / transpose launches + 10 bias copies)
+            _lib.check(_lib.lib().ta_moe_pack_images(parr(m_w1), parr(m_b1), parr(m_w2), parr(m_b2), E + 1, H, In, D, ptr(W1a), ptr(W1ta),
+                                                     ptr(W2a), ptr(W2ta), ptr(B1a), ptr(B2a), stream()), "ta_moe_pack_images")
+            w1, w1t, b1 = list(W1a.unbind(0)), list(W1ta.unbind(0)), list(B1a.unbind(0))
+            w2, w2t, b2 = list(W2a.unbind(0)), list(W2ta.unbind(0)), list(B2a.unbind(0))
+            keep_m = [m_w1, m_b1, m_w2, m_b2]
             arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
             arrays = [arr(w1), arr(w1t), arr(b1), arr(w2), arr(w2t), arr(b2)]
             wts = _lib.MoeWeights(enc_dim=self.encoder_dim, k=self.k, hidden=self.hidden_dim, llm_dim=self.llm_dim,
@@ -166,7 +171,7 @@ class MoEAudioProjector(nn.Module):
                                   norm_w=norm_w.data_ptr(), router_w=router_w.data_ptr())
             for name, a in zip(("w1", "w1_t", "b1", "w2", "w2_t", "b2"), arrays):
                 setattr(wts, name, C.cast(a, C.POINTER(C.c_void_p)))
-            keep = [norm_w, router_w, w1, w1t, b1, w2, w2t, b2, arrays]
+            keep = [norm_w, router_w, w1, w1t, b1, w2, w2t, b2, arrays, W1a, W1ta, W2a, W2ta, B1a, B2a, keep_m]
             self._pack = (wts, keep)
             self._pack_versions = versions
         return self._pack[0]

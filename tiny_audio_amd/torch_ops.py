@@ -284,6 +284,24 @@ def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
     if dy is None:
         dy = torch.zeros((xb.shape[0], module_of(ctx.handle).get_output_length(xb.shape[1]), module_of(ctx.handle).llm_dim),
                          device=xb.device, dtype=F32)
+    direct = getattr(ctx.module, "_grad_direct", None)
+    if direct is not None and ctx.training:
+        # ASRTrainer, one micro-batch per optimizer step: the library writes every gradient straight into its segment of the trainer's flat
+        # buffer (the .grad views) -- no 22 temporaries, no 22 autograd accumulation launches.  The routed experts' segments sit at a
+        # constant stride there as well (fc1.weight, fc1.bias, fc2.weight, fc2.bias per expert), so the grouped launches still apply.
+        mod, L_ = ctx.module, _lib.lib()
+        B, S, _ = xb.shape
+        wts = mod._packed_weights()
+        E = mod.num_experts
+        g_norm, g_router = direct[0], direct[1]
+        gW1, gb1, gW2, gb2 = ([direct[2 + 4 * i + j] for i in range(E + 1)] for j in range(4))
+        arr = lambda ts: (C.c_void_p * (E + 1))(*[t.data_ptr() for t in ts])
+        ws = torch.empty(L_.ta_moe_bwd_workspace_bytes(C.byref(wts), B, S), device=xb.device, dtype=torch.uint8)
+        da = d_aux.to(device=xb.device, dtype=F32).reshape(1).contiguous()
+        _lib.check(L_.ta_moe_projector_backward_dev(C.byref(wts), ptr(xb), B, S, ptr(dy.to(F32).contiguous()), ptr(da), ptr(noise), int(ctx.training),
+                                                    ptr(tape), ptr(g_norm), ptr(g_router), arr(gW1), arr(gb1), arr(gW2), arr(gb2),
+                                                    ptr(ws), ws.numel(), stream()), "ta_moe_projector_backward_dev")
+        return None, None, [None] * ctx.n_params, None, None
     g_norm, g_router, GW1, Gb1, GW2, Gb2 = torch.ops.ta355.moe_projector_backward(dy, d_aux, xb, noise, tape, ctx.handle,
                                                                                    ctx.training)
     shadow = getattr(ctx.module, "_aux_shadow", None)         # (ASRTrainer: the auxiliary-loss share of the two router-path gradients)
