@@ -493,9 +493,14 @@ __device__ __forceinline__ float block_max_1024(float v, float* red) {
   for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
   return t;
 }
+// WCAP: survivors of the top-k cut that fit the LDS candidate list (the bisection narrows the row to <= WCAP candidates with
+// full-row counting passes, then finishes on the list: ~12 + 2 passes over the 600 KB row instead of 64)
+#define WCAP 4096
 __global__ __launch_bounds__(1024) void logits_warp_kernel(float* __restrict__ logits, long ld, int V, float temperature, int top_k,
                                                            float top_p) {
   __shared__ float red[17];
+  __shared__ float cand[WCAP];
+  __shared__ int ncand;
   float* row = logits + (long)blockIdx.x * ld;
   const int tid = threadIdx.x;
   float mx = -INFINITY, mn = INFINITY;
@@ -507,36 +512,61 @@ __global__ __launch_bounds__(1024) void logits_warp_kernel(float* __restrict__ l
   mx = block_max_1024(mx, red);
   mn = -block_max_1024(-mn, red);
   if (!(mx > -INFINITY)) return;                                  // an all -inf row: nothing to do
+  bool listed = false;                                            // the survivors of the top-k cut are in cand[0, ncand)
   if (top_k > 0 && top_k < V) {
-    // the k-th largest value: the largest ordered integer o with count(x >= o) >= k
+    // the k-th largest value = the largest ordered integer o with count(x >= o) >= k.  Full-row passes until the candidates fit the list
     long lo = w_f2ord(mn), hi = w_f2ord(mx);
-    while (lo < hi) {
+    float c_lo = (float)V;                                        // count(x >= lo) (an upper bound before the first pass)
+    while (lo < hi && (c_lo > (float)WCAP || top_k > WCAP)) {
       const long mid = lo + (hi - lo + 1) / 2;
       float c = 0.f;
-      for (int j = tid; j < V; j += 1024) c += (w_f2ord(row[j]) >= mid && row[j] > -INFINITY) ? 1.f : 0.f;
+      for (int j = tid; j < V; j += 1024) { const float v = row[j]; c += (v > -INFINITY && w_f2ord(v) >= mid) ? 1.f : 0.f; }
       c = block_sum_1024(c, red);
-      if (c >= (float)top_k) lo = mid; else hi = mid - 1;
+      if (c >= (float)top_k) { lo = mid; c_lo = c; } else hi = mid - 1;
+    }
+    if (lo < hi) {                                                // <= WCAP values >= lo: list them, finish on the list
+      if (tid == 0) ncand = 0;
+      __syncthreads();
+      for (int j = tid; j < V; j += 1024) { const float v = row[j]; if (v > -INFINITY && w_f2ord(v) >= lo) { const int q = atomicAdd(&ncand, 1); if (q < WCAP) cand[q] = v; } }
+      __syncthreads();
+      const int nc = ncand < WCAP ? ncand : WCAP;
+      while (lo < hi) {
+        const long mid = lo + (hi - lo + 1) / 2;
+        float c = 0.f;
+        for (int q = tid; q < nc; q += 1024) c += w_f2ord(cand[q]) >= mid ? 1.f : 0.f;
+        c = block_sum_1024(c, red);
+        if (c >= (float)top_k) lo = mid; else hi = mid - 1;
+      }
+      listed = true;
     }
     __syncthreads();
     for (int j = tid; j < V; j += 1024) if (w_f2ord(row[j]) < lo) row[j] = -INFINITY;
+    if (listed) {                                                 // keep only the survivors in the list (values; order is irrelevant)
+      const int nc = ncand < WCAP ? ncand : WCAP;
+      for (int q = tid; q < nc; q += 1024) if (w_f2ord(cand[q]) < lo) cand[q] = -INFINITY;
+    }
     __syncthreads();
     mn = INFINITY;
-    for (int j = tid; j < V; j += 1024) { const float v = row[j]; if (v > -INFINITY) mn = fminf(mn, v); }
+    if (listed) { const int nc = ncand < WCAP ? ncand : WCAP; for (int q = tid; q < nc; q += 1024) { const float v = cand[q]; if (v > -INFINITY) mn = fminf(mn, v); } }
+    else for (int j = tid; j < V; j += 1024) { const float v = row[j]; if (v > -INFINITY) mn = fminf(mn, v); }
     mn = -block_max_1024(-mn, red);
   }
   if (top_p < 1.0f) {
-    float z = 0.f;
-    for (int j = tid; j < V; j += 1024) z += __expf(row[j] - mx);
-    z = block_sum_1024(z, red);
+    // mass over the surviving scores: from the list when there is one, else over the row
+    const int nc = listed ? (ncand < WCAP ? ncand : WCAP) : 0;
+    auto mass_le = [&](long bound, bool all) {
+      float m = 0.f;
+      if (listed) { for (int q = tid; q < nc; q += 1024) { const float v = cand[q]; m += (v > -INFINITY && (all || w_f2ord(v) <= bound)) ? __expf(v - mx) : 0.f; } }
+      else for (int j = tid; j < V; j += 1024) { const float v = row[j]; m += (v > -INFINITY && (all || w_f2ord(v) <= bound)) ? __expf(v - mx) : 0.f; }
+      return block_sum_1024(m, red);
+    };
+    const float z = mass_le(0, true);
     // smallest ordered integer o with mass(x <= o) > 1 - top_p: everything below it is removed (the maximum has mass 1: always kept)
     const float cut = (1.0f - top_p) * z;
     long lo = w_f2ord(mn), hi = w_f2ord(mx);
     while (lo < hi) {
       const long mid = lo + (hi - lo) / 2;
-      float m = 0.f;
-      for (int j = tid; j < V; j += 1024) { const float v = row[j]; m += (v > -INFINITY && w_f2ord(v) <= mid) ? __expf(v - mx) : 0.f; }
-      m = block_sum_1024(m, red);
-      if (m > cut) hi = mid; else lo = mid + 1;
+      if (mass_le(mid, false) > cut) hi = mid; else lo = mid + 1;
     }
     __syncthreads();
     for (int j = tid; j < V; j += 1024) if (w_f2ord(row[j]) < hi) row[j] = -INFINITY;
