@@ -27,6 +27,21 @@ typedef struct ihipStream_t* hipStream_t;
 int ta_version(void); /* ABI version, currently 2 (round 3: ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa, ta_attention_enc_fwd,
                           ta_logmel_f32's scratch contract) */
 
+/* ---- storage dtype of the residual streams (round 5; the numerics contract of DESIGN.md section 6).  Process-wide.
+ * The reference runs its frozen models either as bf16 MODULES (ASRConfig default model_dtype="bfloat16",
+ * tiny_audio/asr_config.py:41: every residual add / norm input is bf16) or -- the training recipe of BASELINE configs[1] -- as
+ * fp32 modules under bf16 autocast (configs/config.yaml:14-18 + configs/training/production.yaml:49; loaders
+ * tiny_audio/asr_modeling.py:203-254: residual stream, norm in/out and embeddings stay fp32, only Linear / attention run in bf16).
+ * 0 = bf16 storage (the first regime), 1 = fp32 storage (the second); a negative argument leaves that stream unchanged.
+ * MFMA operand (bf16) and accumulator (fp32) types are the same in both; norms / softmax / CE arithmetic is fp32 in both.
+ *   enc_res_f32: encoder residual stream;  lm_res_f32: LM forward residual stream and its tape;  lm_dx_f32: LM backward d(x)
+ *   stream (bf16 only together with a bf16 forward stream).
+ * Initial values: environment TA355_ENC_RES_F32 / TA355_LM_RES_F32 / TA355_LM_DX_F32 (read once), else 0 / 0 / 0.
+ * Change it BETWEEN steps only: a forward's tape must be read back by a backward in the same mode.  Workspace / tape sizes do not
+ * depend on the mode (the fp32 size is always reserved). */
+int ta_set_stream_modes(int enc_res_f32, int lm_res_f32, int lm_dx_f32);
+int ta_get_stream_modes(int* out3 /* host int[3] */);
+
 /* ============================================================================================
  * Composite ops (what a binding would call)
  * ============================================================================================ */

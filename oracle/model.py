@@ -43,7 +43,8 @@ def masked_scatter_rows(inputs_embeds, is_audio, packed):
 
 def asr_forward(batch, W, cfg, keep_cache=True, frame_keep_mask=None, moe_noise=None, training=False,
                 num_items_in_batch=None):
-    """batch: input_ids, attention_mask, labels, input_features, audio_token_counts.
+    """batch: input_ids, attention_mask, labels, input_features, audio_token_counts (+ optional position_ids [B, L] or [L],
+    handed to the LM as tiny_audio/asr_modeling.py:517-526 does).
     W: dict(encoder=..., projector=..., lm=...); cfg: dict(enc=..., lm=...,
     projector_type, k, audio_token_id, hidden..).
     ``frame_keep_mask`` [B, S] is the injected Bernoulli keep mask of
@@ -66,7 +67,7 @@ def asr_forward(batch, W, cfg, keep_cache=True, frame_keep_mask=None, moe_noise=
         counts = is_audio.sum(-1)
     packed = gather_audio_embeds(y, counts)
     x0 = masked_scatter_rows(emb, is_audio, packed)
-    logits, lc = qwen3.lm_forward(x0, batch.get("attention_mask"), W["lm"], cfg["lm"],
+    logits, lc = qwen3.lm_forward(x0, batch.get("attention_mask"), W["lm"], cfg["lm"], position_ids=batch.get("position_ids"),
                                   keep_cache=keep_cache, lora=W.get("lora"), lora_scale=cfg.get("lora_scale", 0.0))
     out = dict(logits=logits, audio_embeds=y, encoder_out=hs, inputs_embeds=x0, aux_loss=aux)
     if batch.get("labels") is not None:

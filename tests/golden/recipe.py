@@ -121,3 +121,49 @@ def fullft_select(name, arr):
     if name in FULLFT_KEEP:
         return arr[FULLFT_KEEP[name]]
     return arr if arr.ndim == 1 else None           # every norm scale is kept whole
+
+
+# ----------------------------------------------------------------------------- the benchmarked shape (round 5: recipe numerics)
+# BASELINE configs[1]: GLM-ASR encoder defaults, Qwen3-0.6B, V = 151 670, MLP projector H = D = 1024 (SURVEY.md section 8 preamble)
+FULL = dict(enc=OW.enc_config(), lm=OW.lm_config(), k=4, proj_hidden=1024,
+            audio_token_id=151669, pad_id=151643, eos_id=151645)
+FULL_L = 192
+FULL_LOGIT_COL_STRIDE = 29          # stored logits columns: 0, 29, 58, ... (5 230 of 151 670)
+FULL_GRAD_STRIDE = {"linear_1.weight": 16, "linear_2.weight": 4, "norm.weight": 1, "norm_2.weight": 1}
+
+
+def full_clip_tokens():
+    """The bench's token stream for ONE clip: 125 audio tokens, L = 192, 36 label positions."""
+    return OW.synthetic_tokens(1, 125, FULL["lm"]["vocab"], FULL["audio_token_id"], FULL["pad_id"], FULL["eos_id"], L=FULL_L)
+
+
+def full_logit_rows(att, lab):
+    """Rows of the [L, V] logits kept in the fixture: every row that predicts a label, plus every 4th attended row."""
+    att, lab = np.asarray(att).ravel(), np.asarray(lab).ravel()
+    pred = np.nonzero(np.concatenate([lab[1:], [-100]]) != -100)[0]
+    rows = sorted(set(pred.tolist()) | set(np.nonzero(att)[0][::4].tolist()))
+    return np.asarray(rows, np.int64)
+
+
+def full_grad_sample(name, g):
+    return np.ascontiguousarray(np.asarray(g).ravel()[::FULL_GRAD_STRIDE[name]])
+
+
+def lm_input_leftpad(B=2, L=48, pad=9, seed=41):
+    """A LEFT-padded ragged batch with explicit position_ids (what trl's DataCollatorForChatML hands the model):
+    clip 1 carries ``pad`` masked rows in front; its positions count the attended tokens from 0 (HF's convention:
+    attention_mask.cumsum(-1) - 1, masked rows set to 1).  RoPE is translation invariant, so that alone would give the same
+    answer as arange(L); clip 0 therefore gets NON-uniform positions (a gap of 37 after row 19, as when a cached prefix is
+    skipped), which a forward that ignores position_ids cannot reproduce."""
+    cfg = SMALL["lm"]
+    rng = np.random.RandomState(seed)
+    x = (rng.standard_normal((B, L, cfg["hidden"])) / np.sqrt(cfg["hidden"])).astype(np.float32)
+    att = np.ones((B, L), dtype=np.int64)
+    att[1, :pad] = 0
+    pos = np.cumsum(att, -1) - 1
+    pos[att == 0] = 1
+    pos[0, 20:] += 37
+    lab = np.full((B, L), -100, dtype=np.int64)
+    lab[0, 30:48] = rng.randint(0, 1000, 18)
+    lab[1, 33:48] = rng.randint(0, 1000, 15)
+    return x, att, lab, pos.astype(np.int64)

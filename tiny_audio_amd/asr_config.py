@@ -78,7 +78,7 @@ class ASRConfig:
     model_type = "asr_model"
 
     def __init__(self, audio_model_id: str = "zai-org/GLM-ASR-Nano-2512", text_model_id: str = "Qwen/Qwen3-0.6B",
-                 attn_implementation: str = "ta355", model_dtype: str = "float32",
+                 attn_implementation: str = "ta355", model_dtype: str = "bfloat16",
                  system_prompt: str = "You are a helpful assistant.", encoder_dim: Optional[int] = None,
                  llm_dim: Optional[int] = None, encoder_conv_layers: Optional[list] = None,
                  audio_sample_rate: int = 16000, projector_pool_stride: int = 4, downsample_rate: int = 5,

@@ -162,6 +162,17 @@ class ASRModel(nn.Module):
                 self.audio_token_id = config.audio_token_id = int(tid)
         self.system_prompt = getattr(config, "system_prompt", None)
 
+    def _apply_stream_modes(self):
+        """``config.model_dtype`` decides where the residual streams are STORED, as it does in the reference: "bfloat16" (the
+        reference ASRConfig's default, tiny_audio/asr_config.py:41: bf16 modules) -> bf16 streams; "float32" (the training
+        recipe, configs/config.yaml:14-18 with bf16 autocast) -> fp32 streams.  Compute is bf16 MFMA with fp32 accumulation in
+        both (the reference's ``bf16: true``); the trainable masters are fp32 in both.  ``config.residual_dtype`` overrides."""
+        rd = getattr(self.config, "residual_dtype", None) or getattr(self.config, "model_dtype", "bfloat16")
+        f32 = str(rd).replace("torch.", "") in ("float32", "fp32", "float")
+        if self.__dict__.get("_stream_f32") != f32 or ops.get_stream_modes()["lm_res_f32"] != f32:
+            ops.set_stream_modes(f32, f32, f32)
+            self.__dict__["_stream_f32"] = f32
+
     def _setup_lora(self, config, seed=0):
         """Stage-2 adapters on the LM (tiny_audio/asr_modeling.py:289-301: LoraConfig(r, lora_alpha,
         target_modules, lora_dropout, bias="none", task_type="CAUSAL_LM"))."""
@@ -233,8 +244,16 @@ class ASRModel(nn.Module):
                 audio_attention_mask: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
                 labels: Optional[torch.Tensor] = None, audio_token_counts: Optional[torch.Tensor] = None,
                 num_items_in_batch=None, return_logits: bool = True, frame_keep=None, after_encoder=None,
-                **kwargs):
+                position_ids: Optional[torch.Tensor] = None, past_key_values=None, inputs_embeds=None,
+                use_cache: Optional[bool] = None, cache_position=None, **kwargs):
         """Training/eval forward (tiny_audio/asr_modeling.py:481-533).
+
+        ``position_ids`` [B, L] (or [1, L] / [L], broadcast over the batch): the RoPE position of every token, handed to the LM
+        as the reference does (asr_modeling.py:517-526 -> TF:models/qwen3/modeling_qwen3.py:386-389, default arange(L)).
+        A collator that LEFT-pads (trl's DataCollatorForChatML) must pass the positions it wants: nothing is inferred from the
+        attention mask, exactly as in the reference.  ``inputs_embeds`` / ``past_key_values`` / ``use_cache=True`` /
+        ``cache_position`` belong to HF's incremental-decoding protocol, which this forward does not speak (``generate`` owns
+        the KV cache here): they raise instead of being ignored.
 
         ``num_items_in_batch``: as in HF Trainer -- loss = sum(nll) / num_items_in_batch (default: the number of
         label tokens in this batch, i.e. the mean).  ``return_logits=False`` skips materialising the [B, L, V]
@@ -244,10 +263,24 @@ class ASRModel(nn.Module):
         collator that already knows the label positions on the host avoid one device->host sync.
         """
         dev = self.device_
+        if inputs_embeds is not None or past_key_values is not None or use_cache or cache_position is not None:
+            bad = [n for n, v in (("inputs_embeds", inputs_embeds), ("past_key_values", past_key_values), ("use_cache", use_cache or None),
+                                  ("cache_position", cache_position)) if v is not None]
+            raise NotImplementedError(f"ASRModel.forward on MI355X does not take {', '.join(bad)}: the training / eval forward "
+                                      "runs from input_ids (+ input_features) without a KV cache; use generate() for decoding")
         if input_ids is None:
             raise ValueError("input_ids is required")
+        self._apply_stream_modes()
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         B, L = ids.shape
+        pos = None
+        if position_ids is not None:
+            pos = torch.as_tensor(position_ids).to(device=dev, dtype=torch.int32)
+            if pos.dim() == 1:
+                pos = pos[None, :]
+            if pos.dim() != 2 or pos.shape[1] != L or pos.shape[0] not in (1, B):
+                raise ValueError(f"position_ids must be [B, L] (or [1, L] / [L]); got {tuple(pos.shape)} for input_ids {tuple(ids.shape)}")
+            pos = pos.expand(B, L).contiguous().reshape(-1)
         audio, src_row = None, None
         if input_features is None and after_encoder is not None:
             after_encoder()
@@ -273,7 +306,7 @@ class ASRModel(nn.Module):
             audio = torch.zeros((1, self.config.llm_dim), device=dev, dtype=F32)
         loss, nll, logits = FrozenLMLoss.apply(audio, self.language_model, ids, src_row, kmask, rows, targets, n_lab,
                                                scale, bool(return_logits),
-                                               *(self.language_model.lora_parameters() or self.language_model.ft_parameters()))
+                                               *(self.language_model.lora_parameters() or self.language_model.ft_parameters()), pos=pos)
         V = self.config.text_config.vocab_size
         logits = logits.reshape(B, L, -1)[:, :, :V] if return_logits else None
         aux, loss_ce = None, loss
@@ -319,11 +352,14 @@ class ASRModel(nn.Module):
             raise ValueError("input_features required for generation")
         if audio_attention_mask is None:
             raise ValueError("audio_attention_mask required for generation")
+        self._apply_stream_modes()
         max_new = int(self._generation_setting("max_new_tokens", 128, kw))
         if int(self._generation_setting("num_beams", 1, kw)) != 1:
             raise NotImplementedError("num_beams 1 only (the reference's generation config, asr_config.py:103-111); beam search is not built")
         # do_sample / temperature / top_k / top_p (asr_config.py:78-81; round 4): HF's warpers on the device, one multinomial draw per
-        # clip and step from a Philox stream keyed by ``seed`` (a generate() keyword here; default: torch's initial seed)
+        # clip and step from a Philox stream keyed by ``seed`` (a generate() keyword here).  Without one every call draws a FRESH key
+        # from torch's global generator, so repeated calls on the same audio give different samples and torch.manual_seed() makes a
+        # run reproducible -- the behaviour of HF's sampling, which advances the global RNG
         sampling = None
         if bool(self._generation_setting("do_sample", False, kw)):
             temp = self._generation_setting("temperature", None, kw)
@@ -331,7 +367,7 @@ class ASRModel(nn.Module):
             top_p = self._generation_setting("top_p", None, kw)
             seed = kw.pop("seed", None)
             sampling = (1.0 if temp is None else float(temp), 0 if top_k is None else int(top_k), 1.0 if top_p is None else float(top_p),
-                        int(torch.initial_seed()) if seed is None else int(seed))
+                        int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed))
             if not sampling[0] > 0 or sampling[1] < 0 or not 0 < sampling[2] <= 1:
                 raise ValueError("temperature must be > 0, top_k >= 0, 0 < top_p <= 1")
         else:

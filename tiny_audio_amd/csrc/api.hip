@@ -9,7 +9,38 @@
 extern "C" int ta_version(void) { return 2; }
 
 #include <algorithm>
+#include <atomic>
 #include "host_util.h"
+
+// ============================================================================ residual-stream dtypes (the numerics contract)
+// Process-wide: which dtype the encoder's residual stream, the LM's forward residual stream (+ tape) and the LM's backward d(x)
+// stream are STORED in.  bf16 (default) is what a bf16-module reference keeps (ASRConfig model_dtype="bfloat16"); fp32 is what the
+// training recipe keeps (fp32 modules under bf16 autocast: configs/config.yaml:14-18 + configs/training/production.yaml:49).
+// MFMA operands (bf16) and accumulators (fp32) are the same in both.  Initial values from TA355_ENC_RES_F32 / TA355_LM_RES_F32 /
+// TA355_LM_DX_F32 (read once); ta_set_stream_modes changes them between calls (not while a composite is being enqueued).
+namespace {
+struct StreamModes {
+  std::atomic<int> enc_f32, lm_f32, dx_f32;
+  StreamModes() {
+    auto on = [](const char* n) { const char* v = getenv(n); return (v && *v == '1') ? 1 : 0; };
+    enc_f32 = on("TA355_ENC_RES_F32"); lm_f32 = on("TA355_LM_RES_F32"); dx_f32 = on("TA355_LM_DX_F32");
+  }
+};
+StreamModes& stream_modes() { static StreamModes m; return m; }
+}  // namespace
+extern "C" int ta_set_stream_modes(int enc_res_f32, int lm_res_f32, int lm_dx_f32) {
+  StreamModes& m = stream_modes();
+  if (enc_res_f32 >= 0) m.enc_f32 = enc_res_f32 ? 1 : 0;
+  if (lm_res_f32 >= 0) m.lm_f32 = lm_res_f32 ? 1 : 0;
+  if (lm_dx_f32 >= 0) m.dx_f32 = lm_dx_f32 ? 1 : 0;
+  return TA_OK;
+}
+extern "C" int ta_get_stream_modes(int* out3) {
+  if (!out3) return TA_ERR_ARG;
+  StreamModes& m = stream_modes();
+  out3[0] = m.enc_f32; out3[1] = m.lm_f32; out3[2] = m.dx_f32;
+  return TA_OK;
+}
 
 // ============================================================================ encoder
 namespace {
@@ -65,8 +96,8 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
                      w->conv1_b, nullptr, 1, 1, 1, nullptr, st));
   // Residual stream: bf16, the dtype the reference's encoder runs in (model_dtype bfloat16: every residual add and
   // LayerNorm input is bf16 there).  It halves the bytes of the two residual GEMM epilogues and of the LayerNorm reads
-  // per layer -- HBM time that nothing overlaps.  TA355_ENC_RES_F32=1 keeps an fp32 stream instead.
-  static const bool res_f32 = [] { const char* v = getenv("TA355_ENC_RES_F32"); return v && *v == '1'; }();
+  // per layer -- HBM time that nothing overlaps.  ta_set_stream_modes(1, ., .) / TA355_ENC_RES_F32=1 keeps an fp32 stream instead.
+  const bool res_f32 = stream_modes().enc_f32 != 0;
   const int rb = res_f32 ? 0 : 1;
   auto ln = [&](const float* gw, const float* gb, void* yb, float* yf, const float* rowscale) -> int {
     return rb ? ta_layernorm_bf16(e.xr, gw, gb, yb, yf, rowscale, M, H, w->ln_eps, st)
@@ -238,10 +269,7 @@ namespace {
 // Residual stream of the LM (x_in / x1 of every layer, kept in the tape): bf16, the dtype the reference's LM runs in
 // (model_dtype bfloat16).  Halves the bytes of the o / down GEMM epilogues, of the RMSNorm reads (forward and
 // backward) and of the tape.  TA355_LM_RES_F32=1 keeps fp32 instead.  The gradient stream d(x) stays fp32.
-inline bool lm_res_bf16() {
-  static const bool v = [] { const char* e = getenv("TA355_LM_RES_F32"); return !(e && *e == '1'); }();
-  return v;
-}
+inline bool lm_res_bf16() { return stream_modes().lm_f32 == 0; }
 // side stream of the LoRA backward (see lora_bwd in ta_lm_backward): created once per process, on the device current at first use
 struct LoraSide { hipStream_t s; hipEvent_t fork[2], join[2]; };
 static LoraSide* lora_side() {
@@ -744,8 +772,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   // reference's bf16 model back-propagates bf16 gradients of its bf16 activations; s.dxb then IS the stream (updated in place by
   // every RMSNorm backward) and the two f32 images are written only by the last call, for the f32 consumers below the stack:
   // 50 MB instead of 88 MB per RMSNorm backward
-  static const bool dx_f32_env = [] { const char* e = getenv("TA355_LM_DX_F32"); return e && *e == '1'; }();
-  const bool dx_bf16 = lm_res_bf16() && !dx_f32_env;
+  const bool dx_bf16 = lm_res_bf16() && stream_modes().dx_f32 == 0;
   auto norm_bwd = [&](const float* dy, int dyb, const float* x, const float* r, const float* gw, const float* dres, float* dxf,
                       bool last = false) -> int {
     if (dx_bf16) return ta_rmsnorm_bwd_bf16s(dy, dyb, x, r, gw, dres ? s.dxb : nullptr, last ? dxf : nullptr, s.dxb, M, d.D, st);

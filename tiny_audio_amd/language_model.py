@@ -652,11 +652,11 @@ class FrozenLMLoss:
 
     @staticmethod
     def apply(audio_embeds, lm, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale,
-              want_logits, *trainable):
+              want_logits, *trainable, pos=None):
         from . import torch_ops
         loss, nll, logits, _tape, _ws = torch.ops.ta355.lm_forward_loss(
             audio_embeds, list(trainable), torch_ops.register_module(lm), input_ids, src_row, kmask, label_rows, label_targets,
-            int(n_label_rows), float(loss_scale), bool(want_logits))
+            int(n_label_rows), float(loss_scale), bool(want_logits), pos)
         # a fresh tensor: the outputs of a multi-output custom op may not be modified in place, and HF Trainer does
         # `loss *= ...` on what the model returns (TF:trainer.py compute_loss)
         return loss.clone(), nll, logits

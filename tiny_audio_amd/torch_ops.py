@@ -322,18 +322,20 @@ moe_projector.register_autograd(_moe_bwd, setup_context=_moe_setup)
 @torch.library.custom_op("ta355::lm_forward_loss", mutates_args=())
 def lm_forward_loss(audio: Tensor, trainable: Sequence[Tensor], handle: int, input_ids: Tensor, src_row: Optional[Tensor],
                     kmask: Optional[Tensor], label_rows: Optional[Tensor], label_targets: Optional[Tensor], n_label_rows: int,
-                    loss_scale: float, want_logits: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+                    loss_scale: float, want_logits: bool, pos: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (loss f32 [], per-row nll f32 [max(n, 1)], logits bf16 [B*L, vocab_pad] or empty, tape, workspace).
     ``audio`` f32 [rows, D]: the projector's output rows that replace the <audio> positions (``src_row`` from
-    ta_audio_index); ``trainable``: the LoRA masters or, with a trainable base LM, its fp32 masters (autograd inputs)."""
+    ta_audio_index); ``trainable``: the LoRA masters or, with a trainable base LM, its fp32 masters (autograd inputs);
+    ``pos`` int32 [B*L]: RoPE position of every token row (the reference's ``position_ids``; None = arange(L) per clip)."""
     lm = module_of(handle)
     a = audio.detach().to(F32).contiguous()
-    loss, nll, logits, c = lm.forward_loss(input_ids, src_row, a, kmask, label_rows, label_targets, n_label_rows, loss_scale, want_logits)
+    loss, nll, logits, c = lm.forward_loss(input_ids, src_row, a, kmask, label_rows, label_targets, n_label_rows, loss_scale, want_logits,
+                                           pos=pos)
     return loss.reshape(()), nll, (logits if logits is not None else _empty(a.device)), c["tape"], c["ws"]
 
 
 @lm_forward_loss.register_fake
-def _(audio, trainable, handle, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale, want_logits):
+def _(audio, trainable, handle, input_ids, src_row, kmask, label_rows, label_targets, n_label_rows, loss_scale, want_logits, pos):
     lm = module_of(handle)
     B, L = input_ids.shape
     logits = audio.new_empty((B * L, lm.vocab_pad), dtype=BF16) if want_logits else audio.new_empty((0,))
@@ -346,12 +348,13 @@ def _(audio, trainable, handle, input_ids, src_row, kmask, label_rows, label_tar
 
 @torch.library.custom_op("ta355::lm_backward", mutates_args=())
 def lm_backward(tape: Tensor, ws: Tensor, handle: int, input_ids: Tensor, src_row: Optional[Tensor], kmask: Optional[Tensor],
-                label_rows: Optional[Tensor], n_label_rows: int, n_audio_rows: int, want_d_audio: bool) -> List[Tensor]:
+                label_rows: Optional[Tensor], n_label_rows: int, n_audio_rows: int, want_d_audio: bool,
+                pos: Optional[Tensor]) -> List[Tensor]:
     """loss.backward() through the LM for d(loss) = 1 -> [d_audio f32 [n_audio_rows, D] (or empty), then one gradient per
     tensor of ``trainable`` (empty tensors when the LM accumulates straight into Parameter.grad: ASRTrainer's mode)]."""
     lm = module_of(handle)
     B, L = input_ids.shape
-    ctx = dict(tape=tape, ws=ws, B=B, L=L, src_row=src_row, kmask=kmask, pos=None, label_rows=label_rows,
+    ctx = dict(tape=tape, ws=ws, B=B, L=L, src_row=src_row, kmask=kmask, pos=pos, label_rows=label_rows,
                n_label_rows=n_label_rows, ids=input_ids)
     d_audio, _, lg = lm.backward_from_ctx(ctx, n_audio_rows, want_d_audio=want_d_audio)
     dev = tape.device
@@ -362,7 +365,7 @@ def lm_backward(tape: Tensor, ws: Tensor, handle: int, input_ids: Tensor, src_ro
 
 
 @lm_backward.register_fake
-def _(tape, ws, handle, input_ids, src_row, kmask, label_rows, n_label_rows, n_audio_rows, want_d_audio):
+def _(tape, ws, handle, input_ids, src_row, kmask, label_rows, n_label_rows, n_audio_rows, want_d_audio, pos):
     lm = module_of(handle)
     f = lambda *s: tape.new_empty(s, dtype=F32)
     ps = lm.lora_parameters() or lm.ft_parameters() or []
@@ -370,31 +373,31 @@ def _(tape, ws, handle, input_ids, src_row, kmask, label_rows, n_label_rows, n_a
 
 
 def _lm_setup(ctx, inputs, output):
-    (audio, trainable, handle, input_ids, src_row, kmask, label_rows, _targets, n_label_rows, _scale, _want) = inputs
+    (audio, trainable, handle, input_ids, src_row, kmask, label_rows, _targets, n_label_rows, _scale, _want, pos) = inputs
     ctx.handle, ctx.n_label_rows, ctx.n_audio, ctx.n_train = handle, n_label_rows, audio.shape[0], len(trainable)
     ctx.module = module_of(handle)
     ctx.want_d_audio = audio.requires_grad
     # without this autograd materialises ZERO gradients for the unused outputs on every backward -- the tape alone is
     # 8.9 GB at B = 32 (a 1.35 ms fill per step, measured), the workspace 1.2 GB
     ctx.set_materialize_grads(False)
-    ctx.present = [t is not None for t in (src_row, kmask, label_rows)]
-    ctx.save_for_backward(output[3], output[4], input_ids, *[t for t in (src_row, kmask, label_rows) if t is not None])
+    ctx.present = [t is not None for t in (src_row, kmask, label_rows, pos)]
+    ctx.save_for_backward(output[3], output[4], input_ids, *[t for t in (src_row, kmask, label_rows, pos) if t is not None])
 
 
 def _lm_bwd(ctx, g_loss, _g_nll, _g_logits, _g_tape, _g_ws):
     if g_loss is None:                                        # the loss was not used
-        return (None, [None] * ctx.n_train) + (None,) * 9
+        return (None, [None] * ctx.n_train) + (None,) * 10
     tape, ws, ids, *rest = ctx.saved_tensors
     it = iter(rest)
-    src_row, kmask, label_rows = (next(it) if p else None for p in ctx.present)
+    src_row, kmask, label_rows, pos = (next(it) if p else None for p in ctx.present)
     out = torch.ops.ta355.lm_backward(tape, ws, ctx.handle, ids, src_row, kmask, label_rows, ctx.n_label_rows, ctx.n_audio,
-                                      ctx.want_d_audio)
+                                      ctx.want_d_audio, pos)
     d_audio = out[0] * g_loss if ctx.want_d_audio else None
     # gradients of the trainable LM tensors: scaled by d(loss) -- except in accumulate_into_grad mode, where the kernels
     # have already added them to Parameter.grad (empty placeholders come back) and d(loss) is 1 by ASRTrainer's contract
     tg = [(g * g_loss if g.numel() else None) for g in out[1:]]
     tg += [None] * (ctx.n_train - len(tg))
-    return (d_audio, tg[: ctx.n_train]) + (None,) * 9
+    return (d_audio, tg[: ctx.n_train]) + (None,) * 10
 
 
 lm_forward_loss.register_autograd(_lm_bwd, setup_context=_lm_setup)
