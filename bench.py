@@ -20,7 +20,14 @@ ids) are resident in HBM before the timed region; random-init weights at the tru
 The single JSON line carries `roofline` (dominant kernel = the MFMA GEMM, timed in situ with HIP events on
 its launch stream), `host_inputs` (the same step fed from pinned host memory: the PCIe-inclusive rate, never `value`),
 `logits_full` (the same step with the reference's [B, L, V] logits materialised, timed in the same
-run) and, at N=1, `cpu_baseline` (the numpy oracle timed on the host cores on one clip: median of 3 after a warm-up).
+run), `streams_other` (the same step with the residual streams stored in the OTHER dtype: `--streams`) and, at N=1,
+`cpu_baseline` (the numpy oracle timed on the host cores on one clip: median of 5 passes after 2 warm-ups).
+
+Numerics contract: MFMA operands bf16, accumulation fp32, norms / softmax / CE in fp32 -- the reference's
+`bf16: true`.  `--streams` chooses where the residual streams are STORED: `f32` = what the training recipe keeps (fp32 modules
+under bf16 autocast, configs/config.yaml:14-18 + configs/training/production.yaml:49), `bf16` = what ASRConfig's default
+model_dtype="bfloat16" keeps.  `config.streams` names the mode of `value`; `numerics` carries the reference-measured drift of
+both regimes (tests/golden/asr_full_recipe.npz) that the parity tests gate against.
 """
 import argparse
 import json
@@ -35,6 +42,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+DEFAULT_STREAMS = "bf16"            # see DESIGN.md section 6 ("The numerics contract") for why
 PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (2:1-sparse marketing figure is 5 PF)
 
 
@@ -48,6 +56,10 @@ def parse():
     ap.add_argument("--logits", choices=["labelled", "full"], default="labelled",
                     help="'full' additionally materialises outputs.logits [B, L, V] (bf16) every step as the reference does; "
                          "'labelled' computes the loss head only on label positions (identical loss and gradients)")
+    ap.add_argument("--streams", choices=["bf16", "f32"], default=DEFAULT_STREAMS,
+                    help="storage dtype of the encoder / LM residual streams (ASRConfig.model_dtype): f32 = the training recipe's "
+                         "fp32 modules under bf16 autocast, bf16 = bf16 modules (ASRConfig's default).  The other mode is timed as "
+                         "`streams_other` in the same line")
     ap.add_argument("--dropout", type=float, default=0.10, help="audio_token_dropout (configs/config.yaml:32)")
     ap.add_argument("--projector", choices=["mlp", "moe", "qformer", "mosa"], default="mlp",
                     help="mlp = BASELINE configs[1]/[2]; moe = configs[3] (shared + 4 routed experts, top-2, jitter on)")
@@ -237,7 +249,8 @@ def run(a):
         extra = dict(audio_token_id=999)
         a.proj_hidden, a.batch, a.seq_len, n_samples = 128, min(a.batch, 2), 64, 16000
         a.no_cpu_baseline = a.no_roofline = True
-    cfg = ASRConfig(audio_config=audio, text_config=text, freeze_language_model=not a.full_ft, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
+    mdt = {"bf16": "bfloat16", "f32": "float32"}
+    cfg = ASRConfig(model_dtype=mdt[a.streams], audio_config=audio, text_config=text, freeze_language_model=not a.full_ft, projector_type=a.projector, projector_hidden_dim=a.proj_hidden, audio_token_dropout=a.dropout,
                     use_lora=a.lora, freeze_projector=a.lora, **extra)
     torch.manual_seed(0)                                          # identical frozen + projector weights on every rank
     model = ASRModel(cfg, device=dev, init="random", seed=0)
@@ -364,6 +377,19 @@ def run(a):
                        "note": "additionally writes outputs.logits [B, L, V] bf16 every step, as the reference's forward does"}
         trainer.last_logits = None
 
+    # the same step with the residual streams stored in the OTHER dtype (config.model_dtype is read at every forward)
+    streams_other = None
+    if not a.no_logits_full and not dry:
+        other = "f32" if a.streams == "bf16" else "bf16"
+        cfg.model_dtype = mdt[other]
+        k5 = max(1, a.steps)
+        dt5 = timed(k5, max(2, a.warmup), full_logits=full)
+        streams_other = {"streams": other, "ms_per_step": round(dt5 / k5 * 1e3, 3), "value": round(world * B * 10.0 * k5 / dt5, 1),
+                         "steps": k5, "warmup": max(2, a.warmup), "final_loss": round(trainer.last_loss(), 4),
+                         "note": "encoder / LM residual streams, the LM tape and d(x) stored in %s; same MFMA operand / accumulator types" % other}
+        cfg.model_dtype = mdt[a.streams]
+        step(full_logits=full); trainer.flush()                   # back in the headline's mode for the roofline / parity legs below
+
     # the same step fed from HOST buffers (20.5 MB of f32 waveforms + the token tensors per step over PCIe, pinned, same stream):
     # what the boundary costs when the dataloader hands over host memory.  Never `value`.
     host_inputs = None
@@ -449,7 +475,7 @@ def run(a):
                                       " bf16, GLM-ASR-Nano encoder 32L + Qwen3-%s 28L, "
                                       "10 s / 16 kHz clips, L=%d, %d label tokens/clip" % (a.lm.upper(), L, n_lab // B),
                           "clips_per_gpu": B, "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
-                          "logits": a.logits, "audio_token_dropout": a.dropout,
+                          "logits": a.logits, "streams": a.streams, "audio_token_dropout": a.dropout,
                           "algorithmic_gflop_per_clip": round(gf, 1),
                           "step_tflops": round(gf * world * B / (ms * 1e-3) / 1e3, 1)},
                "final_loss": round(loss, 4),
@@ -462,8 +488,8 @@ def run(a):
                            else "synchronous on the compute stream",
                    "note": "events on the compute stream around the collective (sync) / around the wait for it (async)"},
                "replicas": replicas,
-               "logits_full": logits_full, "host_inputs": host_inputs, "roofline": roofline, "cpu_baseline": cpu,
-               "parity": parity}
+               "logits_full": logits_full, "streams_other": streams_other, "host_inputs": host_inputs, "roofline": roofline,
+               "cpu_baseline": cpu, "parity": parity, "numerics": numerics_contract(a.streams)}
         if replicas is not None:
             replicas["rccl_version"] = "gloo (dry run)" if dry else ".".join(str(x) for x in torch.cuda.nccl.version())
             if rccl_log and os.path.exists(rccl_log):
@@ -475,6 +501,25 @@ def run(a):
             raise RuntimeError(f"data-parallel replicas diverged: {replicas}")
     if world > 1:
         dist.destroy_process_group()
+
+
+def numerics_contract(streams):
+    """What the line's arithmetic is, and how far the REFERENCE's own bf16 regimes sit from its fp32 run at the benchmarked shape
+    (tests/golden/asr_full_recipe.npz, generated by tests/golden/make_golden.py from /root/reference; the parity tests gate the
+    HIP path's distance from the same fp32 run against these: tests/test_gpu_round5.py)."""
+    out = {"mfma_operands": "bf16", "accumulate": "fp32", "norm_softmax_ce": "fp32", "trainable_masters": "fp32",
+           "residual_stream_storage": streams,
+           "mirrors": "fp32 modules + bf16 autocast (configs/config.yaml:14-18, production.yaml:49)" if streams == "f32"
+                      else "bf16 modules (ASRConfig model_dtype default, tiny_audio/asr_config.py:41)"}
+    fx = os.path.join(ROOT, "tests", "golden", "asr_full_recipe.npz")
+    if os.path.exists(fx):
+        g = np.load(fx)
+        for mode in ("autocast", "bf16"):
+            out[f"reference_{mode}_vs_reference_fp32"] = {
+                "logits_maxabs": round(float(g[f"{mode}.logits_maxabs_vs_fp32"]), 4), "logits_rms": round(float(g[f"{mode}.logits_rms_vs_fp32"]), 4),
+                "nll_maxabs": round(float(g[f"{mode}.nll_maxabs_vs_fp32"]), 4),
+                "grad_cos_min": round(min(float(g[k]) for k in g.files if k.startswith(f"{mode}.gcos_vs_fp32.")), 5)}
+    return out
 
 
 def hbm_kernel_rates(B, L, cfg, fe, wav, lens):

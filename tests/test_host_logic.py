@@ -390,6 +390,56 @@ def test_trainer_two_ranks_flat_allreduce(mode):
     assert g0a == g1a == g0b == g1b == 3.0           # SUM over ranks of the stand-in gradients (1 + 2), first and last element
 
 
+def _moe_trainer_ga1_worker(rank, world, port, q):
+    """Two ranks, ONE micro-batch per optimizer step: the projector writes its gradients straight into the flat buffer
+    (_grad_direct) and must STILL fill the auxiliary shadow."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import weights as OW
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.asr_config import ASRConfig
+    from tiny_audio_amd.asr_modeling import ASRModel
+    from tiny_audio_amd.trainer import ASRTrainer, TrainingArguments
+    _lib.DRY_RUN = True
+    enc = OW.enc_config(hidden=256, ffn=512, layers=1, heads=4)
+    lm = OW.lm_config(vocab=1000, hidden=256, ffn=512, layers=2, heads=4, kv_heads=2)
+    cfg = ASRConfig(audio_config=enc, text_config=lm, projector_type="moe", projector_hidden_dim=128, audio_token_id=999)
+    torch.manual_seed(0)
+    m = ASRModel(cfg, device="cpu", init="random")
+    tr = ASRTrainer(m, TrainingArguments(gradient_accumulation_steps=1))
+    f = tr.flat
+    ids, att, lab, counts = OW.synthetic_tokens(2, [12, 12], 1000, 999, 990, 991, n_text=10, n_suffix=4)
+    meta = (torch.zeros(40, dtype=torch.int32), torch.zeros(40, dtype=torch.int64), 22 + rank)
+    batch = dict(input_ids=torch.from_numpy(ids), input_features=torch.zeros(2, 128, 100), attention_mask=torch.from_numpy(att),
+                 labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), label_meta=meta)
+    m.train()
+    _lib.lib().calls.clear()
+    tr.training_step(batch)
+    calls = list(_lib.lib().calls)
+    q.put((rank, tr._aux_direct, m.projector._grad_direct is not None, list(f.shadow_names),
+           calls.count("ta_moe_projector_backward_dev"), calls.count("ta_moe_router_aux_grads")))
+    dist.destroy_process_group()
+
+
+def test_moe_trainer_two_ranks_one_micro_batch_fills_the_shadow():
+    """world > 1 with gradient_accumulation_steps = 1 -- the direct-gradient branch of the MoE backward returned
+    before the shadow fill, so `g += (N - 1) * shadow` added zeros and the optimizer's division by N left aux at weight 1 / N.
+    The branch now calls ta_moe_router_aux_grads into the shadow segment (the values are checked on the GPU:
+    tests/test_gpu_round5.py::test_moe_aux_shadow_values)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moe_trainer_ga1_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in procs])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, aux_direct, grad_direct, shadow_names, n_bwd, n_shadow in res:
+        assert aux_direct is False and grad_direct is True
+        assert shadow_names == ["projector.norm.weight", "projector.router.weight"]
+        assert n_bwd == 1 and n_shadow == 1
+
+
 def _moe_trainer_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

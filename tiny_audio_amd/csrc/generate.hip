@@ -619,7 +619,9 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
   }
   const float total = part[1023];
   const float u = philox_uniform(seed, (unsigned)*step_p, blockIdx.x) * total;
-  const float before = part[tid] - s;
+  // thread t's lower bound IS thread t - 1's upper bound (the same float, read back from the scan): `part[tid] - s` is a different
+  // rounding of it, and then two chunks could both claim u (a race on `pick`) or neither (a biased fall-back) -- ADVICE r4
+  const float before = tid ? part[tid - 1] : 0.f;
   if (s > 0.f && before <= u && (u < part[tid] || tid == 1023)) {
     float c = before; int choice = last;
     for (int j = j0; j < j1; ++j) { const float p = __expf(row[j] - mx); c += p; if (p > 0.f && u < c) { choice = j; break; } }

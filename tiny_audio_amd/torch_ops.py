@@ -301,6 +301,14 @@ def _moe_bwd(ctx, dy, d_aux, _dxb, _dtape):
         _lib.check(L_.ta_moe_projector_backward_dev(C.byref(wts), ptr(xb), B, S, ptr(dy.to(F32).contiguous()), ptr(da), ptr(noise), int(ctx.training),
                                                     ptr(tape), ptr(g_norm), ptr(g_router), arr(gW1), arr(gb1), arr(gW2), arr(gb2),
                                                     ptr(ws), ws.numel(), stream()), "ta_moe_projector_backward_dev")
+        # more than one rank with one micro-batch per step: the gradients go straight to the flat buffer AND the auxiliary share of
+        # the two router-path gradients goes to its shadow segment (this branch used to return before the shadow fill,
+        # which left aux at weight 1 / N on N > 1 ranks)
+        shadow = getattr(ctx.module, "_aux_shadow", None)
+        if shadow is not None:
+            sn, sr = moe_router_aux_grads(d_aux, xb, noise, tape, ctx.handle, ctx.training)
+            shadow["norm.weight"].add_(sn)
+            shadow["router.weight"].add_(sr)
         return None, None, [None] * ctx.n_params, None, None
     g_norm, g_router, GW1, Gb1, GW2, Gb2 = torch.ops.ta355.moe_projector_backward(dy, d_aux, xb, noise, tape, ctx.handle,
                                                                                    ctx.training)

@@ -194,7 +194,7 @@ class _StreamTimer:
 class ASRTrainer:
     def __init__(self, model, args: Optional[TrainingArguments] = None, group=None, decoder_learning_rate: Optional[float] = None,
                  decoder_weight_decay: Optional[float] = None, projector_weight_decay: Optional[float] = None,
-                 overlap_allreduce: bool = False, time_allreduce: bool = False):
+                 overlap_allreduce: bool = False, time_allreduce: bool = False, aux_shadow: Optional[bool] = None):
         """``decoder_*`` / ``projector_weight_decay``: the split parameter groups of scripts/train.py:384-437 -- parameters
         under ``language_model.`` (the LoRA adapters in stage 2) take the decoder LR / weight decay, everything else the
         base LR and the projector weight decay; each falls back to ``args.learning_rate`` / ``args.weight_decay``; norm
@@ -205,7 +205,7 @@ class ASRTrainer:
         that does not read trainable weights -- so the collective runs under ~half a step of compute.  Same arithmetic,
         same order of updates; ``flush()`` applies a still-pending update (end of training, before saving / evaluating).
         ``time_allreduce``: bracket the time the compute stream spends on / waiting for the collective with events
-        (``allreduce_exposed_ms()``)."""
+        (``allreduce_exposed_ms()``).  ``aux_shadow``: see ``_aux_direct`` below."""
         self.model, self.args, self.group = model, args or TrainingArguments(), group
         self.decoder_learning_rate, self.decoder_weight_decay = decoder_learning_rate, decoder_weight_decay
         self.projector_weight_decay = projector_weight_decay
@@ -219,7 +219,8 @@ class ASRTrainer:
         world = 1
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
-        self._aux_direct = world == 1 and int(self.args.gradient_accumulation_steps) == 1
+        # ``aux_shadow=True`` forces the shadow form on one rank too (tests: the N > 1 arithmetic on a 1-GPU box)
+        self._aux_direct = world == 1 and int(self.args.gradient_accumulation_steps) == 1 and not aux_shadow
         self.flat = FlatTrainable(list(model.named_parameters()), shadow_of=() if self._aux_direct else aux_names)
         if hasattr(proj, "_aux_shadow"):
             proj._aux_shadow = None
