@@ -44,7 +44,7 @@ SHAPES = [("enc.qkv rope", 16000, 3840, 1280, "rope"), ("enc.o_proj", 16000, 128
           ("enc.fc2", 16000, 1280, 5120, "bias_res"), ("conv2-like", 16000, 1280, 3840, "gelu"),
           ("lm.qkv", 6144, 4096, 1024, "plain"), ("lm.o", 6144, 1024, 2048, "res"), ("lm.gate|up", 6144, 6144, 1024, "plain"),
           ("lm.down", 6144, 1024, 3072, "res"), ("lm.d(act)", 6144, 3072, 1024, "plain"), ("lm.d(xn) gu", 6144, 1024, 6144, "plain"),
-          ("lm.d(attn-out)", 6144, 2048, 2048, "plain"), ("lm.d(xn) qkv", 6144, 1024, 4096, "plain"),
+          ("lm.d(attn-out)", 6144, 2048, 1024, "plain"), ("lm.d(xn) qkv", 6144, 1024, 4096, "plain"),
           ("sq4096", 4096, 4096, 4096, "plain"), ("sq8192", 8192, 8192, 8192, "plain")]
 if "--match" in sys.argv:
     SHAPES = [s for s in SHAPES if sys.argv[sys.argv.index("--match") + 1] in s[0]]

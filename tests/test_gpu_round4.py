@@ -11,7 +11,8 @@ from tiny_audio_amd import ops
 
 pytestmark = pytest.mark.gpu
 DEV, BF16, F32 = "cuda", torch.bfloat16, torch.float32
-V7 = {13: (256, 256, 3), 14: (256, 320, 4), 15: (192, 256, 12)}      # variant -> (BM, BN, ping-pong variant of the same tile)
+# variant -> (BM, BN, a ping-pong variant to compare with bit for bit); 16 / 17 (round 5): two workgroups per CU on half-size tiles
+V7 = {13: (256, 256, 3), 14: (256, 320, 4), 15: (192, 256, 12), 16: (128, 256, 3), 17: (256, 128, 3)}
 
 
 def rnd(*shape, seed=0, scale=1.0, dtype=F32):
@@ -133,7 +134,8 @@ def test_v7_row_mapped_conv(v):
     assert torch.equal(xr, xr2)
 
 
-@pytest.mark.parametrize("v,M,N,K", [(13, 8192, 4096, 1024), (14, 16000, 5120, 1280), (15, 6144, 4096, 1024), (14, 16000, 1280, 5120)])
+@pytest.mark.parametrize("v,M,N,K", [(13, 8192, 4096, 1024), (14, 16000, 5120, 1280), (15, 6144, 4096, 1024), (14, 16000, 1280, 5120),
+                                     (16, 6144, 4096, 1024), (16, 16000, 1280, 1280), (17, 6144, 6144, 1024), (17, 6144, 1024, 3072)])
 def test_v7_repeated_launches_are_identical(v, M, N, K):
     """Race hunt: 30 launches over the same operands (with a different kernel in between that evicts L2), all bit-identical."""
     A, W = rnd(M, K, seed=1, dtype=BF16), rnd(N, K, seed=2, scale=1 / math.sqrt(K), dtype=BF16)

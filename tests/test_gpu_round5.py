@@ -139,6 +139,17 @@ def test_benchmarked_model_vs_reference_recipe_fixture(golden, streams):
     assert rec["nll_maxabs_vs_fp32"] <= MAXABS_FACTOR * rec["ref_regime_nll_maxabs_vs_fp32"], rec
     # two independent bf16 roundings of the same fp32 function: the distance between them stays below the sum of their distances
     assert rec["logits_rms_vs_regime"] <= rec["logits_rms_vs_fp32"] + rec["ref_regime_logits_rms_vs_fp32_same_sample"], rec
+    # The HEADLINE question (added after the first run of this test, with the factors above unchanged): is the default bf16-stream
+    # mode also within the same factors of the RECIPE's regime -- the reference's fp32 modules under autocast?  First measurement
+    # (profiles/r05_a_recipe_drift.json): logits RMS 0.0204 vs the recipe's 0.0169 (1.21x), max-abs 0.101 vs 0.091 (1.12x), NLL RMS
+    # 0.0176 vs 0.0180, NLL max-abs 0.039 vs 0.040, gradient cosine 0.99958 vs 0.99965 -- i.e. as far from the fp32 function as the
+    # reference's own training recipe is on the quantities training consumes, 1.2x on raw logits.
+    rec_reg = {"logits_rms": rms(ref["autocast"] - ref["fp32"]), "logits_maxabs": mab(ref["autocast"] - ref["fp32"]),
+               "nll_rms": float(g["autocast.nll_rms_vs_fp32"]), "nll_maxabs": float(g["autocast.nll_maxabs_vs_fp32"]),
+               "grad_cos_min": min(float(g[f"autocast.gcos_vs_fp32.{k}"]) for k in gc)}
+    assert rec["logits_rms_vs_fp32"] <= RMS_FACTOR * rec_reg["logits_rms"] and rec["logits_maxabs_vs_fp32"] <= MAXABS_FACTOR * rec_reg["logits_maxabs"], (rec, rec_reg)
+    assert rec["nll_rms_vs_fp32"] <= RMS_FACTOR * rec_reg["nll_rms"] and rec["nll_maxabs_vs_fp32"] <= MAXABS_FACTOR * rec_reg["nll_maxabs"], (rec, rec_reg)
+    assert 1.0 - rec["grad_cos_vs_fp32_min"] <= RMS_FACTOR ** 2 * (1.0 - rec_reg["grad_cos_min"]), (rec, rec_reg)     # 1 - cos ~ (relative error)^2
 
 
 # ============================================================================ (b) the oracle-based full-depth tests in the fp32-stream mode
@@ -259,6 +270,7 @@ def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
     for dt in ("bfloat16", "float32", "bfloat16"):
         cfg = ASRConfig(audio_config=enc, text_config=lmc, projector_hidden_dim=128, audio_token_id=1023, pad_token_id=1000,
                         eos_token_id=1001, model_dtype=dt)
+        torch.manual_seed(0)                                              # (the projector's nn.Linear init draws from the global generator)
         m = ASRModel(cfg, device=DEV, init="random", seed=0)
         f = LogMelFeatureExtractor(128, DEV)([OW.synthetic_wave(0, 32000)], sampling_rate=16000)
         ids, att, lab, counts = OW.synthetic_tokens(1, 25, 1024, 1023, 1000, 1001, n_text=10, n_suffix=4)

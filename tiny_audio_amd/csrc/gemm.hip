@@ -1316,7 +1316,7 @@ std::vector<long> g_log;
 // an experimental build corrupted a reported A/B in round 3).  ta_gemm_reload_knobs() re-reads the environment: tests and the A/B
 // scripts that switch a knob between launches call it (tiny_audio_amd/ops.py does so when it sees one of them change).
 struct GemmKnobs {
-  int variant, no96, v5_mink, v7_mask, ring, persist_kext, m32, group_m, group_m_auto, epi_narrow, dbg, persist;
+  int variant, no96, v5_mink, v7_mask, v9_mask, ring, persist_kext, m32, group_m, group_m_auto, epi_narrow, dbg, persist;
   double r320, r10, r12;
   void load() {
     auto s = [](const char* n) -> const char* { const char* v = getenv(n); return (v && *v) ? v : nullptr; };
@@ -1329,6 +1329,7 @@ struct GemmKnobs {
     r12 = f("TA355_RATE_192x256", TA355_RATE_192x256_PP);
     v5_mink = i("TA355_V5_MINK", 2048);
     v7_mask = i("TA355_V7_MASK", 0);
+    v9_mask = i("TA355_V9_MASK", 0);
     ring = i("TA355_GEMM_RING", 0) == 1;
     persist_kext = i("TA355_GEMM_PERSIST_KEXT", 0) == 1;
     m32 = i("TA355_GEMM_M32", 0) == 1;
@@ -1352,9 +1353,9 @@ static int pick_variant(int M, int N, int K, int splits) {
   const GemmKnobs& kn = knobs();
   const int forced = kn.variant;
 #ifdef TA355_EXPERIMENTS
-  if (forced >= 0 && forced <= 15) return forced;     // 6 / 7: the 4-slot ring (v3), 8 / 9: the stamped builds, 11: v6 -- experiment builds only
+  if (forced >= 0 && forced <= 17) return forced;     // 6 / 7: the 4-slot ring (v3), 8 / 9: the stamped builds, 11: v6 -- experiment builds only
 #else
-  if (forced >= 0 && forced <= 15 && !(forced >= 6 && forced <= 9) && forced != 11) return forced;   // 13 / 14 / 15: gemm_v7.hip
+  if (forced >= 0 && forced <= 17 && !(forced >= 6 && forced <= 9) && forced != 11) return forced;   // 13 ... 17: gemm_v7.hip
 #endif
   const bool no96 = kn.no96;
   const double r320 = kn.r320;
@@ -1392,6 +1393,20 @@ static int pick_variant(int M, int N, int K, int splits) {
       else if (best == 12 && (v7m & 16)) best = 15;
       else if (best == 3 && (v7m & 32)) best = 13;
     }
+    // round 5: the two-workgroups-per-CU form (variants 16 = 128x256 / 17 = 256x128) per shape family of the LM side (M = B * L rows):
+    // TA355_V9_MASK bits: 1 what went to the 192x256 tile (q|k|v, d(attn-out)), 2 what went to 192x128 / v5 (the N = 1024 products),
+    // 4 what went to the 256x320 tile with N not in {1280, 3840, 5120} (gate|up, d(act)), 8 the N = 1280 family, 16 N = 3840, 32 N = 5120;
+    // bit 256 selects 256x128 (17) instead of 128x256 (16)
+    const int v9m = kn.v9_mask;
+    if (v9m && splits == 1) {
+      const int v9 = (v9m & 256) ? 17 : 16;
+      if (best == 12 && (v9m & 1)) best = v9;
+      else if ((best == 10 || best == 5 || best == 0) && N <= 1024 && M >= 1024 && (v9m & 2)) best = v9;
+      else if (best == 4) {
+        const int bit = N == 1280 ? 8 : (N == 3840 ? 16 : (N == 5120 ? 32 : 4));
+        if (v9m & bit) best = v9;
+      }
+    }
     // (A second form of that kernel on v_mfma_f32_32x32x16_bf16 with an LDS-staged epilogue -- variants 16-18 of one visit -- was built on the
     // strength of a constant-data probe (1 151 against 1 281 cycles per k-step), passed the same tests, and measured 4-9 % SLOWER than
     // gemm_v7 on random operands (fc2 179 vs 164 us, 8192^3 1 309 vs 1 406 TF/s: profiles/r04_j_gemm_v8_32x32x16_ab.txt): on real data the
@@ -1418,11 +1433,12 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
 #endif
   if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
   if (a.w_blocked && variant >= 6 && variant != 12) return TA_ERR_ARG;         // the ring kernel (and v5 / v6) stage plain [N, K] weights only
-  if (variant >= 13 && variant <= 15 && !gemm_v7_serves(variant, ACT, OUT_BF16, HAS_RES, a)) variant = variant == 13 ? 3 : (variant == 14 ? 4 : 12);
+  if (variant >= 13 && variant <= 17 && !gemm_v7_serves(variant, ACT, OUT_BF16, HAS_RES, a))
+    variant = variant == 13 ? 3 : (variant == 14 ? 4 : (variant == 15 ? 12 : 3));
   if (variant == 12 && (a.a_idx || a_far || a.A2)) variant = 3;
-  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12 || variant == 15) ? 192 : 256));
+  const int bm = (variant == 0 || variant == 16) ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12 || variant == 15) ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
-  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9 || variant == 14) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12 || variant == 13 || variant == 15) ? 256 : 128);
+  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9 || variant == 14) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12 || variant == 13 || variant == 15 || variant == 16) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
@@ -1456,8 +1472,10 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
     (void)hipEventRecord(r.a, st);
   }
-  if (variant >= 13 && variant <= 15) {
-    const int rc = launch_gemm_v7<ACT, OUT_BF16, HAS_RES>(variant, a, pgrid, st);
+  if (variant >= 13 && variant <= 17) {
+    // 16 / 17: two 4-wave workgroups per CU (persistent: at most 2 per CU)
+    const int pg7 = variant >= 16 ? (grid < 2 * ncu ? grid : 2 * ncu) : pgrid;
+    const int rc = launch_gemm_v7<ACT, OUT_BF16, HAS_RES>(variant, a, pg7, st);
     if (rc) return rc;
   }
   else if (a.A2) {

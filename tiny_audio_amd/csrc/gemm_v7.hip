@@ -31,7 +31,7 @@
 #include "gemm_common.h"
 #include <type_traits>
 
-#define V7_NS 4                     /* ring stages */
+#define V7_NS 4                     /* ring stages of the one-workgroup-per-CU form (template parameter NS; the two-per-CU form has 3) */
 #define V7_LUT_BYTES (GELU_LUT_N * 8)
 #define V7_BIAS_BYTES 768        /* per wave: the bias of its <= 160 columns (+ 32 floats the clamped reads of a ragged tile may touch) */
 
@@ -127,8 +127,15 @@ __device__ __forceinline__ TileCtx v7_tile_ctx(const GemmArgs& p, int hh, int to
 }
 
 // MI x NJ: 16 x 16 fragments per wave (waves 2 x 2).
-template <int MI, int NJ, int ACT, bool OUT_BF16, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
+//
+// Round 5, WPC = 2: TWO such workgroups per CU on half-size tiles (MI x NJ = 4 x 8: 128 x 256, or 8 x 4: 256 x 128) -- 128 accumulator
+// AGPRs + <= 128 VGPRs per lane, a THREE-stage ring (72 KB) per workgroup.  The two workgroups of a CU run out of phase on their own
+// tile sequences, so one's epilogue (stores, the next tile's start values) sits beside the other's k loop on the same SIMDs instead of
+// leaving the matrix pipe idle: what the step's short contractions (K = 1024 ... 2048: 32 ... 64 k-steps per tile) lack with one
+// workgroup per CU.  NS = 3 keeps the three-k-step DMA lead: group G + 3 goes to the stage k-step G is multiplying FROM REGISTERS --
+// its fragment reads were issued during k-step G - 1 and are waited for (lgkmcnt(0)) in front of the barrier that opens k-step G.
+template <int MI, int NJ, int ACT, bool OUT_BF16, bool HAS_RES, int NS = V7_NS, int WPC = 1>
+__global__ __launch_bounds__(256, WPC) void gemm_nt_kernel_v7(GemmArgs p) {
   constexpr int BM7 = 32 * MI, BN7 = 32 * NJ;
   constexpr int PA = BM7 / 16, PW = BN7 / 16;            // 1-KB pieces (16 rows x 64 B) of A / of W per k-step
   constexpr int NDA = PA / 4, NDW = PW / 4, ND = NDA + NDW;   // pieces per wave: wave w stages pieces w, w + 4, ...
@@ -143,8 +150,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
   constexpr bool GELU = ACT == 1;
   constexpr int LUT_BYTES = GELU ? V7_LUT_BYTES : 0;
   constexpr bool ELS = ACT != 2;                                   // bias through LDS (rope keeps its table in global memory: 32 KB per tile)
-  static_assert(V7_NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) char smem[V7_NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES];
+  static_assert(NS == 3 || NS == 4, "ring stages");
+  static_assert(NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES <= 160 * 1024 / WPC, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + LUT_BYTES + 4 * V7_BIAS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -161,11 +169,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
   const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem) + wave * 1024;
 
   if (GELU) {                                                    // the chord table of the erf-GELU epilogue, once per workgroup
-    for (int i = tid; i < V7_LUT_BYTES / 16; i += 256) ((uint4*)(smem + V7_NS * STAGE))[i] = ((const uint4*)kGeluLut)[i];
+    for (int i = tid; i < V7_LUT_BYTES / 16; i += 256) ((uint4*)(smem + NS * STAGE))[i] = ((const uint4*)kGeluLut)[i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (published by the first barrier below)
   }
-  const float2* lut = GELU ? (const float2*)(smem + V7_NS * STAGE) : nullptr;
-  char* bias_lds = smem + V7_NS * STAGE + LUT_BYTES + wave * V7_BIAS_BYTES;   // wave-private: no barrier around it
+  const float2* lut = GELU ? (const float2*)(smem + NS * STAGE) : nullptr;
+  char* bias_lds = smem + NS * STAGE + LUT_BYTES + wave * V7_BIAS_BYTES;   // wave-private: no barrier around it
 
   // ---- DMA side: THREE k-steps ahead of the MFMAs.  Inside a tile the two base pointers step by 64 B per k-step; when the MFMAs
   //      stand three k-steps before a tile's end, the DMA side moves to the workgroup's next tile (dma_setup) -- host: every tile has
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
   // of stage G - 1, which group G + 3 -- requested during k-step G -- overwrites
   auto sync = [&]() {
     v7_wait_vm<ND>();
+    if constexpr (NS == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stage group G + 3 will overwrite
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -270,8 +279,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
         dma_setup(nx);
       }
       // one k-step: SL MFMAs, between them the fragment reads of k-step + 1 and the DMA pieces of k-step + 3
-      const char* Sn = smem + ((rs + 1) & 3) * STAGE;
-      const int is = (rs + 3) & 3;
+      const char* Sn = smem + (rs + 1 == NS ? 0 : rs + 1) * STAGE;
+      const int is = NS == 3 ? rs : ((rs + 3) & 3);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel_v7(GemmArgs p) {
         const long st = (more || ks + 4 < nk) ? 64 : 0;
         a_base = uniform_ptr(a_base + st); w_base = uniform_ptr(w_base + st);
       }
-      rs = (rs + 1) & 3;
+      rs = rs + 1 == NS ? 0 : rs + 1;
       if (more || ks + 1 < nk) sync();
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // last MFMA results -> VALU reads of the accumulators
@@ -342,8 +351,11 @@ static bool v7_geometry(int variant, int& bm, int& bn) {
   if (variant == 13) { bm = 256; bn = 256; return true; }
   if (variant == 14) { bm = 256; bn = 320; return true; }
   if (variant == 15) { bm = 192; bn = 256; return true; }
+  if (variant == 16) { bm = 128; bn = 256; return true; }         // two workgroups per CU (round 5)
+  if (variant == 17) { bm = 256; bn = 128; return true; }
   return false;
 }
+bool gemm_v7_two_per_cu(int variant) { return variant == 16 || variant == 17; }
 
 bool gemm_v7_serves(int variant, int act, bool out_bf16, bool has_res, const GemmArgs& a) {
   int bm, bn;
@@ -351,15 +363,16 @@ bool gemm_v7_serves(int variant, int act, bool out_bf16, bool has_res, const Gem
   if (a.a_idx || a.seg || a.krange || a.grp_n > 0 || a.A2 || a.w_blocked || a.sw_gu || a.lnf_mode) return false;
   if (act < 0 || act > 2) return false;
   if (act != 0 && (!out_bf16 || has_res)) return false;           // GELU / rope: bf16 out, no residual (what the step launches)
+  if (gemm_v7_two_per_cu(variant) && act == 1) return false;      // (the GELU table does not fit beside two 72-KB rings)
   if ((a.K / BK) / a.splits < 2) return false;                    // >= 4 k-steps of 32 per tile
   if (a.lda * 2 * 256 >= (1L << 32) || (long)a.K * 2 * 320 >= (1L << 32)) return false;
   if (!a.a_plain && ((long)(a.M / a.a_rpb + 1) * a.a_bs + a.lda * a.a_rpb) * 2 >= (1L << 32)) return false;
   return true;
 }
 
-template <int MI, int NJ, int ACT, bool OUT_BF16, bool HAS_RES>
+template <int MI, int NJ, int ACT, bool OUT_BF16, bool HAS_RES, int NS = V7_NS, int WPC = 1>
 static int v7_launch_one(const GemmArgs& a, int pgrid, hipStream_t st) {
-  TA_LAUNCH((gemm_nt_kernel_v7<MI, NJ, ACT, OUT_BF16, HAS_RES>), dim3(pgrid), dim3(256), 0, st, a);
+  TA_LAUNCH((gemm_nt_kernel_v7<MI, NJ, ACT, OUT_BF16, HAS_RES, NS, WPC>), dim3(pgrid), dim3(256), 0, st, a);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
@@ -373,6 +386,10 @@ int launch_gemm_v7(int variant, GemmArgs a, int pgrid, hipStream_t st) {
     if (variant == 13) return v7_launch_one<8, 8, ACT, OUT_BF16, HAS_RES>(a, pgrid, st);
     if (variant == 14) return v7_launch_one<8, 10, ACT, OUT_BF16, HAS_RES>(a, pgrid, st);
     if (variant == 15) return v7_launch_one<6, 8, ACT, OUT_BF16, HAS_RES>(a, pgrid, st);
+    if constexpr (ACT != 1) {
+      if (variant == 16) return v7_launch_one<4, 8, ACT, OUT_BF16, HAS_RES, 3, 2>(a, pgrid, st);
+      if (variant == 17) return v7_launch_one<8, 4, ACT, OUT_BF16, HAS_RES, 3, 2>(a, pgrid, st);
+    }
     return TA_ERR_ARG;
   }
 }
