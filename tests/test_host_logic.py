@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     handle = _lib.lib()                      # binds every prototype; AttributeError if one is not exported
     for name in protos:
         assert hasattr(handle, name), name
-    assert handle.ta_version() == 2
+    assert handle.ta_version() == 3
     # every extern "C" ta_* symbol the library exports is declared in the header (no undocumented entry points)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True).stdout

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "ta355.h")
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(HERE, "libta355.so")
-SOURCES = ["gemm.hip", "gemm_v7.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
+SOURCES = ["gemm.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "attention_enc.hip", "qkv_post.hip", "elementwise.hip", "loss.hip",
            "logmel.hip", "optim.hip", "moe.hip", "lora.hip", "nn_prims.hip", "generate.hip", "decode_fused.hip", "api.hip"]
 
 
@@ -32,9 +32,7 @@ class Ta355Error(RuntimeError):
 # ----------------------------------------------------------------------------- structs (must mirror ta355.h)
 class EncLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo",
-                                          "w1", "b1", "w2", "b2", "wqk_il", "bqk_il", "bo_fold",
-                                          "wqk_ln", "wv_ln", "w1_ln", "c1_qk", "c2_qk", "c1_v", "c1_1", "c2_1", "bo_fold2",
-                                          "wqkv_fa", "bqkv_fa")]
+                                          "w1", "b1", "w2", "b2", "wqkv_fa", "bqkv_fa")]
 
 
 class EncoderWeights(C.Structure):
@@ -66,8 +64,7 @@ class LmLayer(C.Structure):
 
 class GemmOpts(C.Structure):
     _fields_ = [("a2", C.c_void_p), ("w2", C.c_void_p), ("k2", C.c_int), ("lda2", C.c_long), ("residual_bf16", C.c_void_p),
-                ("swiglu_gu", C.c_void_p), ("swiglu_dgu", C.c_void_p), ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int),
-                ("lnf_stats", C.c_void_p), ("lnf_c1", C.c_void_p), ("lnf_mode", C.c_int), ("rope_cols", C.c_int)]
+                ("rope_tab", C.c_void_p), ("rope_rows", C.c_int), ("w_blocked", C.c_int), ("rope_cols", C.c_int)]
 
 
 class AttnLayout(C.Structure):
@@ -148,8 +145,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # attention_enc.hip: no NaN can reach its row maxima (scores are finite MFMA sums; masked keys are -1e30, not -inf), and
     # without this every fmaxf on an MFMA result is preceded by a canonicalising v_max_f32 x, x (12 extra VALU per key tile)
     extra = {"attention_enc.hip": ["-fno-honor-nans"]}
-    # gemm_v7.hip keeps its accumulators in AGPRs on purpose (inline-assembly MFMAs with "+a" operands)
-    no_vgpr_form = {"gemm_v7.hip"}
+    no_vgpr_form = set()                # (sources that keep their accumulators in AGPRs on purpose: none in the product library)
     hdr_time = max(os.path.getmtime(h) for h in hdrs)
 
     def compile_one(src):

@@ -6,7 +6,7 @@
 #include "internal.h"
 #include "../../include/ta355.h"
 
-extern "C" int ta_version(void) { return 2; }
+extern "C" int ta_version(void) { return 3; }
 
 #include <algorithm>
 #include <atomic>
@@ -16,15 +16,11 @@ extern "C" int ta_version(void) { return 2; }
 // Process-wide: which dtype the encoder's residual stream, the LM's forward residual stream (+ tape) and the LM's backward d(x)
 // stream are STORED in.  bf16 (default) is what a bf16-module reference keeps (ASRConfig model_dtype="bfloat16"); fp32 is what the
 // training recipe keeps (fp32 modules under bf16 autocast: configs/config.yaml:14-18 + configs/training/production.yaml:49).
-// MFMA operands (bf16) and accumulators (fp32) are the same in both.  Initial values from TA355_ENC_RES_F32 / TA355_LM_RES_F32 /
-// TA355_LM_DX_F32 (read once); ta_set_stream_modes changes them between calls (not while a composite is being enqueued).
+// MFMA operands (bf16) and accumulators (fp32) are the same in both.  Initially bf16 / bf16 / bf16; ta_set_stream_modes changes them
+// between calls (not while a composite is being enqueued).
 namespace {
 struct StreamModes {
-  std::atomic<int> enc_f32, lm_f32, dx_f32;
-  StreamModes() {
-    auto on = [](const char* n) { const char* v = getenv(n); return (v && *v == '1') ? 1 : 0; };
-    enc_f32 = on("TA355_ENC_RES_F32"); lm_f32 = on("TA355_LM_RES_F32"); dx_f32 = on("TA355_LM_DX_F32");
-  }
+  std::atomic<int> enc_f32{0}, lm_f32{0}, dx_f32{0};
 };
 StreamModes& stream_modes() { static StreamModes m; return m; }
 }  // namespace
@@ -47,7 +43,6 @@ namespace {
 struct EncWs {
   bf16_t *x0, *x1, *xn, *qkv, *q, *k, *vt, *ao, *hf;
   float* xr;
-  float* stats;        // [M][2] LayerNorm statistics of the folded-LN path
   size_t bytes;
 };
 EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
@@ -65,7 +60,6 @@ EncWs enc_carve(const ta_encoder_weights* w, int B, int T, void* base) {
   e.vt = c.take<bf16_t>((size_t)B * H * Sp);
   e.ao = c.take<bf16_t>((size_t)M * H);
   e.hf = c.take<bf16_t>((size_t)M * w->ffn);
-  e.stats = c.take<float>((size_t)M * 2 + 8);
   e.bytes = c.total();
   return e;
 }
@@ -85,10 +79,6 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   const int M = B * S;
   EncWs e = enc_carve(w, B, T, ws);
   if ((long)e.bytes > ws_bytes) return TA_ERR_ARG;
-  // The strided attention reads Lp = pad64(S) key columns per clip from the V^T image [H, M]: past a clip's S columns come
-  // the next clip's (finite, masked), and past the LAST row of the image the 128-element slack behind it -- masked as well,
-  // but P = 0 times a NaN bit pattern is NaN, so the slack must hold finite values: zero it (the GEMMs never write it)
-  if (hipMemsetAsync(e.qkv + (size_t)M * 3 * H, 0, 128 * sizeof(bf16_t), st) != hipSuccess) return TA_ERR_LAUNCH;
   // conv front end as two row-mapped GEMMs over zero-padded time-major buffers
   RC(ta_feats_to_time_major(feats, e.x0, B, NM, T, st));
   RC(ta_zero_pad_rows(e.x1, B, T, H, st));
@@ -96,7 +86,7 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
                      w->conv1_b, nullptr, 1, 1, 1, nullptr, st));
   // Residual stream: bf16, the dtype the reference's encoder runs in (model_dtype bfloat16: every residual add and
   // LayerNorm input is bf16 there).  It halves the bytes of the two residual GEMM epilogues and of the LayerNorm reads
-  // per layer -- HBM time that nothing overlaps.  ta_set_stream_modes(1, ., .) / TA355_ENC_RES_F32=1 keeps an fp32 stream instead.
+  // per layer -- HBM time that nothing overlaps.  ta_set_stream_modes(1, ., .) keeps an fp32 stream instead.
   const bool res_f32 = stream_modes().enc_f32 != 0;
   const int rb = res_f32 ? 0 : 1;
   auto ln = [&](const float* gw, const float* gb, void* yb, float* yf, const float* rowscale) -> int {
@@ -110,40 +100,14 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
   RC(ta_gemm_bf16_nt(e.x1, w->conv2_w, e.xr, M, H, 3 * H, 2L * H, S, (long)(T + 2) * H, H, 0, 0, 0, w->conv2_b, nullptr,
                      1, rb, 1, nullptr, st));
   const float scale = 0.125f;   // head_dim ** -0.5, head_dim = 64
-  // Fused q|k|v path (no qkv_post pass: 246 MB of HBM traffic per layer at B = 32): needs the derived weight images and
-  // M % 8 == 0 (the V^T GEMM has N = ldc = M).  TA355_ENC_QKV_FUSED=0 keeps the three-kernel path.
-  const char* fz = getenv("TA355_ENC_QKV_FUSED");             // read per call: the tests compare both paths
-  const bool fused = !(fz && *fz == '0') && w->rope_il && (M % 8) == 0;
-  // TA355_ENC_LN_FOLD=1 (experiment, off): LayerNorms folded into the GEMMs behind them.  Measured 0.3 ms SLOWER per step
-  // (52.6 vs 52.3 ms): the two statistics passes plus the extra per-fragment loads / FMAs of three un-overlapped GEMM
-  // epilogues cost more than the two LayerNorm kernels (19 us each) they replace.
-  const char* lz = getenv("TA355_ENC_LN_FOLD");
-  const bool lnfold = lz && *lz == '1';
-  const char* az = getenv("TA355_ENC_ATTN_V2");               // 0 = the round-2 attention path (V^T GEMM + attn_fwd_kernel); read per call
-  const bool fa = !(az && *az == '0') && !(fz && *fz == '0') && w->rope_il && !lnfold && (H / nh) == 64;
+  // Default: q | k | v from ONE GEMM + ta_attention_enc_fwd (needs the derived weight images, head_dim 64).  TA355_ENC_QKV_FUSED=0
+  // keeps the three-kernel path (q|k|v GEMM + ta_enc_qkv_post + ta_attention_fwd); read per call: the tests compare both.
+  // (Rounds 1-2 had a third form -- rope in the q|k epilogue + V^T = Wv xn^T as a second GEMM; rounds 1-3 a folded-LayerNorm form:
+  // both removed in round 5)
+  const char* fz = getenv("TA355_ENC_QKV_FUSED");
+  const bool fa = !(fz && *fz == '0') && w->rope_il && (H / nh) == 64;
   for (int l = 0; l < w->n_layers; ++l) {
     const ta_enc_layer& L = w->layers[l];
-    const bool fold = fused && lnfold && rb && L.wqk_ln && L.wv_ln && L.w1_ln && L.c1_qk && L.c2_qk && L.c1_v && L.c1_1 &&
-                      L.c2_1 && L.bo_fold2;
-    if (fold) {
-      // Both LayerNorms live in the GEMMs that follow them: only the row statistics are computed (one read of the bf16
-      // stream, 8 bytes written per row), the GEMMs read the stream itself against gamma-scaled weights.
-      RC(ta_layernorm_stats(e.xr, 1, e.stats, M, H, w->ln_eps, st));
-      ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S;
-      o.lnf_stats = e.stats; o.lnf_c1 = L.c1_qk; o.lnf_mode = 1;
-      RC(gemm_opt(e.xr, L.wqk_ln, e.qkv, M, 2 * H, H, L.c2_qk, nullptr, 2, 1, o, st));
-      bf16_t* vt = e.qkv + (size_t)M * 2 * H;
-      ta_gemm_opts ov = opts_none(); ov.lnf_stats = e.stats; ov.lnf_c1 = L.c1_v; ov.lnf_mode = 2;
-      RC(gemm_opt(L.wv_ln, e.xr, vt, H, M, H, nullptr, nullptr, 0, 1, ov, st));
-      const ta_attn_layout lay = {(long)S * 2 * H, 64, 2L * H, (long)S * 2 * H, 64, 2L * H, S, 64L * M, M};
-      RC(ta_attention_fwd_ex(e.qkv, e.qkv + H, vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, &lay, st));
-      RC(res_gemm(e.ao, L.wo, H, L.bo_fold2));
-      RC(ta_layernorm_stats(e.xr, 1, e.stats, M, H, w->ln_eps, st));
-      ta_gemm_opts o1 = opts_none(); o1.lnf_stats = e.stats; o1.lnf_c1 = L.c1_1; o1.lnf_mode = 1;
-      RC(gemm_opt(e.xr, L.w1_ln, e.hf, M, F, H, L.c2_1, nullptr, 1, 1, o1, st));
-      RC(res_gemm(e.hf, L.w2, F, L.b2));
-      continue;
-    }
     RC(ln(L.ln1_w, L.ln1_b, e.xn, nullptr, nullptr));
     if (fa && L.wqkv_fa && L.bqkv_fa) {
       // Round 3: q | k | v out of ONE GEMM as a token-major [M, 3H] buffer (rope on the q | k columns, q pre-scaled by
@@ -153,16 +117,6 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
       RC(gemm_opt(e.xn, L.wqkv_fa, e.qkv, M, 3 * H, H, L.bqkv_fa, nullptr, 2, 1, o, st));
       RC(ta_attention_enc_fwd(e.qkv, e.ao, B, nh, S, st));
       RC(res_gemm(e.ao, L.wo, H, L.bo));
-    } else if (fused && L.wqk_il && L.bqk_il && L.bo_fold) {
-      // q|k = rope(xn Wqk^T + b) straight from the GEMM epilogue (token-major [M, 2H], heads' rotary pairs interleaved),
-      // V^T [H, M] = Wv xn^T as a second GEMM (its bias lives in bo_fold); attention reads both in place.
-      ta_gemm_opts o = opts_none(); o.rope_tab = w->rope_il; o.rope_rows = S;
-      RC(gemm_opt(e.xn, L.wqk_il, e.qkv, M, 2 * H, H, L.bqk_il, nullptr, 2, 1, o, st));
-      bf16_t* vt = e.qkv + (size_t)M * 2 * H;
-      RC(gemm((const bf16_t*)L.wqkv + (size_t)2 * H * H, e.xn, vt, H, M, H, nullptr, nullptr, 0, 1, st));
-      const ta_attn_layout lay = {(long)S * 2 * H, 64, 2L * H, (long)S * 2 * H, 64, 2L * H, S, 64L * M, M};
-      RC(ta_attention_fwd_ex(e.qkv, e.qkv + H, vt, e.ao, nullptr, nullptr, B, nh, nh, S, Sp, 64, 0, scale, &lay, st));
-      RC(res_gemm(e.ao, L.wo, H, L.bo_fold));
     } else {
       RC(gemm(e.xn, L.wqkv, e.qkv, M, 3 * H, H, L.bqkv, nullptr, 0, 1, st));
       RC(ta_enc_qkv_post(e.qkv, w->rope_cos, w->rope_sin, e.q, e.k, e.vt, B, nh, S, Sp, st));
@@ -270,19 +224,6 @@ namespace {
 // (model_dtype bfloat16).  Halves the bytes of the o / down GEMM epilogues, of the RMSNorm reads (forward and
 // backward) and of the tape.  TA355_LM_RES_F32=1 keeps fp32 instead.  The gradient stream d(x) stays fp32.
 inline bool lm_res_bf16() { return stream_modes().lm_f32 == 0; }
-// side stream of the LoRA backward (see lora_bwd in ta_lm_backward): created once per process, on the device current at first use
-struct LoraSide { hipStream_t s; hipEvent_t fork[2], join[2]; };
-static LoraSide* lora_side() {
-  static LoraSide ls;
-  static const bool ok = [] {
-    if (hipStreamCreateWithFlags(&ls.s, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 2; ++i)
-      if (hipEventCreateWithFlags(&ls.fork[i], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ls.join[i], hipEventDisableTiming) != hipSuccess) return false;
-    return true;
-  }();
-  return ok ? &ls : nullptr;
-}
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
@@ -347,7 +288,7 @@ LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLa
   return t;
 }
 struct LmWs {
-  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB, *dyB2;
+  bf16_t *xn, *act, *hl, *dxb, *dact, *dgu, *dao, *dot, *dq, *dk, *dv, *dqkv, *dyB;
   float* lora_part;            // round 4: per-chunk partial adapter gradients of every layer (two-level reduction, no atomics)
   long lp_layer, lp_off[8], lp_size[8]; int lp_chunks[8];   // kinds in ta_lm_lora_grads order: la_qkv, lb_qkv, la_o, lb_o, la_gu, lb_gu, la_d, lb_d
   float *logits, *dhl, *dhn, *dxa, *dxb32, *dxn, *delta, *skws;
@@ -384,7 +325,6 @@ LmWs lm_ws(const ta_lm_weights* w, int B, int L, int n_lab, void* base) {
   s.dv = c.take<bf16_t>((size_t)d.M * d.nkv * d.hd);
   s.dqkv = c.take<bf16_t>((size_t)d.M * d.NQKV);
   s.dyB = c.take<bf16_t>((size_t)d.M * 64);
-  s.dyB2 = c.take<bf16_t>((size_t)d.M * 64);
   s.lora_part = nullptr; s.lp_layer = 0;
   if (w->lora_rank > 0) {
     const int r = w->lora_rank, bq = d.nq * d.hd;
@@ -513,9 +453,8 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     RC(norm(p.x_in, Lw.ln_in_w, xn, p.r_in));
     if (lgm & 1) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv, 3));
     RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
-    // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging (TA355_ATTN_FWD_FUSED=0: two kernels)
-    static const bool fuse_fwd = [] { const char* e = getenv("TA355_ATTN_FWD_FUSED"); return !(e && *e == '0'); }();
-    const bool fused_fwd = fuse_fwd && d.hd == 128 && L <= 192 && (d.nq / d.nkv) * ((L + 31) / 32) <= 12;
+    // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging; longer ones take two kernels
+    const bool fused_fwd = d.hd == 128 && L <= 192 && (d.nq / d.nkv) * ((L + 31) / 32) <= 12;
     if (fused_fwd)
       RC(ta_attention_fwd_qkv(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.rq, p.rk, p.ao, p.lse, kmask,
                               B, d.nq, d.nkv, L, scale, w->eps, st));
@@ -571,11 +510,9 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
     // ignored rows contribute exactly zero to both loss and gradient.
     RC(ta_gather_rows_bf16(t.hn, label_rows, s.hl, n_lab, d.D, st));
     // The labelled logits are bf16 -- what the reference's bf16 lm_head produces before `logits.float()`
-    // (TF:loss/loss_utils.py:55) -- which halves the bytes of the head epilogue and of the CE pass (0.25 ms per step);
-    // TA355_CE_LOGITS_BF16=0 keeps them in fp32.
-    static const bool lb = [] { const char* e = getenv("TA355_CE_LOGITS_BF16"); return !(e && *e == '0'); }();
-    RC(gemm(s.hl, w->embed_bf16, s.logits, n_lab, w->vocab_pad, d.D, nullptr, nullptr, 0, lb ? 1 : 0, st));
-    RC(ta_cross_entropy(s.logits, lb ? 1 : 0, w->vocab_pad, nullptr, label_targets, n_lab, w->vocab, loss_scale, nll_rows, loss,
+    // (TF:loss/loss_utils.py:55) -- which halves the bytes of the head epilogue and of the CE pass (0.25 ms per step).
+    RC(gemm(s.hl, w->embed_bf16, s.logits, n_lab, w->vocab_pad, d.D, nullptr, nullptr, 0, 1, st));
+    RC(ta_cross_entropy(s.logits, 1, w->vocab_pad, nullptr, label_targets, n_lab, w->vocab, loss_scale, nll_rows, loss,
                         t.dlogits, w->vocab_pad, st));
   }
   return TA_OK;
@@ -669,9 +606,8 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       for (int l = 1; l < NL; ++l)
         if (fld(lora_grads[l], k) != fld(lora_grads[0], k) + (size_t)l * sz[k]) { stacked = false; break; }
     // round 4: with stacked gradient tensors the adapter-gradient kernels store per-chunk partial sums and ONE kernel at the end adds
-    // them in a fixed order (TA355_LORA_TN_PARTS=0: float atomics as in rounds 1-3) -- deterministic, and no memset of the gradients
-    static const bool parts_env = [] { const char* e = getenv("TA355_LORA_TN_PARTS"); return !(e && *e == '0'); }();
-    lora_parts = stacked && parts_env && s.lora_part && (r % 4 == 0);
+    // them in a fixed order -- deterministic, and no memset of the gradients; otherwise (per-layer tensors, r % 4 != 0): float atomics
+    lora_parts = stacked && s.lora_part && (r % 4 == 0);
     for (int k = 0; k < 8 && lora_parts; ++k) if (sz[k] != (size_t)s.lp_size[k]) lora_parts = false;
     if (stacked) {
       if (!lora_parts || lgm != 15)
@@ -690,44 +626,15 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   //   dx  = dy W + dyB (sAcat) (K extension of the dX GEMM) dAcat = s (dyB)^T x
   // `arm` only prepares the K extension; the caller then issues the frozen dX GEMM.
   ta_gemm_opts kx = opts_none();                     // K extension of the NEXT frozen dX GEMM
-  // round 4 experiment, OPT-IN (TA355_LORA_SIDE_STREAM=1): the two adapter-gradient products of a group (dB = dy^T xa, dA = s (dy B)^T x:
-  // HBM-bound streams over dy and x whose results nothing in the backward chain waits for) on a SIDE stream, beside the frozen dX GEMM
-  // that follows on the caller's stream.  Ordering: fork event after the group's dyB kernel; the caller's stream waits for the side
-  // kernel of group k before it leaves the lora_bwd of group k + 1 -- no kernel between two lora_bwd calls overwrites the earlier
-  // group's dy (d(x) bf16 / dgu / dqkv are rewritten only after the NEXT group's dX GEMM), and dyB alternates between two buffers.
-  // Measured 47.38 ms per LoRA step against 46.33 in line (3 + 3 runs, one box, profiles/r04_n_ab_lora_side_stream.txt): the GEMMs are
-  // one persistent workgroup per CU with 123-147 KB of LDS, so the side kernel's workgroups do not fit beside them -- they take CUs
-  // from the next GEMM's first round instead, and that round then ends with a straggler.
-  static const bool side_env = [] { const char* e = getenv("TA355_LORA_SIDE_STREAM"); return e && *e == '1'; }();
-  LoraSide* side = (lora && side_env && lgm == 15) ? lora_side() : nullptr;   // (target subsets change which kernels lie between two groups)
-  int side_n = 0;                                    // groups forked so far
   auto lora_bwd = [&](const bf16_t* dy, int N, const bf16_t* x, int in, const bf16_t* xa, const LoraImg& g, float* dla,
                       float* dlb, int members, int b0, int b1, int layer, int grp) -> int {
-    bf16_t* dyB = (side && (side_n & 1)) ? s.dyB2 : s.dyB;
-    RC(ta_i_lora_skinny_nt(dy, N, g.bt, dyB, M, members * r, st));
-    static const bool dual = [] { const char* e = getenv("TA355_LORA_TN_DUAL"); return !(e && *e == '0'); }();
-    hipStream_t ts = st;
-    if (side) {
-      const int k = side_n & 1;
-      if (hipEventRecord(side->fork[k], st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork[k], 0) != hipSuccess) return TA_ERR_LAUNCH;
-      ts = side->s;
-    }
-    if (dual || lora_parts) {                          // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3)
-      float* pb = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp + 1] : nullptr;
-      float* pa = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp] : nullptr;
-      RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, dyB, members * r, dla, 1, in, w->lora_scale,
-                              0, 0, 0, M, pb, s.lp_size[2 * grp + 1], pa, s.lp_size[2 * grp], ts));
-    } else {
-      RC(ta_i_lora_skinny_tn(dy, N, xa, 64, members * r, dlb, r, 1, M, 1.0f, r, b0, b1, ts));
-      RC(ta_i_lora_skinny_tn(x, in, dyB, 64, members * r, dla, 1, in, M, w->lora_scale, 0, 0, 0, ts));
-    }
-    if (side) {
-      const int k = side_n & 1;
-      if (hipEventRecord(side->join[k], side->s) != hipSuccess) return TA_ERR_LAUNCH;
-      if (side_n > 0 && hipStreamWaitEvent(st, side->join[k ^ 1], 0) != hipSuccess) return TA_ERR_LAUNCH;   // the previous group's
-      ++side_n;
-    }
-    kx = opts_kext(dyB, g.at);
+    RC(ta_i_lora_skinny_nt(dy, N, g.bt, s.dyB, M, members * r, st));
+    // dB = dy^T xa and dA = s (dy B)^T x in ONE launch (round 3); per-chunk partial sums when the gradients are stacked (round 4)
+    float* pb = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp + 1] : nullptr;
+    float* pa = lora_parts ? s.lora_part + (long)layer * s.lp_layer + s.lp_off[2 * grp] : nullptr;
+    RC(ta_i_lora_skinny_tn2(dy, N, xa, members * r, dlb, r, 1, 1.0f, r, b0, b1, x, in, s.dyB, members * r, dla, 1, in, w->lora_scale,
+                            0, 0, 0, M, pb, s.lp_size[2 * grp + 1], pa, s.lp_size[2 * grp], st));
+    kx = opts_kext(s.dyB, g.at);
     return TA_OK;
   };
   auto take_ext = [&]() { const ta_gemm_opts o = kx; kx = opts_none(); return o; };
@@ -739,12 +646,11 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   RC(ta_scatter_rows_f32(s.dhl, label_rows, s.dhn, n_lab, d.D, st));
   // ---- weight gradients (full decoder fine-tuning): dW[N_out, K_in] += dY^T X as an NT GEMM over transposed bf16 images
   const int Kp = pad64(M);
-  // TA355_WGRAD_TN: 0 = always two transposes + the NT GEMM, 2 = always the TN kernel (csrc/gemm_tn.hip), 1 (default) = TN
-  // where it measured faster at M = 6144 (q|k|v 85 vs 93 us, o 58 vs 69; gate|up 151 vs 127 and down 88 vs 78 stay NT)
-  static const int tn_mode = [] { const char* e = getenv("TA355_WGRAD_TN"); return e && *e ? atoi(e) : 1; }();
+  // the TN kernel (csrc/gemm_tn.hip) where it measured faster at M = 6144 (q|k|v 85 vs 93 us, o 58 vs 69), two transposes + the NT GEMM
+  // elsewhere (gate|up 151 vs 127, down 88 vs 78)
   auto wgrad = [&](const bf16_t* dy, int n_out, const bf16_t* x, int k_in, float* dW) -> int {
     if (!dW) return TA_OK;
-    if (tn_mode == 2 || (tn_mode == 1 && n_out <= 4096 && k_in <= 2048))
+    if (n_out <= 4096 && k_in <= 2048)
       return ta_gemm_bf16_tn(dy, x, dW, M, n_out, k_in, 1, s.wsk, ta_gemm_bf16_tn_ws_bytes(M, n_out, k_in), st);
     RC(ta_transpose_to_bf16(dy, 0, n_out, 0, 0, s.tA, Kp, M, n_out, st));
     RC(ta_transpose_to_bf16(x, 0, k_in, 0, 0, s.tB, Kp, M, k_in, st));
@@ -787,16 +693,10 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (lgm & 8) RC(lora_bwd(s.dxb, d.D, p.act_s, d.F, p.xa_d, p.i_d, lora_grads[l].dla_d, lora_grads[l].dlb_d, 1, 1 << 30, 1 << 30, l, 3));
     const ta_lm_layer_wgrads* g = wg ? &wg->layers[l] : nullptr;
     if (g) RC(wgrad(s.dxb, d.D, p.act_s, d.F, g->dwd));
-    // Measured (same box, 3 runs each): fusing the SwiGLU backward into this GEMM's epilogue makes the step 0.4 ms SLOWER
-    // (54.8 vs 54.3 ms) -- at one workgroup per CU nothing overlaps an epilogue, so bytes moved there (gate|up read,
-    // d(gate|up) written in 32-B pieces) cost more than the separate streaming kernel at 6 TB/s.  Off unless asked for.
-    static const bool fuse_swiglu = [] { const char* e = getenv("TA355_FUSE_SWIGLU_BWD"); return e && *e == '1'; }();
-    {
-      ta_gemm_opts o = take_ext();
-      if (fuse_swiglu) { o.swiglu_gu = p.gu; o.swiglu_dgu = s.dgu; }
-      RC(gemm_opt(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, o, st));
-    }
-    if (!fuse_swiglu) RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
+    // (Fusing the SwiGLU backward into this GEMM's epilogue measured 0.4 ms per step SLOWER -- at one workgroup per CU nothing overlaps
+    // an epilogue, so bytes moved there cost more than the separate streaming kernel at 6 TB/s; the form left the library in round 5.)
+    RC(gemm_opt(s.dxb, Lw.wd_t, s.dact, M, d.F, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
+    RC(ta_swiglu_bwd(s.dact, p.gu, s.dgu, M, d.F, st));
     if (lgm & 4) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30, l, 2));
     if (g) RC(wgrad(s.dgu, 2 * d.F, p.xn2_s, d.D, g->dwgu));
     RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
@@ -806,37 +706,13 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (lgm & 2) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30, l, 1));
     if (g) RC(wgrad(s.dxb, d.D, p.ao, bq, g->dwo));
     RC(gemm_opt(s.dxb, Lw.wo_t, s.dao, M, d.nq * d.hd, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
-    // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue (TA355_ATTN_BWD_FUSED=0:
-    // head-major dQ / dK / dV + ta_lm_qkv_post_bwd, which also serves the trainable-norm case)
-    static const bool fuse_post = [] { const char* e = getenv("TA355_ATTN_BWD_FUSED"); return !(e && *e == '0'); }();
-    // round 4: one workgroup per (clip, kv head) -- K / V resident, Delta inside, no ta_attn_bwd_prep.  OPT-IN (TA355_ATTN_BWD_GQA=1):
-    // measured 92.8 us per layer warm / 117.5 cold against 91.8 / 106.0 for the tiled kernels + the Delta pass, and 41.08 against 40.45
-    // ms per step (profiles/r04_g_*, r04_h_*): with the dK / dV accumulators of all 192 keys in registers only ONE 4-wave workgroup
-    // fits a CU, and a single wave per SIMD waits out every LDS round trip of its 2 280 fragment reads by itself (67 of the 93 us are
-    // the tile-pair arithmetic at ~15 cycles per instruction).  Outside its envelope (L <= 128 or > 192, other group sizes) it
-    // answers TA_ERR_ARG and the tiled path runs.
-    static const bool gqa_bwd = [] { const char* e = getenv("TA355_ATTN_BWD_GQA"); return e && *e == '1'; }();
-    bool attn_done = false;
-    if (gqa_bwd && fuse_post && !(g && (g->dqn || g->dkn))) {
-      const int rc = ta_attention_bwd_gqa(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.ao, p.lse, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
-                                          w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.hd, scale, st);
-      if (rc == TA_OK) attn_done = true;
-      else if (rc != TA_ERR_ARG) return rc;
-    }
-    // round 4: Delta = rowsum(dO o O) computed inside the fused backward from O -- OPT-IN (TA355_ATTN_DELTA_FUSED=1).  It removes the
-    // ta_attn_bwd_prep launch (9.5 us) but the O rows each dK / dV workgroup then carries raise the tiled kernel's spill from 20 to
-    // 100 bytes per lane: 87.3 us against 67.2 + 9.5, 40.8 against 40.4 ms per step (profiles/r04_zj_ab_delta_fused_lean.txt).  The
-    // first A/B of this change (r04_k) toggled the path inside ONE binary whose kernel already carried the extra registers on both
-    // sides and so reported a gain: an environment A/B is only valid when the code it toggles is compiled separately (the Delta-in
-    // form is a template parameter since).
-    static const bool delta_in = [] { const char* e = getenv("TA355_ATTN_DELTA_FUSED"); return e && *e == '1'; }();
-    const bool fused_path = fuse_post && !(g && (g->dqn || g->dkn));
-    if (!attn_done && !(fused_path && delta_in)) RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
-    if (attn_done) {
-    } else if (fused_path && delta_in) {
-      RC(ta_attention_bwd_qkv_o(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.ao, p.lse, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
-                                w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
-    } else if (fused_path) {
+    // frozen q_norm / k_norm: the q|k|v post-processing backward rides in the attention backward's epilogue; trainable norms (full
+    // fine-tuning) take head-major dQ / dK / dV + ta_lm_qkv_post_bwd, which also produces d(q_norm) / d(k_norm).
+    // (Round 4 built two more forms and removed them in round 5 after measuring them slower: one workgroup per (clip, kv head) with
+    // K / V resident -- 92.8 us warm / 117.5 cold per layer against 91.8 / 106.0 here --, and Delta = rowsum(dO o O) inside this
+    // kernel -- 87.3 us against 67.2 + 9.5; profiles/r04_g/h_*, r04_zj_*.)
+    RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
+    if (!(g && (g->dqn || g->dkn))) {
       RC(ta_attention_bwd_qkv(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
                               w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     } else {
@@ -855,7 +731,6 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     return TA_ERR_LAUNCH;
   if (d_audio && src_row) RC(ta_audio_grad_gather(src_row, dx, d_audio, M, d.D, st));
   if (wg && wg->dembed) RC(ta_embed_grad_scatter(ids, src_row, dx, wg->dembed, M, d.D, w->vocab, st));
-  if (side && side_n > 0 && hipStreamWaitEvent(st, side->join[(side_n - 1) & 1], 0) != hipSuccess) return TA_ERR_LAUNCH;   // join
   if (lora_parts) {                                  // second level of the adapter-gradient reduction: every layer, every kind, one launch
     LoraReduceDesc rd;
     float* const f0[8] = {lora_grads[0].dla_qkv, lora_grads[0].dlb_qkv, lora_grads[0].dla_o, lora_grads[0].dlb_o,

@@ -900,14 +900,13 @@ __device__ __forceinline__ void qkv_post_bwd_tile(const char* st, const QkvPostB
 
 // ============================================================================ backward: dQ
 // grid (q tiles, Hq, B).  dQ^T[d,q] = sum_key K^T[d,key] dS^T[key,q],  dS = P o (dP - Delta) * scale
-template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
+template <int HD, bool CAUSAL>
 __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ KT,
                                                  const bf16_t* __restrict__ dO, long dO_stride,
                                                  const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                  const int* __restrict__ kmask, bf16_t* __restrict__ dQ,
-                                                 int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F,
-                                                 const bf16_t* __restrict__ Otok) {
+                                                 int B, int Hq, int Hkv, int L, int Lp, float scale, const QkvPostBwd& F) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int nq = (L + 63) / 64, grp = Hq / Hkv;
   int group, member;
@@ -929,26 +928,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     dof[ks] = *(const bf16x8*)(dOb + (long)qr * dO_stride + ks * 32 + g * 8);
   }
   const float lse2 = LSE[(long)(b * Hq + h) * L + qr] * LOG2E;
-  // round 4: Delta = rowsum(dO o O) computed HERE when O is given (token-major with dO's row stride) -- the lane's own dO fragments
-  // times the same elements of O, summed over the four lanes of the row -- instead of read from the array ta_attn_bwd_prep wrote
-  float delta;
-  if constexpr (DIN) {
-    const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD;
-    float part = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < HD / 32; ++ks) {
-      const uint4 o4 = *(const uint4*)(orow + ks * 32 + g * 8);
-      const uint32_t ou[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t du = ((const uint32_t*)&dof[ks])[e];
-        part += bf2f((bf16_t)(du & 0xffff)) * bf2f((bf16_t)(ou[e] & 0xffff)) + bf2f((bf16_t)(du >> 16)) * bf2f((bf16_t)(ou[e] >> 16));
-      }
-    }
-    delta = group_sum(part);
-  } else {
-    delta = Delta[(long)(b * Hq + h) * L + qr];
-  }
+  const float delta = Delta[(long)(b * Hq + h) * L + qr];
   f32x4 dq[HD / 16];
 #pragma unroll
   for (int i = 0; i < HD / 16; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1032,7 +1012,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
 // ============================================================================ backward: dK, dV
 // grid (key tiles, Hkv, B); loops over the Hq/Hkv query heads of the group and over query tiles.
 //   dV^T[d,key] += dO^T[d,q] P[q,key]      dK^T[d,key] += Q^T[d,q] dS[q,key]
-template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
+template <int HD, bool CAUSAL>
 __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
                                                   const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                   const bf16_t* __restrict__ dO, long dO_stride,
@@ -1040,7 +1020,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
                                                   const float* __restrict__ LSE, const float* __restrict__ Delta,
                                                   const int* __restrict__ kmask, bf16_t* __restrict__ dK,
                                                   bf16_t* __restrict__ dV, int B, int Hq, int Hkv, int L, int Lp,
-                                                  float scale, const QkvPostBwd& F, const bf16_t* __restrict__ Otok) {
+                                                  float scale, const QkvPostBwd& F) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int grp = Hq / Hkv;
   int group, kt_idx;
@@ -1068,7 +1048,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   static_assert(HD == 128, "the DMA staging of the backward is written for head_dim 128");
   const unsigned lds0 = lds_addr_of(smem);
   float pl = 1.0e30f, pd = 0.f;
-  [[maybe_unused]] uint4 po[DIN ? 4 : 1];              // (DIN) this thread's quarter of an O row: 32 of its 128 elements, raw
   int it = 0;
   auto issue = [&](int hh, int qt, int buf) {
     const int h = hk * grp + hh, q0 = qt * 64;
@@ -1080,13 +1059,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
     pl = 1.0e30f; pd = 0.f;
     if (tid < 64 && q0 + tid < L) {
       pl = LSE[(long)(b * Hq + h) * L + q0 + tid];
-      if constexpr (!DIN) pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
-    }
-    if constexpr (DIN) {                               // four threads per query row (tid >> 2), 32 elements each
-      const int qr = min(q0 + (tid >> 2), L - 1);
-      const bf16_t* orow = Otok + ((long)b * L + qr) * dO_stride + (long)h * HD + (tid & 3) * 32;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) po[j] = *(const uint4*)(orow + j * 8);
+      pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
     }
   };
   if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
@@ -1097,25 +1070,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       char* dOs = Qs + RowTile<HD>::BYTES;
       float* Ls = (float*)(dOs + RowTile<HD>::BYTES);  // [64] lse * log2e
       float* Ds = Ls + 64;                             // [64] delta
-      if (tid < 64) { Ls[tid] = pl * LOG2E; if constexpr (!DIN) Ds[tid] = pd; }
+      if (tid < 64) { Ls[tid] = pl * LOG2E; Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if constexpr (DIN) {                             // Delta of the tile's 64 queries from the dO tile that has just landed
-        const int row = tid >> 2, quarter = tid & 3;
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint4 d4 = *(const uint4*)(dOs + RowTile<HD>::off(row, quarter * 4 + j));
-          const uint32_t du[4] = {d4.x, d4.y, d4.z, d4.w}, ou[4] = {po[j].x, po[j].y, po[j].z, po[j].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            part += bf2f((bf16_t)(du[e] & 0xffff)) * bf2f((bf16_t)(ou[e] & 0xffff)) + bf2f((bf16_t)(du[e] >> 16)) * bf2f((bf16_t)(ou[e] >> 16));
-        }
-        part += dpp_mov<0xB1>(part);                   // quad_perm [1,0,3,2]
-        part += dpp_mov<0x4E>(part);                   // quad_perm [2,3,0,1]
-        if (quarter == 0) Ds[row] = part;
-        __syncthreads();
-      }
       if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
       else if (hh + 1 < grp) issue(hh + 1, qt_begin, (it + 1) & 1);
       f32x4 s[4], dp[4];
@@ -1189,7 +1146,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
 // One launch for both halves of the backward: blocks [0, n_dkv) run the dK / dV body, the rest the dQ body.  The two
 // are independent (both only read Q, K, V, dO), so a single grid lets the dQ workgroups fill the CUs while the longer
 // dK / dV ones drain, without a second stream or a kernel boundary in between.  The heavier dK / dV blocks go first.
-template <int HD, bool CAUSAL, bool DIN = false>      // DIN: Delta computed inside from O (Otok); else read from the array
+template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ QT,
                                                        const bf16_t* __restrict__ K, const bf16_t* __restrict__ KT,
                                                        const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, long dO_stride,
@@ -1197,360 +1154,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(const bf16_t* __restri
                                                        const float* __restrict__ Delta, const int* __restrict__ kmask,
                                                        bf16_t* __restrict__ dQ, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV,
                                                        int B, int Hq, int Hkv, int L, int Lp, float scale, int n_dkv,
-                                                       const QkvPostBwd F, const bf16_t* __restrict__ Otok) {
+                                                       const QkvPostBwd F) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (n_dkv < 0) {
-    // interleaved order (TA355_ATTN_BWD_MERGED=2): the nq dK/dV workgroups and the grp * nq dQ workgroups of one (clip, kv head) get CONSECUTIVE ids
-    // on the same XCD, so Q / K / V / dO of that group are pulled into that L2 once for all nine of them (with every dK/dV block
-    // ahead of every dQ block the two halves fetched their operands separately: 262 MB per launch, L2 hit rate 0.49)
-    const int nq = (L + 63) / 64, grp = Hq / Hkv, gsz = nq + grp * nq;
-    int group, member;
-    if (!decode_group(blockIdx.x, gsz, B * Hkv, group, member)) return;
-    const int xcd = group & 7, j = group >> 3;
-    if (member < nq)
-      attn_bwd_dkv_body<HD, CAUSAL, DIN>(smem, (j * nq + member) * 8 + xcd, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
-    else
-      attn_bwd_dq_body<HD, CAUSAL, DIN>(smem, (j * grp * nq + (member - nq)) * 8 + xcd, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
-    return;
-  }
   if ((int)blockIdx.x < n_dkv)
-    attn_bwd_dkv_body<HD, CAUSAL, DIN>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F, Otok);
+    attn_bwd_dkv_body<HD, CAUSAL>(smem, blockIdx.x, Q, QT, K, V, dO, dO_stride, dOT, LSE, Delta, kmask, dK, dV, B, Hq, Hkv, L, Lp, scale, F);
   else
-    attn_bwd_dq_body<HD, CAUSAL, DIN>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F, Otok);
+    attn_bwd_dq_body<HD, CAUSAL>(smem, blockIdx.x - n_dkv, Q, K, V, KT, dO, dO_stride, LSE, Delta, kmask, dQ, B, Hq, Hkv, L, Lp, scale, F);
 }
 
-
-// ============================================================================ backward, short sequences (LM, L <= 192): ONE workgroup per (clip, kv head)
-// Round 4.  The tiled backward above runs nine workgroups per (clip, kv head) -- three dK/dV key tiles + 2 x 3 dQ query tiles --
-// that re-stage K / V resp. Q / dO for one another (198 MB fetched per launch for ~75 MB of operands, L2 hit rate 0.50), each a
-// short chain of dependent memory phases, plus a separate pass for Delta = rowsum(dO o O).  Here the whole GQA group lives in one
-// 4-wave workgroup (B x Hkv = 256 of them at B = 32: one per CU, the whole register file):
-//   * K and V of the kv head stay in LDS for the life of the workgroup (3 + 3 row tiles, 96 KB), by DMA, once;
-//   * the 2 x 3 (query head, query tile) pairs are ONE sequence of iterations: Q / dO tile by DMA into a single buffer -- the next
-//     pair's request goes out as soon as the last MFMA of this one has read the buffer, i.e. it travels under the dQ epilogue;
-//   * dK^T / dV^T of ALL 192 keys accumulate across both query heads in AGPRs (2 x 3 x 8 fragments = 192 registers; inline-assembly
-//     MFMAs with "+a" operands -- this file is built with -amdgpu-mfma-vgpr-form, whose accumulators are VGPRs), dQ^T of the
-//     current pair in VGPRs;
-//   * Delta is computed here: the lane's own dO fragments (LDS) times the same elements of O (16-B global loads requested one
-//     iteration ahead), reduced over the four lanes of a row -- no attn_bwd_prep launch, no Delta array;
-//   * the q|k|v post-processing backward (RoPE^T, RMSNorm backward, token-major store) is the epilogue of every dQ tile and of the
-//     six dK / dV tiles, through a 32-row f32 image (two passes per tile: the full 64-row image does not fit next to K, V, Q, dO).
-// Both score orientations are still computed (lane <-> query for dQ, lane <-> key for dK / dV: 7 products per tile pair instead of
-// the 5 a register transpose of P / dS would need) -- the kernel is latency-bound, not MFMA-bound.  Same arithmetic per element as the
-// tiled kernels (same exp2 arguments, same bf16 rounding of P / dS, fp32 accumulation in key / query order), frozen q_norm / k_norm
-// only (the trainable-norm case keeps the tiled path).
-constexpr int BWG_MAXT = 3;                                   // key / query tiles of 64: L <= 192
-constexpr int BWG_HALF = 32 * QP_PITCH;                       // the f32 image of half a tile
-constexpr int BWG_LDS = 2 * BWG_MAXT * RowTile<128>::BYTES + 2 * RowTile<128>::BYTES + BWG_HALF + (64 + 64 + 64 * BWG_MAXT) * 4;
-__device__ __forceinline__ void mfma_acc_a(f32x4& c, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-// half h (rows 32 h .. 32 h + 31) of a 64-row tile: the two waves that own those rows write their accumulators
-__device__ __forceinline__ void qkv_stage_half(char* st, const f32x4* acc, int wave, int l15, int g, int h) {
-  if ((wave >> 1) != h) return;
-#pragma unroll
-  for (int dt = 0; dt < 8; ++dt)
-    *(float4*)(st + ((wave & 1) * 16 + l15) * QP_PITCH + (dt * 16 + g * 4) * 4) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
-}
-// qkv_post_bwd_tile for the 32 staged rows of half h of the tile whose first sequence row is row0 (all 256 threads: 8 lanes per row)
-__device__ __forceinline__ void qkv_post_bwd_half(const char* st, const QkvPostBwd& F, int sec, int b, int row0, int h, int L, int head,
-                                                  int Hq, int Hkv, int tid) {
-  constexpr int HD = 128;
-  const long ld = (long)(Hq + 2 * Hkv) * HD;
-  const int Hs = sec == 0 ? Hq : Hkv, j = tid & 7;
-  const long coff = (long)(sec == 0 ? head : (sec == 1 ? Hq + head : Hq + Hkv + head)) * HD;
-  float w1[8], w2[8];
-  if (sec < 2) {
-    const float* nw = sec == 0 ? F.qn_w : F.kn_w;
-    const float4 a = *(const float4*)(nw + 8 * j), b4 = *(const float4*)(nw + 8 * j + 4), c = *(const float4*)(nw + 64 + 8 * j), d = *(const float4*)(nw + 64 + 8 * j + 4);
-    w1[0] = a.x; w1[1] = a.y; w1[2] = a.z; w1[3] = a.w; w1[4] = b4.x; w1[5] = b4.y; w1[6] = b4.z; w1[7] = b4.w;
-    w2[0] = c.x; w2[1] = c.y; w2[2] = c.z; w2[3] = c.w; w2[4] = d.x; w2[5] = d.y; w2[6] = d.z; w2[7] = d.w;
-  }
-  const int tl = tid >> 3, l = row0 + h * 32 + tl;
-  const bool live = l < L;
-  const int lc = live ? l : L - 1;
-  const long tok = (long)b * L + lc;
-  const float* sr = (const float*)(st + tl * QP_PITCH);
-  float d1[8], d2[8];
-  { const float4 a = *(const float4*)(sr + 8 * j), b4 = *(const float4*)(sr + 8 * j + 4), c = *(const float4*)(sr + 64 + 8 * j), d = *(const float4*)(sr + 64 + 8 * j + 4);
-    d1[0] = a.x; d1[1] = a.y; d1[2] = a.z; d1[3] = a.w; d1[4] = b4.x; d1[5] = b4.y; d1[6] = b4.z; d1[7] = b4.w;
-    d2[0] = c.x; d2[1] = c.y; d2[2] = c.z; d2[3] = c.w; d2[4] = d.x; d2[5] = d.y; d2[6] = d.z; d2[7] = d.w; }
-  if (sec < 2) {
-    const bf16_t* src = F.qkv0 + tok * ld + coff;
-    const uint4 xa = *(const uint4*)(src + 8 * j), xb = *(const uint4*)(src + 64 + 8 * j);
-    const uint32_t ua[4] = {xa.x, xa.y, xa.z, xa.w}, ub[4] = {xb.x, xb.y, xb.z, xb.w};
-    float x1[8], x2[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      x1[2 * k] = bf2f((bf16_t)(ua[k] & 0xffff)); x1[2 * k + 1] = bf2f((bf16_t)(ua[k] >> 16));
-      x2[2 * k] = bf2f((bf16_t)(ub[k] & 0xffff)); x2[2 * k + 1] = bf2f((bf16_t)(ub[k] >> 16));
-    }
-    const int p = F.pos ? F.pos[tok] : lc;
-    const float4 c0 = *(const float4*)(F.cosT + (long)p * 64 + 8 * j), c1 = *(const float4*)(F.cosT + (long)p * 64 + 8 * j + 4);
-    const float4 s0 = *(const float4*)(F.sinT + (long)p * 64 + 8 * j), s1 = *(const float4*)(F.sinT + (long)p * 64 + 8 * j + 4);
-    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float r = (sec == 0 ? F.rq : F.rk)[tok * Hs + head];
-    float dot = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dn1 = d1[e] * cs[e] + d2[e] * sn[e], dn2 = d2[e] * cs[e] - d1[e] * sn[e];     // RoPE^T
-      x1[e] *= r; x2[e] *= r;                                                               // x-hat
-      d1[e] = dn1 * w1[e]; d2[e] = dn2 * w2[e];
-      dot += d1[e] * x1[e] + d2[e] * x2[e];
-    }
-    const float md = oct_sum8(dot) / (float)HD;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { d1[e] = r * (d1[e] - x1[e] * md); d2[e] = r * (d2[e] - x2[e] * md); }
-  }
-  if (live) {
-    bf16_t* dst = F.dqkv + ((long)b * L + l) * ld + coff;
-    *(uint4*)(dst + 8 * j) = make_uint4(pack2bf(d1[0], d1[1]), pack2bf(d1[2], d1[3]), pack2bf(d1[4], d1[5]), pack2bf(d1[6], d1[7]));
-    *(uint4*)(dst + 64 + 8 * j) = make_uint4(pack2bf(d2[0], d2[1]), pack2bf(d2[2], d2[3]), pack2bf(d2[4], d2[5]), pack2bf(d2[6], d2[7]));
-  }
-}
-
-// NQ x GRP (query tiles x query heads per kv head) are compile-time and the pair sequence is straight-line code: with the pairs of the
-// later key tiles behind run-time branches the register allocator split the live ranges of the 192 AGPR accumulators at every merge
-// point (755 v_accvgpr moves, 600 B of scratch); unrolled there is not one accumulator move in the kernel.
-template <int NQ, int GRP>
-__global__ __launch_bounds__(256) void attn_bwd_gqa_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO, long dO_stride,
-                                                           const bf16_t* __restrict__ O, const float* __restrict__ LSE,
-                                                           const int* __restrict__ kmask, int B, int Hq, int Hkv, int L, float scale,
-                                                           const QkvPostBwd F, int dbg) {
-  constexpr int HD = 128, TB = RowTile<HD>::BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: region A = [K tile 0..2 | Q tile] (64 KB), region B = [dO tile | V tile 0..2] (64 KB), then the epilogue image and the small
-  // arrays.  Every fragment address is  (one of a few per-lane base registers) + (a compile-time offset < 64 KB): the XOR swizzle of
-  // the row tiles permutes a lane's 16-B chunks by a LANE constant, so a chunk offset per k-step / per column block is computed once
-  // per kernel -- computed in place (RowTile::off per access) they were ~400 VALU instructions per tile pair, and hoisted by the
-  // compiler ~100 live address registers.
-  char* RA = smem;
-  char* RB = smem + 4 * TB;
-  char* St = RB + 4 * TB;                               // 32 rows of f32 for the fused epilogue
-  float* Ls = (float*)(St + BWG_HALF);                  // [64] lse * log2e of the current query tile
-  float* Ds = Ls + 64;                                  // [64] Delta
-  int* Ms = (int*)(Ds + 64);                            // [192] key mask (1 = attend)
-  constexpr int A_K = 0, A_Q = 3 * TB, B_DO = 0, B_V = TB;   // tile offsets inside the regions
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
-  constexpr int grp = GRP, nq = NQ;
-  const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
-  const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
-  const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
-  const float sl2 = scale * LOG2E;
-  const unsigned ldsA = lds_addr_of(RA), ldsB = lds_addr_of(RB);
-
-  // ---- per-lane chunk offsets (bytes inside a tile, row part included)
-  //   fo[ks]: 16-B chunk ks * 4 + g of row l15 (+ 16 X rows = + 4096 X):   RowTile::off(X * 16 + l15, ks * 4 + g)
-  //   to[dt]: the ds_read_b64_tr_b16 address of column block dt, row 4 g + (l15 >> 2) (+ 16 X rows):   read_colfrag_tr's r0 / chunk / half
-  int fo[4], to[8];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fo[ks] = l15 * 256 + (((ks * 4 + g) ^ l15) << 4);
-  {
-    const int r = 4 * g + (l15 >> 2), a = (l15 & 3) >> 1, half = l15 & 1;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) to[dt] = r * 256 + (((2 * dt + a) ^ r) << 4) + half * 8;
-  }
-  auto frag = [&](const char* region, int tile_off, int X, int ks) -> bf16x8 {           // row X * 16 + l15 of a tile, k-step ks
-    return *(const bf16x8*)(region + fo[ks] + (tile_off + X * 4096));
-  };
-  auto colfrag = [&](const char* region, int tile_off, int dt, int kp) -> bf16x8 {       // read_colfrag_tr(tile, dt, l15, 32 kp + 4 g, 32 kp + 16 + 4 g)
-    const char* pa = region + to[dt] + (tile_off + kp * 8192);
-    const bf16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)pa);
-    const bf16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(pa + 4096));
-    return (bf16x8){x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-  };
-
-  // ---- requests of one (head, query tile) pair: the two tiles by DMA, the lane's own O elements and LSE as raw loads (waited for at
-  //      the top of the pair's iteration; no arithmetic on them here -- it would put the wait right behind the DMA issues)
-  uint4 ofr[4];
-  float lse_raw = 0.f;
-  auto request = [&](int hh, int qt) {
-    const int h = hk * grp + hh, q0 = qt * 64;
-    dma_rowtile128(Q + ((long)(b * Hq + h) * L) * HD, HD, q0, L, ldsA + A_Q, wave, lane);
-    dma_rowtile128(dO + (long)b * L * dO_stride + (long)h * HD, dO_stride, q0, L, ldsB + B_DO, wave, lane);
-    const int qr = min(q0 + wave * 16 + l15, L - 1);
-    const bf16_t* orow = O + ((long)b * L + qr) * dO_stride + (long)h * HD;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ofr[ks] = *(const uint4*)(orow + ks * 32 + g * 8);
-    lse_raw = LSE[(long)(b * Hq + h) * L + qr];
-  };
-  for (int t = 0; t < nq; ++t) {
-    dma_rowtile128(Kb, HD, t * 64, L, ldsA + A_K + t * TB, wave, lane);
-    dma_rowtile128(Vb, HD, t * 64, L, ldsB + B_V + t * TB, wave, lane);
-  }
-  for (int i = tid; i < 64 * BWG_MAXT; i += 256) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
-  request(0, 0);
-
-  f32x4 dk[BWG_MAXT][8], dv[BWG_MAXT][8];               // AGPRs: d(K)^T, d(V)^T of this wave's 16 keys of every key tile
-#pragma unroll
-  for (int t = 0; t < BWG_MAXT; ++t)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { dk[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-  constexpr int npairs = grp * nq;
-  auto iteration = [&](auto it_tag) {
-    constexpr int it = decltype(it_tag)::value;
-    constexpr int hh = it / nq, qt = it % nq;
-    const int h = hk * grp + hh, q0 = qt * 64;
-    const int qrow = q0 + wave * 16 + l15;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // Q / dO tile (and, the first time, K / V and the mask) have landed
-    // ---- the lane's own query row: Q and dO fragments, Delta, LSE
-    bf16x8 qf[4], dof[4];
-    float part = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = frag(RA, A_Q, wave, ks);
-      dof[ks] = frag(RB, B_DO, wave, ks);
-      const uint32_t ou[4] = {ofr[ks].x, ofr[ks].y, ofr[ks].z, ofr[ks].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t du = ((const uint32_t*)&dof[ks])[e];
-        part += bf2f((bf16_t)(du & 0xffff)) * bf2f((bf16_t)(ou[e] & 0xffff)) + bf2f((bf16_t)(du >> 16)) * bf2f((bf16_t)(ou[e] >> 16));
-      }
-    }
-    const float delta = group_sum(part);               // over the four lanes (g) of the row: all 128 dims
-    const float lse2 = qrow < L ? lse_raw * LOG2E : 1.0e30f;
-    if (g == 0) { Ls[wave * 16 + l15] = lse2; Ds[wave * 16 + l15] = delta; }
-    __syncthreads();                                   // Ls / Ds of the tile are complete (the dK / dV part reads all 64)
-    f32x4 dq[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto pair = [&](auto kt_tag) {
-      constexpr int KT = decltype(kt_tag)::value;
-      constexpr int key0 = KT * 64;
-      constexpr bool DIAG = KT == qt;                    // only the diagonal tile pair needs the causal compare
-      // ---- lane <-> query: S^T = K Q^T, dP^T = V dO^T, dS^T -> dQ^T += K^T dS^T
-      {
-        f32x4 s[4], dp[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          s[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          dp[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            s[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(RA, A_K + KT * TB, kk, ks), qf[ks], s[kk], 0, 0, 0);
-            dp[kk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(RB, B_V + KT * TB, kk, ks), dof[ks], dp[kk], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int4 mk = *(const int4*)(Ms + key0 + kk * 16 + g * 4);
-          const int mkv[4] = {mk.x, mk.y, mk.z, mk.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = key0 + kk * 16 + g * 4 + r;
-            bool v = mkv[r] != 0;                        // (rows past L carry lse2 = 1e30: exp2 gives 0)
-            if (DIAG) v = v && (key <= qrow);
-            const float e = __builtin_amdgcn_exp2f(s[kk][r] * sl2 - lse2);
-            const float p = v ? e : 0.f;
-            s[kk][r] = p * (dp[kk][r] - delta) * scale;
-          }
-        }
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-          const bf16x8 dsb = pack_p(s[2 * kp], s[2 * kp + 1]);
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colfrag(RA, A_K + KT * TB, dt, kp), dsb, dq[dt], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);                 // (the two orientations one after the other: interleaved they need > 256 VGPRs)
-      // ---- lane <-> key: S = Q K^T, dP = dO V^T, P / dS -> dV^T += dO^T P, dK^T += Q^T dS
-      {
-        const int krow = key0 + wave * 16 + l15;
-        const bool kvalid = Ms[krow] != 0;               // (0 for keys past L)
-        bf16x8 kf[4], vf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          kf[ks] = frag(RA, A_K + KT * TB, wave, ks);
-          vf[ks] = frag(RB, B_V + KT * TB, wave, ks);
-        }
-        f32x4 s[4], dp[4], ds[4];
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) {
-          s[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          dp[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            s[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(RA, A_Q, qs, ks), kf[ks], s[qs], 0, 0, 0);
-            dp[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag(RB, B_DO, qs, ks), vf[ks], dp[qs], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) {
-          const float4 ls = *(const float4*)(Ls + qs * 16 + g * 4);
-          const float4 dl = *(const float4*)(Ds + qs * 16 + g * 4);
-          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
-          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = q0 + qs * 16 + g * 4 + r;
-            bool v = kvalid;                             // (queries past L carry Ls = 1e30)
-            if (DIAG) v = v && (krow <= q);
-            const float e = __builtin_amdgcn_exp2f(s[qs][r] * sl2 - lsv[r]);
-            const float p = v ? e : 0.f;
-            s[qs][r] = p;
-            ds[qs][r] = p * (dp[qs][r] - dlv[r]) * scale;
-          }
-        }
-#pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          const bf16x8 pb = pack_p(s[2 * qp], s[2 * qp + 1]);
-          const bf16x8 dsb = pack_p(ds[2 * qp], ds[2 * qp + 1]);
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt) {
-            const bf16x8 da = colfrag(RB, B_DO, dt, qp);
-            const bf16x8 qa = colfrag(RA, A_Q, dt, qp);
-            mfma_acc_a(dv[KT][dt], da, pb);
-            mfma_acc_a(dk[KT][dt], qa, dsb);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    pair(std::integral_constant<int, 0>{});
-    if constexpr (qt >= 1) pair(std::integral_constant<int, 1>{});
-    if constexpr (qt >= 2) pair(std::integral_constant<int, 2>{});
-
-    __syncthreads();                                   // every wave is done with the Q / dO tiles (and with Ls / Ds)
-    if constexpr (it + 1 < npairs) request((it + 1) / nq, (it + 1) % nq);      // travels under this pair's epilogue
-    // ---- dQ of this pair: q|k|v post-processing backward through the half-tile image
-    if (!(dbg & 1))
-    for (int hf = 0; hf < 2; ++hf) {
-      qkv_stage_half(St, dq, wave, l15, g, hf);
-      __syncthreads();
-      qkv_post_bwd_half(St, F, 0, b, q0, hf, L, h, Hq, Hkv, tid);
-      __syncthreads();
-    }
-    else if (dq[0][0] == 1.2345f) F.dqkv[tid] = 0;
-  };
-  iteration(std::integral_constant<int, 0>{});
-  if constexpr (npairs > 1) iteration(std::integral_constant<int, 1>{});
-  if constexpr (npairs > 2) iteration(std::integral_constant<int, 2>{});
-  if constexpr (npairs > 3) iteration(std::integral_constant<int, 3>{});
-  if constexpr (npairs > 4) iteration(std::integral_constant<int, 4>{});
-  if constexpr (npairs > 5) iteration(std::integral_constant<int, 5>{});
-  static_assert(npairs <= 6, "unrolled pair sequence");
-  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the last accumulating MFMAs -> VALU reads of dk / dv
-  // ---- dK, dV of every key tile
-#pragma unroll
-  for (int t = 0; t < BWG_MAXT; ++t) {
-    if (t < nq && !(dbg & 2)) {
-#pragma unroll
-      for (int sec = 1; sec <= 2; ++sec) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          qkv_stage_half(St, sec == 1 ? dk[t] : dv[t], wave, l15, g, hf);
-          __syncthreads();
-          qkv_post_bwd_half(St, F, sec, b, t * 64, hf, L, hk, Hq, Hkv, tid);
-          __syncthreads();
-        }
-      }
-    }
-  }
-}
 
 // ----------------------------------------------------------------------------- C-ABI
 template <int HD> static size_t fwd_lds() { return RowTile<HD>::BYTES + (HD + 16) * CT_STRIDE + 64 * 4; }
@@ -1569,8 +1180,7 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
   // LM with a short prompt: the whole sequence of a (clip, kv head) lives in LDS, one workgroup serves the GQA group
   if (!lay_in) {
     const int grp = Hq / Hkv;
-    static const bool gqa_off = [] { const char* e = getenv("TA355_ATTN_GQA"); return e && *e == '0'; }();
-    if (!gqa_off && head_dim == 128 && causal && L <= 192 && grp * ((L + 31) / 32) <= 12) {
+    if (head_dim == 128 && causal && L <= 192 && grp * ((L + 31) / 32) <= 12) {
       constexpr int MAXT = 3, QS = 2, NW = 6;          // 6 waves x 2 passes x 32 queries = 384 query rows per workgroup
       const size_t lds = MAXT * (RowTile<128>::BYTES + (128 + 16) * CT_STRIDE) + MAXT * 64 * 4;
       static bool attr = false;
@@ -1589,7 +1199,6 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
   const long vor = lay.v_bs | lay.v_hs | lay.v_rs;
   const uintptr_t vp = (uintptr_t)VT;
   int valign = (!(vor & 7) && !(vp & 15)) ? 0 : ((!(vor & 3) && !(vp & 7)) ? 1 : 2);
-  { const char* e = getenv("TA355_ATTN_NOPEEL"); if (e && *e == '1') valign |= 4; }
   // encoder (hd 64, S = 500, non-causal): 128 query rows per workgroup; LM (hd 128, short causal L): 64
   const int qsub = (head_dim == 64) ? 2 : 1;
   dim3 grid(grouped_grid((Hq / Hkv) * ta_cdiv(L, 64 * qsub), B * Hkv)), blk(256);
@@ -1607,9 +1216,8 @@ extern "C" int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT,
 
 static int attention_bwd_launch(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
                                 const float* Delta, const int* kmask, void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L,
-                                int Lp, int head_dim, int causal, float scale, const QkvPostBwd& F, hipStream_t st,
-                                const void* Otok = nullptr) {
-  if (!Delta && !Otok) return TA_ERR_ARG;
+                                int Lp, int head_dim, int causal, float scale, const QkvPostBwd& F, hipStream_t st) {
+  if (!Delta) return TA_ERR_ARG;
   if (B <= 0 || L <= 0) return TA_OK;
   if (Hq % Hkv || Lp % 64 || Lp < L || head_dim != 128) return TA_ERR_ARG;
   constexpr int HD = 128;
@@ -1619,59 +1227,20 @@ static int attention_bwd_launch(const void* Q, const void* K, const void* V, con
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<HD, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     attr_done = true;
   }
   const int n_dq = grouped_grid((Hq / Hkv) * ta_cdiv(L, 64), B * Hkv), n_dkv = grouped_grid(ta_cdiv(L, 64), B * Hkv);
   dim3 grid(n_dq + n_dkv), blk(256);
-  static const bool split = [] { const char* e = getenv("TA355_ATTN_BWD_MERGED"); return e && *e == '0'; }();   // experiment: two launches
-  // TA355_ATTN_BWD_MERGED=2 (experiment): the dK/dV and dQ workgroups of one (clip, kv head) interleaved on one XCD instead of every
-  // dK/dV block ahead of every dQ block: measured 45.42 vs 45.29 ms per step -- the heavier blocks first balance the tail better
-  // than the shared L2 lines help
-  static const bool interleaved = [] { const char* e = getenv("TA355_ATTN_BWD_MERGED"); return e && *e == '2'; }();
-  const int n_dkv_arg = interleaved ? -1 : n_dkv;
+  // One launch for both halves: the heavier dK / dV blocks first, the dQ blocks fill the CUs while they drain.  (Measured alternatives,
+  // removed in round 5: two launches -- +0.47 ms per step, r02; the dK/dV and dQ workgroups of one (clip, kv head) interleaved on
+  // one XCD -- 45.42 vs 45.29 ms per step: the heavier blocks first balance the tail better than the shared L2 lines help.)
   const bf16_t* nul = nullptr;
-#define BWD(C_, GRID_, NDKV_)                                                                                                       \
-  do {                                                                                                                              \
-    if (Otok)                                                                                                                       \
-      TA_LAUNCH((attn_bwd_kernel<HD, C_, true>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V, \
-                (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F, \
-                (const bf16_t*)Otok);                                                                                               \
-    else                                                                                                                            \
-      TA_LAUNCH((attn_bwd_kernel<HD, C_, false>), GRID_, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V, \
-                (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, NDKV_, F, \
-                (const bf16_t*)nullptr);                                                                                            \
-  } while (0)
-  if (split) {                                       // the same bodies as two launches: n_dkv = 0 (all dQ) resp. n_dkv = grid (all dK / dV)
-    if (causal) { BWD(true, dim3(n_dq), 0); BWD(true, dim3(n_dkv), n_dkv); }
-    else { BWD(false, dim3(n_dq), 0); BWD(false, dim3(n_dkv), n_dkv); }
-  } else if (causal) {
-    BWD(true, grid, n_dkv_arg);
-  } else {
-    BWD(false, grid, n_dkv_arg);
-  }
+#define BWD(C_)                                                                                                                     \
+  TA_LAUNCH((attn_bwd_kernel<HD, C_>), grid, blk, lds_kv, st, (const bf16_t*)Q, nul, (const bf16_t*)K, nul, (const bf16_t*)V,       \
+            (const bf16_t*)dO, dO_stride, nul, LSE, Delta, kmask, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, B, Hq, Hkv, L, Lp, scale, n_dkv, F)
+  if (causal) BWD(true);
+  else BWD(false);
 #undef BWD
-  TA_CHECK_LAUNCH();
-  return TA_OK;
-}
-
-// Round 4: the backward of the LM's short causal sequences as ONE workgroup per (clip, kv head) -- K / V resident in LDS, dK / dV of
-// both query heads accumulated in AGPRs, Delta computed inside (from O, token-major like dO), the q|k|v post-processing backward in
-// the epilogue.  head_dim 128, L <= 192, causal.  Returns TA_ERR_ARG outside that envelope (callers keep the tiled path).
-extern "C" int ta_attention_bwd_gqa(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
-                                    const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
-                                    const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
-                                    void* dqkv, int B, int Hq, int Hkv, int L, int head_dim, float scale, hipStream_t st) {
-  if (B <= 0 || L <= 0) return TA_OK;
-  if (!Q || !K || !V || !dO || !O || !LSE || !qkv0 || !dqkv || !rq || !rk || !qn_w || !kn_w || !cosT || !sinT) return TA_ERR_ARG;
-  if (head_dim != 128 || Hkv <= 0 || Hq != 2 * Hkv || L <= 128 || L > 64 * BWG_MAXT || (dO_stride % 8) != 0) return TA_ERR_ARG;   // 3 tiles x 2 heads
-  QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
-  static const int dbg = [] { const char* e = getenv("TA355_ATTN_BWD_GQA_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments: 1 no dQ epilogue, 2 no dK / dV epilogue (wrong results)
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_gqa_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BWG_LDS); attr = true; }
-  TA_LAUNCH((attn_bwd_gqa_kernel<3, 2>), dim3(B * Hkv), dim3(256), BWG_LDS, st, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-            (const bf16_t*)dO, dO_stride, (const bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, scale, F, dbg);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
@@ -1716,16 +1285,4 @@ extern "C" int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V,
   QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
   return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, Delta, kmask, nullptr, nullptr, nullptr, B, Hq, Hkv, L, Lp, head_dim, causal,
                               scale, F, st);
-}
-// round 4: the same without ta_attn_bwd_prep -- Delta = rowsum(dO o O) is computed inside both halves of the backward from O
-// (token-major, dO's row stride): one launch and one [B, Hq, L] array less per layer
-extern "C" int ta_attention_bwd_qkv_o(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const void* O,
-                                      const float* LSE, const int* kmask, const void* qkv0, const float* rq, const float* rk,
-                                      const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,
-                                      void* dqkv, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal, float scale,
-                                      hipStream_t st) {
-  if (!O || !qkv0 || !dqkv || !rq || !rk || !qn_w || !kn_w || !cosT || !sinT) return TA_ERR_ARG;
-  QkvPostBwd F = {(const bf16_t*)qkv0, rq, rk, qn_w, kn_w, cosT, sinT, pos, (bf16_t*)dqkv};
-  return attention_bwd_launch(Q, K, V, dO, dO_stride, LSE, nullptr, kmask, nullptr, nullptr, nullptr, B, Hq, Hkv, L, Lp, head_dim, causal,
-                              scale, F, st, O);
 }

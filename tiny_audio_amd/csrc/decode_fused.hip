@@ -506,7 +506,7 @@ int ta_i_dec_norm_linear(const float* x, const float* lnw, float eps, const void
   const dim3 blk(512);
   const DecPf pf = to_pf(next);
 #define DL(EPI_, UN_, COLS_) TA_LAUNCH((dec_linear_kernel<true, EPI_, UN_, COLS_, true>), dim3(ta_cdiv(N, COLS_) + pf_wgs(next, ta_cdiv(N, COLS_))), blk, 0, st, (const void*)x, lnw, eps, (const bf16_t*)W, out, (const float*)nullptr, M, N, K, ta_cdiv(N, COLS_), pf)
-  static const int qkv32 = [] { const char* e = getenv("TA355_DEC_QKV_COLS"); return !(e && atoi(e) == 16); }();   // 32 columns = 128 workgroups: with the cache prefetchers beside them 1.455 ms per token against 1.59 at 16 columns (r04_w)
+  constexpr bool qkv32 = true;   // 32 columns = 128 workgroups: with the cache prefetchers beside them 1.455 ms per token against 1.59 at 16 columns (r04_w)
   if (swiglu) { if (ks <= 4) DL(EPI_SWIGLU, 4, TA355_DEC_COLS_GU); else DL(EPI_SWIGLU, 8, TA355_DEC_COLS_GU); }
   else if (qkv32 && N % 32 == 0) { if (ks <= 4) DL(EPI_BF16, 4, 32); else DL(EPI_BF16, 8, 32); }
   else { if (ks <= 4) DL(EPI_BF16, 4, TA355_DEC_COLS_QKV); else DL(EPI_BF16, 8, TA355_DEC_COLS_QKV); }

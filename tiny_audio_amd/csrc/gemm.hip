@@ -520,8 +520,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v4(GemmArgs p) {
   };
   // The epilogue's constants of tile c into the stage whose wave window starts at `base` (see EPI_LDS_*): issued where the main
   // loop's LAST K tile would request its successor, waited for by that K tile's own vmcnt(0) + barriers.
-  constexpr bool GELU = ACT == 1 || ACT == 3;
-  constexpr bool ROPE = ACT == 2 || ACT == 4;
+  constexpr bool GELU = ACT == 1;
+  constexpr bool ROPE = ACT == 2;
   auto dma_epi = [&](const TileCtx& c, unsigned base) {
     const int te = fresh_tid();                                 // (keeps this address arithmetic out of the K loop's live ranges)
     if (c.biasp && te < BN2 / 4) {
@@ -1303,7 +1303,7 @@ bool g_log_on = false;
 std::vector<long> g_log;
 }  // namespace
 
-// Round 4: the product library carries the variants the launch-time model can choose (0-5, 10, 12) plus gemm_v7.hip's (13-15, opt-in);
+// The product library carries the variants the launch-time model can choose (0-5, 10, 12);
 // the ring form (6 / 7), the stamped timing builds (8 / 9), the 32x32x16 form of v5 (11) and v5's timing experiments exist only in a
 // library built with -DTA355_EXPERIMENTS (TA355_BUILD_EXPERIMENTS=1 for tiny_audio_amd/_lib.build; scripts/gemm_phase_times.py,
 // gemm_wg_life.py, gemm_v5_exp.py, gemm_ab.py --ring need it).  gemm.hip then compiles in ~55 s instead of ~100.
@@ -1316,20 +1316,25 @@ std::vector<long> g_log;
 // an experimental build corrupted a reported A/B in round 3).  ta_gemm_reload_knobs() re-reads the environment: tests and the A/B
 // scripts that switch a knob between launches call it (tiny_audio_amd/ops.py does so when it sees one of them change).
 struct GemmKnobs {
-  int variant, no96, v5_mink, v7_mask, v9_mask, ring, persist_kext, m32, group_m, group_m_auto, epi_narrow, dbg, persist;
+  int variant, no96, v5_mink, ring, persist_kext, m32, group_m, group_m_auto, epi_narrow, dbg, persist;
   double r320, r10, r12;
   void load() {
     auto s = [](const char* n) -> const char* { const char* v = getenv(n); return (v && *v) ? v : nullptr; };
     auto i = [&](const char* n, int d) { const char* v = s(n); return v ? atoi(v) : d; };
-    auto f = [&](const char* n, double d) { const char* v = s(n); return v ? atof(v) : d; };
     variant = i("TA355_GEMM_VARIANT", -1);        // force one tile variant (tests, microbenchmarks)
+    dbg = 0;
+    if (i("TA355_GELU_LUT", 1) == 0) dbg |= 8;    // arithmetic erf-GELU instead of the chord table (the tests compare both)
+    // The product library has exactly these two run-time knobs.  Everything below is the measured default; an EXPERIMENT build
+    // (TA355_BUILD_EXPERIMENTS=1) reads the environment for them as rounds 1-4 did (scripts/gemm_*.py).
+    no96 = 0; r320 = TA355_RATE_256x320_PP; r10 = TA355_RATE_192x128; r12 = TA355_RATE_192x256_PP; v5_mink = 2048; ring = 0;
+    persist_kext = 0; m32 = 0; group_m = 0; group_m_auto = 0; epi_narrow = 0; persist = 1;
+#ifdef TA355_EXPERIMENTS
+    auto f = [&](const char* n, double d) { const char* v = s(n); return v ? atof(v) : d; };
     no96 = i("TA355_GEMM_NO96", 0) == 1;
     r320 = f("TA355_RATE_256x320", TA355_RATE_256x320_PP);
     r10 = f("TA355_RATE_192x128", TA355_RATE_192x128);
     r12 = f("TA355_RATE_192x256", TA355_RATE_192x256_PP);
     v5_mink = i("TA355_V5_MINK", 2048);
-    v7_mask = i("TA355_V7_MASK", 0);
-    v9_mask = i("TA355_V9_MASK", 0);
     ring = i("TA355_GEMM_RING", 0) == 1;
     persist_kext = i("TA355_GEMM_PERSIST_KEXT", 0) == 1;
     m32 = i("TA355_GEMM_M32", 0) == 1;
@@ -1337,9 +1342,9 @@ struct GemmKnobs {
     group_m_auto = i("TA355_GROUP_M_AUTO", 0) == 1;
     epi_narrow = i("TA355_EPI_WIDE", 1) == 0;
     persist = i("TA355_GEMM_PERSIST", 1);         // 0: one workgroup per tile (v2); 2: persistent only for launches of more than one round
-    dbg = i("TA355_GEMM_DEBUG", 0);               // experiments: 1 no epilogue stores, 2 one K tile only, 4 life stamps, ...
-    if (i("TA355_GELU_LUT", 1) == 0) dbg |= 8;    // arithmetic erf-GELU instead of the chord table (A/B, tests)
+    dbg |= i("TA355_GEMM_DEBUG", 0);              // 1 no epilogue stores, 2 one K tile only, 4 life stamps, ...
     if (i("TA355_GEMM_RES_INIT", 1) == 0) dbg |= 1 << 20;   // bf16 residual added in the epilogue instead of being the accumulators' start
+#endif
   }
 };
 static GemmKnobs& knobs() {
@@ -1353,9 +1358,9 @@ static int pick_variant(int M, int N, int K, int splits) {
   const GemmKnobs& kn = knobs();
   const int forced = kn.variant;
 #ifdef TA355_EXPERIMENTS
-  if (forced >= 0 && forced <= 17) return forced;     // 6 / 7: the 4-slot ring (v3), 8 / 9: the stamped builds, 11: v6 -- experiment builds only
+  if (forced >= 0 && forced <= 12) return forced;     // 6 / 7: the 4-slot ring (v3), 8 / 9: the stamped builds, 11: v6 -- experiment builds only
 #else
-  if (forced >= 0 && forced <= 17 && !(forced >= 6 && forced <= 9) && forced != 11) return forced;   // 13 ... 17: gemm_v7.hip
+  if (forced >= 0 && forced <= 12 && !(forced >= 6 && forced <= 9) && forced != 11) return forced;
 #endif
   const bool no96 = kn.no96;
   const double r320 = kn.r320;
@@ -1384,35 +1389,10 @@ static int pick_variant(int M, int N, int K, int splits) {
     // (the same minimum contraction length as for v5's own choice -- two K tiles -- so that tiny-K launches stay on the small tiles)
     if (r12 > 0.0 && K / splits >= 128 && t < best_t) { best_t = t; best = 12; }
   }
-  // gemm_v7.hip (one wave per SIMD, AGPR accumulators) instead of the ping-pong kernel on the same tile, per shape family:
-  // TA355_V7_MASK bits: 1 N = 1280 (o_proj / fc2 / conv2), 2 N = 3840 (q|k|v), 4 N = 5120 (fc1), 8 other 256x320, 16 the 192x256 tile, 32 256x256
-  {
-    const int v7m = kn.v7_mask;
-    if (v7m) {
-      if (best == 4) { const int bit = N == 1280 ? 1 : (N == 3840 ? 2 : (N == 5120 ? 4 : 8)); if (v7m & bit) best = 14; }
-      else if (best == 12 && (v7m & 16)) best = 15;
-      else if (best == 3 && (v7m & 32)) best = 13;
-    }
-    // round 5: the two-workgroups-per-CU form (variants 16 = 128x256 / 17 = 256x128) per shape family of the LM side (M = B * L rows):
-    // TA355_V9_MASK bits: 1 what went to the 192x256 tile (q|k|v, d(attn-out)), 2 what went to 192x128 / v5 (the N = 1024 products),
-    // 4 what went to the 256x320 tile with N not in {1280, 3840, 5120} (gate|up, d(act)), 8 the N = 1280 family, 16 N = 3840, 32 N = 5120;
-    // bit 256 selects 256x128 (17) instead of 128x256 (16)
-    const int v9m = kn.v9_mask;
-    if (v9m && splits == 1) {
-      const int v9 = (v9m & 256) ? 17 : 16;
-      if (best == 12 && (v9m & 1)) best = v9;
-      else if ((best == 10 || best == 5 || best == 0) && N <= 1024 && M >= 1024 && (v9m & 2)) best = v9;
-      else if (best == 4) {
-        const int bit = N == 1280 ? 8 : (N == 3840 ? 16 : (N == 5120 ? 32 : 4));
-        if (v9m & bit) best = v9;
-      }
-    }
-    // (A second form of that kernel on v_mfma_f32_32x32x16_bf16 with an LDS-staged epilogue -- variants 16-18 of one visit -- was built on the
-    // strength of a constant-data probe (1 151 against 1 281 cycles per k-step), passed the same tests, and measured 4-9 % SLOWER than
-    // gemm_v7 on random operands (fc2 179 vs 164 us, 8192^3 1 309 vs 1 406 TF/s: profiles/r04_j_gemm_v8_32x32x16_ab.txt): on real data the
-    // 32x32x16 instruction sustains less than 16x16x32 (the r02 register-only probe already said 2 264 vs 2 424 TF/s).  Removed from the
-    // library; the source is kept as scripts/attic/gemm_v8.hip.txt.)
-  }
+  // (Rounds 4-5 built two more kernel families on these tiles and removed them from the library after measuring them slower in the step:
+  // gemm_v7 -- one 4-wave workgroup per CU, one wave per SIMD, 256 AGPR accumulators, 4-stage BK = 32 ring -- and its round-5
+  // two-workgroups-per-CU form on 128x256 / 256x128 tiles; a 32x32x16 form (gemm_v8).  Sources: scripts/attic/; measurements:
+  // profiles/r04_a/e_*, profiles/r05_b_gemm_2wg_*)
 #ifdef TA355_EXPERIMENTS
   // TA355_GEMM_RING=1 (experiment build): the 4-slot ring form of the ping-pong tiles instead of the 2-slot one
   if (kn.ring && (best == 3 || best == 4)) best += 3;
@@ -1431,14 +1411,12 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
 #ifdef TA355_EXPERIMENTS
   if (variant == 10 && ACT == 0 && kn.m32) variant = 11;   // TA355_GEMM_M32=1: plain linears on the 32x32x16 form of the same tile (v6)
 #endif
-  if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0 && !a.sw_gu && !a.lnf_mode)) variant = 10;   // v6 stores 8-column chunks
+  if (variant == 11 && !(ACT == 0 && (((long)a.N | a.ldc | a.c_off | a.c_bs) & 7) == 0)) variant = 10;   // v6 stores 8-column chunks
   if (a.w_blocked && variant >= 6 && variant != 12) return TA_ERR_ARG;         // the ring kernel (and v5 / v6) stage plain [N, K] weights only
-  if (variant >= 13 && variant <= 17 && !gemm_v7_serves(variant, ACT, OUT_BF16, HAS_RES, a))
-    variant = variant == 13 ? 3 : (variant == 14 ? 4 : (variant == 15 ? 12 : 3));
   if (variant == 12 && (a.a_idx || a_far || a.A2)) variant = 3;
-  const int bm = (variant == 0 || variant == 16) ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12 || variant == 15) ? 192 : 256));
+  const int bm = variant == 0 ? 128 : (variant == 5 ? 96 : ((variant == 10 || variant == 11 || variant == 12) ? 192 : 256));
   if ((variant == 8 || variant == 9) && !(ACT == 0 && OUT_BF16 && !HAS_RES && !a.A2)) return TA_ERR_ARG;   // the timing build exists for plain bf16 GEMMs only
-  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9 || variant == 14) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12 || variant == 13 || variant == 15 || variant == 16) ? 256 : 128);
+  const int bn = (variant == 4 || variant == 7 || variant == 8 || variant == 9) ? 320 : ((variant == 1 || variant == 3 || variant == 6 || variant == 12) ? 256 : 128);
   // rows-grouped launch: every group may end in a partial M tile, so the tile grid is an upper bound (surplus tiles exit)
   a.tiles_m = ta_cdiv(a.M, bm) + ((a.grp_n > 0 && a.seg) ? a.grp_n : 0); a.tiles_n = ta_cdiv(a.N, bn);
   const int grid = a.tiles_m * a.tiles_n * a.splits;
@@ -1472,13 +1450,7 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
     r.flops = 2.0 * (double)a.M * (double)a.N * (double)a.K;
     (void)hipEventRecord(r.a, st);
   }
-  if (variant >= 13 && variant <= 17) {
-    // 16 / 17: two 4-wave workgroups per CU (persistent: at most 2 per CU)
-    const int pg7 = variant >= 16 ? (grid < 2 * ncu ? grid : 2 * ncu) : pgrid;
-    const int rc = launch_gemm_v7<ACT, OUT_BF16, HAS_RES>(variant, a, pg7, st);
-    if (rc) return rc;
-  }
-  else if (a.A2) {
+  if (a.A2) {
     if constexpr (ACT == 0) {                     // the K extension exists for plain linears only (LoRA)
       if (variant == 0) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 128, true>), dim3(grid), dim3(256), 0, st, a);
       else if (variant == 5) TA_LAUNCH((gemm_nt_kernel<ACT, OUT_BF16, HAS_RES, 96, true>), dim3(grid), dim3(256), 0, st, a);
@@ -1538,10 +1510,10 @@ static int launch_gemm(GemmArgs a, hipStream_t st) {
   if (g_prof_on) { (void)hipEventRecord(r.b, st); g_prof.push_back(r); }
   if (g_log_on) {
     const long flags = (a.a_idx ? 1 : 0) | (a.seg ? 2 : 0) | (a.krange ? 4 : 0) | (a.A2 ? 8 : 0) | (a.w_blocked ? 16 : 0) | (a.grp_n > 0 ? 32 : 0) |
-                       (a.lnf_mode ? 64 : 0) | (a.sw_gu ? 128 : 0) | (a.a_plain ? 256 : 0) | (a.c_plain ? 512 : 0);
+                       (a.a_plain ? 256 : 0) | (a.c_plain ? 512 : 0);
     const long rec[TA_GEMM_LOG_FIELDS] = {a.M, a.N, a.K, a.lda, a.a_rpb, a.a_bs, a.ldc, a.c_rpb, a.c_bs, a.c_off, ACT, OUT_BF16 ? 1 : 0,
                                           HAS_RES ? 1 : 0, a.res_bf16, a.bias ? 1 : 0, a.splits, a.rope_cols, a.rope_rows, flags, a.K2, variant,
-                                          a.grp_n, a.lnf_mode, persist ? 1 : 0};
+                                          a.grp_n, 0, persist ? 1 : 0};
     g_log.insert(g_log.end(), rec, rec + TA_GEMM_LOG_FIELDS);
   }
   TA_CHECK_LAUNCH();
@@ -1555,9 +1527,9 @@ extern "C" int ta_profile_gemm(int enable) {
   return TA_OK;
 }
 // the launches logged since ta_profile_gemm(2): rows of 24 longs {M, N, K, lda, a_rpb, a_bs, ldc, c_rpb, c_bs, c_off, act (the epilogue
-// instantiation: 0 none, 1 GELU, 2 rope, 3-6 the folded-LayerNorm / fused-SwiGLU forms), out_bf16, has_residual, residual_bf16,
+// instantiation: 0 none, 1 GELU, 2 rope), out_bf16, has_residual, residual_bf16,
 // has_bias, splits, rope_cols, rope_rows, flags (1 gather, 2 segments, 4 K range, 8 K extension, 16 blocked W, 32 grouped,
-// 64 LayerNorm fold, 128 SwiGLU backward, 256 / 512 identity A / C row map), K2, tile variant as launched, groups, lnf mode,
+// 256 / 512 identity A / C row map), K2, tile variant as launched, groups, 0 (reserved),
 // persistent}.  Returns the number of rows (at most max_rows are written; out may be NULL to count).
 extern "C" long ta_profile_gemm_log(long* out, long max_rows) {
   const long n = (long)(g_log.size() / TA_GEMM_LOG_FIELDS);
@@ -1614,11 +1586,10 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
                                    int act, int out_bf16, int splits, float* splitk_ws,
                                    const int* a_idx, const int* seg, const int* krange, const ta_gemm_opts* opts,
                                    hipStream_t st) {
-  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+  static const ta_gemm_opts none = {nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, 0};
   const ta_gemm_opts& o = opts ? *opts : none;
   const void* resb = o.residual_bf16;
   if (resb) { if (residual) return TA_ERR_ARG; residual = (const float*)resb; }
-  const void* sw_gu = o.swiglu_gu; void* sw_dgu = o.swiglu_dgu;
   const void *xA2 = o.a2, *xW2 = o.w2;
   const int xK2 = o.a2 ? o.k2 : 0;
   if (o.a2 && (o.k2 <= 0 || o.k2 % BK || o.lda2 % 8 || !o.w2)) return TA_ERR_ARG;
@@ -1637,21 +1608,13 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
   a.c_plain = (a.c_rpb >= M && (!seg || a.c_rpb == 0x7fffffff)) ? 1 : 0;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
   a.A2 = (const bf16_t*)xA2; a.W2 = (const bf16_t*)xW2; a.K2 = xK2; a.lda2 = o.lda2;
-  a.sw_gu = (const bf16_t*)sw_gu; a.sw_dgu = (bf16_t*)sw_dgu;
   a.res_bf16 = resb != nullptr;
   a.rope_tab = o.rope_tab; a.rope_rows = o.rope_rows; a.rope_cols = o.rope_cols > 0 ? o.rope_cols : N;
   a.w_blocked = o.w_blocked ? 1 : 0;
-  a.lnf_stats = o.lnf_stats; a.lnf_c1 = o.lnf_c1; a.lnf_mode = o.lnf_mode;
   a.dbg = 0; a.grp_n = 0; a.grp_w_stride = 0;
-  if (a.lnf_mode) {
-    const bool row_ok = a.lnf_mode == 1 && act != 0;
-    const bool col_ok = a.lnf_mode == 2 && act == 0 && out_bf16 && !residual && (N % 4) == 0;
-    if (!o.lnf_stats || !o.lnf_c1 || !(row_ok || col_ok) || splits > 1 || seg || a_idx) return TA_ERR_ARG;
-  }
   if (a.w_blocked && ((N & 63) || xA2 || krange || a_idx)) return TA_ERR_ARG;
-  if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || sw_gu || (N % 64) || o.rope_cols < 0 || (o.rope_cols % 64))) return TA_ERR_ARG;
+  if (act == 2 && (!o.rope_tab || o.rope_rows <= 0 || !out_bf16 || residual || splits > 1 || (N % 64) || o.rope_cols < 0 || (o.rope_cols % 64))) return TA_ERR_ARG;
   if (resb && splits > 1) return TA_ERR_ARG;
-  if (sw_gu && (!out_bf16 || act != 0 || residual || bias || splits > 1 || a.c_rpb != M || ldc != N || c_off != 0 || seg)) return TA_ERR_ARG;
   if (a.A2 && (splits > 1 || krange)) return TA_ERR_ARG;
   a.tiles_m = ta_cdiv(M, BM); a.tiles_n = ta_cdiv(N, BN);
   a.splits = splits > 1 ? splits : 1;
@@ -1673,10 +1636,6 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     return TA_OK;
   }
   const bool hr = residual != nullptr;
-  if (a.sw_gu) return launch_gemm<6, true, false>(a, st);                               // validated above: act 0, bf16, plain
-  if (a.lnf_mode == 2) return launch_gemm<5, true, false>(a, st);                       // validated above: act 0, bf16 out, no residual
-  if (a.lnf_mode == 1 && act == 1 && out_bf16 && !hr) return launch_gemm<3, true, false>(a, st);
-  if (a.lnf_mode == 1 && act != 2) return TA_ERR_ARG;
   if (act == 0) {
     if (out_bf16) return hr ? launch_gemm<0, true, true>(a, st) : launch_gemm<0, true, false>(a, st);
     return hr ? launch_gemm<0, false, true>(a, st) : launch_gemm<0, false, false>(a, st);
@@ -1684,7 +1643,7 @@ extern "C" int ta_gemm_bf16_nt_opt(const void* A, const void* W, void* C, int M,
     if (out_bf16) return hr ? launch_gemm<1, true, true>(a, st) : launch_gemm<1, true, false>(a, st);
     return hr ? launch_gemm<1, false, true>(a, st) : launch_gemm<1, false, false>(a, st);
   } else if (act == 2) {
-    return a.lnf_mode == 1 ? launch_gemm<4, true, false>(a, st) : launch_gemm<2, true, false>(a, st);
+    return launch_gemm<2, true, false>(a, st);
   }
   return TA_ERR_ARG;
 }
@@ -1704,8 +1663,8 @@ extern "C" int ta_gemm_bf16_nt_grouped(const void* A, const void* W, void* C, in
   a.lda = K; a.a_rpb = 0x7fffffff; a.a_bs = 0; a.ldc = N; a.c_rpb = 0x7fffffff; a.c_bs = 0; a.c_off = 0;
   a.a_plain = 1; a.c_plain = 1;
   a.a_idx = a_idx; a.seg = seg; a.krange = krange;
-  a.A2 = nullptr; a.W2 = nullptr; a.K2 = 0; a.lda2 = 0; a.sw_gu = nullptr; a.sw_dgu = nullptr; a.res_bf16 = 0;
-  a.rope_tab = nullptr; a.rope_rows = 0; a.rope_cols = 0; a.w_blocked = 0; a.lnf_stats = nullptr; a.lnf_c1 = nullptr; a.lnf_mode = 0; a.dbg = 0;
+  a.A2 = nullptr; a.W2 = nullptr; a.K2 = 0; a.lda2 = 0; a.res_bf16 = 0;
+  a.rope_tab = nullptr; a.rope_rows = 0; a.rope_cols = 0; a.w_blocked = 0; a.dbg = 0;
   a.grp_n = n_groups; a.grp_w_stride = w_stride;
   a.splits = krange ? n_groups : 1;           // K-slice form: z = group, slabs c_stride apart
   a.slab_stride = krange ? c_stride : (long)M * N;

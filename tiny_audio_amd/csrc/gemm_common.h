@@ -23,9 +23,6 @@ struct GemmArgs {
   // K extension (LoRA): after the K columns of A / W the contraction continues over K2 more columns taken from
   // A2 [M, K2] (row stride lda2) and W2 [N, K2]:  C = A W^T + A2 W2^T  in one accumulator pass
   const bf16_t* A2; const bf16_t* W2; int K2; long lda2;
-  // fused SwiGLU backward (LM): the GEMM result is d(act) [M, N = F]; instead of storing it, the epilogue reads gate|up
-  // from sw_gu [M, 2F] and writes d(gate|up) to sw_dgu [M, 2F]  (plain row map only)
-  const bf16_t* sw_gu; bf16_t* sw_dgu;
   int res_bf16;        // the residual is bf16 (same row map as C), not f32
   // act == 2: partial rotary embedding in the epilogue (GLM-ASR q|k projection).  Heads are 64 columns; the first 32
   // columns of every head hold the 16 rotation pairs INTERLEAVED (pair i = columns 2i, 2i+1), so both members of a pair
@@ -35,11 +32,6 @@ struct GemmArgs {
   int wide;            // bf16 epilogue may use 16-B (8-column) stores: N, ldc, c_off, c_bs all multiples of 8
   int w_blocked;       // W is stored as [N/64][K/64][64][64] blocks (8 KB contiguous per 64 rows x one K tile)
   int a_plain, c_plain; // the row map is the identity (one batch): skips two integer divisions per row in prologue / epilogue
-  // LayerNorm folded into this GEMM: A is the UN-normalised row x, W' = gamma o W, and the epilogue applies
-  //   mode 1 (rows are tokens):    v = acc * rstd[m] + (-mean rstd)[m] * c1[n]   (then bias = c2, activation, ...)
-  //   mode 2 (columns are tokens): v = acc * rstd[n] + (-mean rstd)[n] * c1[m]   (the V^T = Wv x^T product)
-  // lnf_stats f32 [tokens][2] = (rstd, -mean rstd) from ta_layernorm_stats; lnf_c1[j] = sum_k W'[j, k]
-  const float* lnf_stats; const float* lnf_c1; int lnf_mode;
   int dbg;             // experiments only (TA355_GEMM_DEBUG): bit 0 = no epilogue stores, bit 1 = contract over ONE K tile only
   // Grouped launch (MoE experts in ONE launch, ta_gemm_bf16_nt_grouped):
   //   rows form    seg = int[2 * grp_n] {row base, row count}: M tile indices run over the concatenation of the groups' row
@@ -125,25 +117,19 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
                                                int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
                                                bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0,
                                                uint2* oret = nullptr) {
-  // ACT 3 / 4 / 5 = GELU / rope / none WITH the folded LayerNorm of ta_gemm_opts.lnf_* (rows- resp. columns-are-tokens
-  // form).  Separate instantiations: the extra loads and FMAs cost the plain epilogues 0.8 ms per step when they were
-  // merely present behind a run-time flag.
-  constexpr bool LNF_ROW = ACT == 3 || ACT == 4, LNF_COL = ACT == 5;
-  constexpr bool SWIGLU = ACT == 6;                 // fused SwiGLU backward (ta_gemm_opts.swiglu_*), its own instantiation too
-  constexpr int BASE = ACT == 3 ? 1 : (ACT == 4 ? 2 : ((ACT == 5 || ACT == 6) ? 0 : ACT));
+  // ACT: 0 none, 1 erf-GELU, 2 partial rotary embedding.  (Rounds 1-4 also carried a folded-LayerNorm form (ACT 3 / 4 / 5) and a fused
+  // SwiGLU-backward form (ACT 6) as separate instantiations; both measured slower in the step than the streaming kernels they
+  // replaced -- DESIGN.md section 8 -- and left the library in round 5.)
+  static_assert(ACT >= 0 && ACT <= 2, "epilogue form");
+  constexpr int BASE = ACT;
   // ---- gather phase: every load of the strip, unconditional (column clamped into the matrix)
-  float4 bq[NT], rt[NT], rf[NT], lc[NT], ls0[NT], ls1[NT];
+  float4 bq[NT], rt[NT], rf[NT];
   uint2 rb[NT];
-  float2 lst = make_float2(1.f, 0.f); float lcm = 0.f;
-  if (LNF_ROW) lst = ((const float2*)p.lnf_stats)[m];
-  if (LNF_COL) lcm = p.lnf_c1[m];
   const long rope_row = BASE == 2 ? (long)(m % p.rope_rows) * 16 : 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = nb + j * 16 + g * 4;
     const int nn = n < p.N ? n : p.N - 4;          // (tiles are column-aligned to 4; out-of-range values are never stored)
-    if (LNF_ROW) lc[j] = *(const float4*)(p.lnf_c1 + nn);
-    if (LNF_COL) { ls0[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn); ls1[j] = *(const float4*)(p.lnf_stats + 2 * (long)nn + 4); }
     if (bias) bq[j] = ELS ? *(const float4*)(els + EPI_LDS_BIAS + (nn - ecol0) * 4) : *(const float4*)(bias + nn);
     if (BASE == 2) {
       const int pc = nn & 63;
@@ -161,16 +147,6 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     const int n = nb + j * 16 + g * 4;
     const bool in = n < p.N;
     f32x4 v = acc[j];
-    if (LNF_ROW) {
-      const float4 c = lc[j];
-      v[0] = v[0] * lst.x + lst.y * c.x; v[1] = v[1] * lst.x + lst.y * c.y;
-      v[2] = v[2] * lst.x + lst.y * c.z; v[3] = v[3] * lst.x + lst.y * c.w;
-    }
-    if (LNF_COL) {
-      const float4 s0 = ls0[j], s1 = ls1[j];
-      v[0] = v[0] * s0.x + s0.y * lcm; v[1] = v[1] * s0.z + s0.w * lcm;
-      v[2] = v[2] * s1.x + s1.y * lcm; v[3] = v[3] * s1.z + s1.w * lcm;
-    }
     if (bias) { v[0] += bq[j].x; v[1] += bq[j].y; v[2] += bq[j].z; v[3] += bq[j].w; }
     if (BASE == 1) {
       if (TA355_GELU_ALWAYS_LUT || lut) { v[0] = gelu_lut(v[0], lut); v[1] = gelu_lut(v[1], lut); v[2] = gelu_lut(v[2], lut); v[3] = gelu_lut(v[3], lut); }
@@ -197,25 +173,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
     }
-    if (SWIGLU) {
-      if (in) {
-        const long go = roff * 2 + n;                            // row m of [M, 2F]: roff = m * F
-        const uint2 gv = *(const uint2*)(p.sw_gu + go), uv = *(const uint2*)(p.sw_gu + go + p.N);
-        const float gt[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
-        const float up[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
-        float dg[4], du[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float sg = 1.f / (1.f + __expf(-gt[q]));
-          dg[q] = v[q] * up[q] * (sg * (1.f + gt[q] * (1.f - sg)));
-          du[q] = v[q] * gt[q] * sg;
-        }
-        uint2 w; w.x = pack2bf(dg[0], dg[1]); w.y = pack2bf(dg[2], dg[3]);
-        *(uint2*)(p.sw_dgu + go) = w;
-        w.x = pack2bf(du[0], du[1]); w.y = pack2bf(du[2], du[3]);
-        *(uint2*)(p.sw_dgu + go + p.N) = w;
-      }
-    } else if (OUT_BF16) {
+    if (OUT_BF16) {
       o[j].x = pack2bf(v[0], v[1]);
       o[j].y = pack2bf(v[2], v[3]);
       if (oret) oret[j] = o[j];
@@ -224,7 +182,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
       *(float4*)(Cb + (roff + n) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
-  if (OUT_BF16 && wide && !SWIGLU && !oret) {
+  if (OUT_BF16 && wide && !oret) {
 #pragma unroll
     for (int j = 0; j + 1 < NT; j += 2) {
       const auto a = __builtin_amdgcn_permlane16_swap(o[j].x, o[j + 1].x, false, false);
@@ -392,7 +350,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (*acc)[NT]) {
 // free: every wave past its last LDS read of the main loop.
 template <int ACT, int NTHREADS>
 __device__ __forceinline__ const float2* stage_gelu_lut(char* smem, const GemmArgs& p, int tid, bool barrier_first) {
-  if constexpr (ACT == 1 || ACT == 3) {
+  if constexpr (ACT == 1) {
     if (!(p.dbg & 8)) {
       if (barrier_first) __syncthreads();
       for (int i = tid; i < GELU_LUT_N * 8 / 16; i += NTHREADS) ((uint4*)smem)[i] = ((const uint4*)kGeluLut)[i];
@@ -466,6 +424,3 @@ __device__ __forceinline__ TileCtx tile_ctx(const GemmArgs& p, int h, int total)
   return c;
 }
 
-// gemm_v7.hip: variants 13 (256x256), 14 (256x320), 15 (192x256) -- returns TA_ERR_ARG when the launch is outside what the kernel serves
-template <int ACT, bool OUT_BF16, bool HAS_RES> int launch_gemm_v7(int variant, GemmArgs a, int pgrid, hipStream_t st);
-bool gemm_v7_serves(int variant, int act, bool out_bf16, bool has_res, const GemmArgs& a);

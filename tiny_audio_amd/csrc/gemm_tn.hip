@@ -135,7 +135,7 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slabs, int nz, long s
 
 static int tn_chunks(int M, int Ny, int Nx) {
   const long tiles = (long)ta_cdiv(Nx, TN_BX) * ta_cdiv(Ny, TN_BY);
-  static const long target = [] { const char* e = getenv("TA355_TN_WGS"); return e && *e ? atol(e) : 512L; }();   // experiment knob
+  const long target = 512;
   long z = (target + tiles - 1) / tiles;               // ~512 workgroups (two per CU)
   const long zmax = ta_cdiv(M, 64);
   if (z > zmax) z = zmax;

@@ -13,12 +13,10 @@
 #include "internal.h"
 
 static bool read_decode_fused() { const char* e = getenv("TA355_DECODE_FUSED"); return !(e && *e == '0'); }
-static bool read_decode_prefetch() { const char* e = getenv("TA355_DECODE_PREFETCH"); return !(e && *e == '0'); }
-static int read_decode_pf_wgs() { const char* e = getenv("TA355_DECODE_PF_WGS"); return e && *e ? atoi(e) : 0; }   // 0 = decode_fused.hip's default (96)
-static bool g_decode_fused = read_decode_fused();                 // read at load; ta_gemm_reload_knobs() re-reads them (tests, A/B scripts)
-static bool g_decode_prefetch = read_decode_prefetch();
-static int g_decode_pf_wgs = read_decode_pf_wgs();
-void ta_i_reload_decode_knobs() { g_decode_fused = read_decode_fused(); g_decode_prefetch = read_decode_prefetch(); g_decode_pf_wgs = read_decode_pf_wgs(); }
+static bool g_decode_fused = read_decode_fused();                 // read at load; ta_gemm_reload_knobs() re-reads it (the tests compare both sequences)
+static const bool g_decode_prefetch = true;                       // next-kernel prefetch workgroups (1.54 -> 1.455 ms per token, r04)
+static const int g_decode_pf_wgs = 0;                             // 0 = decode_fused.hip's default (96: 1.94 ms at 32, 1.46 at 96-128, 1.59 at 256+)
+void ta_i_reload_decode_knobs() { g_decode_fused = read_decode_fused(); }
 
 namespace {
 constexpr int HD = 128;

@@ -27,7 +27,7 @@ inline int gemm_opt(const void* A, const void* W, void* C, int M, int N, int K, 
   return ta_gemm_bf16_nt_opt(A, W, C, M, N, K, K, 0, 0, N, 0, 0, 0, bias, res, act, out_bf16, 1, nullptr, nullptr, nullptr, nullptr,
                              &o, st);
 }
-inline ta_gemm_opts opts_none() { return ta_gemm_opts{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0}; }
+inline ta_gemm_opts opts_none() { return ta_gemm_opts{nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, 0}; }
 inline ta_gemm_opts opts_kext(const void* a2, const void* w2) { ta_gemm_opts o = opts_none(); o.a2 = a2; o.w2 = w2; o.k2 = 64; o.lda2 = 64; return o; }
 // split-K heuristic: fill the 512 resident workgroup slots (256 CUs x 2) when the tile grid is small
 inline int pick_splits(int M, int N, int K) {

@@ -3,11 +3,10 @@
 // periodic Hann, |rDFT-400|^2 (last frame dropped), slaney mel bank [201 x n_mels], clamp 1e-10, log10,
 // per-clip max(x, max-8), (x+4)/4 -- and :330-339 for the frame mask.
 //
-// n_fft = 400 is not a power of two and the whole stage is < 0.1 % of the step's flops, so the DFT is
-// evaluated as an exact-f32 matrix product against a host-built (float64-rounded) twiddle matrix instead of
-// an FFT (see logmel_power_kernel).  The clip maximum is an atomicMax on an
-// order-preserving integer image of the float; a second tiny kernel applies floor/scale (the only
-// second pass over the 512 KB/clip output).
+// n_fft = 400 = 16 x 25: a mixed-radix complex FFT ((4.4) x (5.5)), two real frames per transform, f32 throughout (round 2; round
+// 1's exact-f32 DFT-as-GEMM on v_mfma_f32_16x16x4_f32 -- 262-278 us per 32 clips against 42 -- left the library in round 5).
+// The clip maximum is an atomicMax on an order-preserving integer image of the float (one per persistent workgroup); a second
+// tiny kernel applies floor/scale (the only second pass over the 512 KB/clip output).
 #include <cstdlib>
 #include "common.h"
 
@@ -18,135 +17,12 @@
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-// dft [NFFT][2*NBIN] f32: column k = cos(2 pi k n / 400), column NBIN + k = sin(..); window [NFFT]; melfb [NBIN][n_mels]
-//
-// The DFT is a GEMM  [frames x 400] x [400 x 402]  in EXACT f32 on the matrix cores: v_mfma_f32_16x16x4_f32 is a
-// fused-multiply-add chain over k, i.e. the same arithmetic as the scalar FMA loop it replaces (5.5x faster: the
-// scalar loop ran at 18 TFLOP/s of the 157 TFLOP/s f32 matrix peak).  One workgroup = FT frames of one clip:
-// windowed frames staged in LDS (the A operand, one ds_read per lane per k-step), the twiddle table streams from
-// L2 (B operand, 64-B coalesced rows); wave w owns column blocks w, w+4, ...; re / im land back in LDS over the
-// frames, become powers in place, and the same workgroup applies the mel bank.
-#define FT 64            // frames per block
-#define FRS 420          // LDS row stride (floats): >= 26 column blocks of 16 for re|im, and 400 samples of a frame
-#define NCB 26           // ceil(402 / 16)
 typedef __attribute__((ext_vector_type(4))) float lm_f32x4;
-
-__global__ __launch_bounds__(256) void logmel_power_kernel(const float* __restrict__ wav, int Ls, const float* __restrict__ dft,
-                                                           const float* __restrict__ window, const float* __restrict__ melfb,
-                                                           int n_mels, float* __restrict__ out, int* __restrict__ clip_max,
-                                                           int T) {
-  __shared__ __attribute__((aligned(16))) float fr[FT * FRS];    // frames -> re|im -> powers
-  const int b = blockIdx.y, t0 = blockIdx.x * FT, tid = threadIdx.x;
-  const float* w = wav + (long)b * Ls;
-  for (int i = tid; i < FT * NFFT; i += 256) {
-    const int f = i / NFFT, n = i - f * NFFT;
-    int j = (t0 + f) * HOP + n - NFFT / 2;          // index into the (virtually) reflect-padded signal
-    if (j < 0) j = -j;
-    if (j >= Ls) j = 2 * (Ls - 1) - j;
-    float v = 0.f;
-    if (t0 + f < T && j >= 0 && j < Ls) v = w[j] * window[n];
-    fr[f * FRS + n] = v;
-  }
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-  lm_f32x4 acc[4][7];
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-    for (int c = 0; c < 7; ++c) acc[rb][c] = (lm_f32x4){0.f, 0.f, 0.f, 0.f};
-  float bv[7], bn[7];
-  auto load_b = [&](int k0, float* dst) {
-    const float* drow = dft + (long)(k0 + lg) * (2 * NBIN);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) {
-      const int col = (wave + 4 * c) * 16 + li;
-      dst[c] = col < 2 * NBIN ? drow[col] : 0.f;                        // (column blocks >= NCB read 0 and are never stored)
-    }
-  };
-  load_b(0, bv);
-  for (int k0 = 0; k0 < NFFT; k0 += 4) {
-    if (k0 + 4 < NFFT) load_b(k0 + 4, bn);                              // next twiddle rows fly under this step's MFMAs
-    float a[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) a[rb] = fr[(rb * 16 + li) * FRS + k0 + lg];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) {
-      if (wave + 4 * c < NCB) {                                         // wave-uniform
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[rb][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb], bv[c], acc[rb][c], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 7; ++c) bv[c] = bn[c];
-  }
-  __syncthreads();                                                      // every wave is done with the frames
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-    for (int c = 0; c < 7; ++c) {
-      const int cb = wave + 4 * c;
-      if (cb < NCB) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fr[(rb * 16 + lg * 4 + r) * FRS + cb * 16 + li] = acc[rb][c][r];
-      }
-    }
-  __syncthreads();
-  // |X|^2, re-laid out bin-major pw[k][frame] over the same LDS (every thread first reads all of its re / im values)
-  constexpr int PER = (FT * NBIN + 255) / 256;
-  float pwv[PER];
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * 256;
-    if (i < FT * NBIN) {
-      const int k = i / FT, f = i - k * FT;
-      const float re = fr[f * FRS + k], im = fr[f * FRS + NBIN + k];
-      pwv[q] = re * re + im * im;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const int i = tid + q * 256;
-    if (i < FT * NBIN) fr[i] = pwv[q];                                  // i = k * FT + f
-  }
-  __syncthreads();
-  // mel + log10: thread = (mel bin m, group of FT / fgroups frames); the filter weight is loaded once per bin and the
-  // powers of 4 frames come as one broadcast 16-B LDS read.  Same fmaf order over the bins as a scalar loop.
-  float lmax = -INFINITY;
-  const int fgroups = 256 / n_mels;   // n_mels in {64, 128, 256}: validated on the host
-  const int m = tid % n_mels, fg = tid / n_mels, nf = FT / fgroups;      // nf in {16, 32, 64}
-  for (int fb = 0; fb < nf; fb += 16) {
-    float am[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) am[q] = 0.f;
-    const int f0 = fg * nf + fb;
-    for (int kk = 0; kk < NBIN; ++kk) {
-      const float wgt = melfb[kk * n_mels + m];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 pv = *(const float4*)(fr + kk * FT + f0 + 4 * q);
-        am[4 * q] = fmaf(wgt, pv.x, am[4 * q]); am[4 * q + 1] = fmaf(wgt, pv.y, am[4 * q + 1]);
-        am[4 * q + 2] = fmaf(wgt, pv.z, am[4 * q + 2]); am[4 * q + 3] = fmaf(wgt, pv.w, am[4 * q + 3]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int t = t0 + f0 + q;
-      if (t < T) {
-        const float v = log10f(fmaxf(am[q], 1e-10f));
-        out[((long)b * n_mels + m) * T + t] = v;
-        lmax = fmaxf(lmax, v);
-      }
-    }
-  }
-  lmax = wave_max(lmax);
-  if ((tid & 63) == 0 && lmax > -INFINITY) atomicMax(clip_max + b, f2ord(lmax));
-}
 
 
 // ============================================================================ FFT form (default)
 // The 400-point transform as a mixed-radix FFT, 400 = 16 x 25 = (4 x 4) x (5 x 5), in f32 on the VALU: 17 MFLOP per clip
-// instead of the 322 MFLOP of the DFT-as-GEMM above, which makes the stage what the north star asks of it -- bound by its
+// instead of the 322 MFLOP of round 1's DFT-as-GEMM, which makes the stage what the north star asks of it -- bound by its
 // 1.15 MB of HBM traffic per clip, not by arithmetic.  (f32 FFT error ~1e-7 of the largest bin, below the O(N) error of a
 // direct f32 summation; same 5e-4 tolerance against the reference's torch.stft as before.)
 //   X[k1 + 16 k2] = sum_{n2} W25^{n2 k2} * ( W400^{n2 k1} * sum_{n1} W16^{n1 k1} z[25 n1 + n2] )
@@ -570,61 +446,29 @@ extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, 
   const int T = Ls / HOP;
   if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256) || !clip_ws || !mel_ranges) return TA_ERR_ARG;
   TA_LAUNCH(logmel_init_kernel, dim3(1), dim3(256), 0, st, clip_ws, B);
-  // TA355_LOGMEL_DFT=1: the exact-f32 DFT-as-GEMM form (bit-for-bit a scalar fmaf chain) instead of the mixed-radix FFT
-  static const bool use_dft = [] { const char* e = getenv("TA355_LOGMEL_DFT"); return e && *e == '1'; }();
-  bool two_pass = true;
-  if (use_dft) {
-    TA_LAUNCH(logmel_power_kernel, dim3(ta_cdiv(T, FT), B), dim3(256), 0, st, wav, Ls, dft, window, melfb, n_mels,
-              feats, clip_ws, T);
-  } else {
-    static const int dbg = [] { const char* e = getenv("TA355_LOGMEL_DEBUG"); return e && *e ? atoi(e) : 0; }();   // experiments
-    static const int big = [] { const char* e = getenv("TA355_LOGMEL_FT64"); return e && *e == '1'; }();
-    // round 4 experiment (TA355_LOGMEL_MFMA=1 in an experiment build): the sub-transforms on the f32 matrix cores.  Measured 76.4 us per launch against 68.2 for the
-    // register FFT (profiles/r04_za_*): the transform was never the long phase of this kernel (17 of 68 us), see the persistent loop
-#ifdef TA355_EXPERIMENTS
-    static const bool mfma = [] { const char* e = getenv("TA355_LOGMEL_MFMA"); return e && *e == '1'; }();
-#else
-    constexpr bool mfma = false;                     // (the instantiation exists in experiment builds only: TA355_BUILD_EXPERIMENTS=1)
-#endif
-    // TA355_LOGMEL_ONEPASS=1 (experiment; measured SLOWER, profiles/r03_f_logmel_onepass.txt: 113.7 us against 80.9 for 32 clips):
-    // the clip's workgroups rendezvous on an arrival counter and write the tile once from LDS instead of the second pass -- but a
-    // workgroup then holds its CU slot until the slowest of its clip's 32 arrives, and the second wave of clips starts that much later
-    static const bool onepass_off = [] { const char* e = getenv("TA355_LOGMEL_ONEPASS"); return !(e && *e == '1'); }();
+  {
     auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 32; };
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
-#ifdef TA355_EXPERIMENTS
-      (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
-#endif
       attr = true;
     }
     static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     // the mel stage works on groups of 16 frames per thread: LFT / (256 / n_mels) >= 16 holds for <32, 2> only at n_mels = 128
-    const bool wide = big || n_mels != 128;
+    const bool wide = n_mels != 128;
     const int nblk = ta_cdiv(T, wide ? 64 : 32), resident = ncu * (wide ? 1 : 2);
-    // single pass needs every workgroup of a clip resident at once (they wait for one another): consecutive ids make that so
-    // as long as a clip is a small part of the resident set; very long clips (> ~40 s at 256 CUs) keep the two-pass form
-    two_pass = onepass_off || dbg != 0 || nblk * 4 > resident;
-    int* arrived = two_pass ? nullptr : clip_ws + B;
-    // two-pass form: persistent workgroups over the tiles of all clips (TA355_LOGMEL_PERSIST=0: one workgroup per tile as in rounds 2-3);
-    // the rendezvous form keeps the 2-D launch (a clip's workgroups must be resident together)
-    static const bool persist_env = [] { const char* e = getenv("TA355_LOGMEL_PERSIST"); return !(e && *e == '0'); }();
-    const bool persist = persist_env && two_pass;
+    // persistent workgroups over the tiles of all clips (round 4).  Measured and removed in round 5: one workgroup per tile (rounds 2-3:
+    // 68 us against 42), a single-pass form whose workgroups rendezvous per clip (113.7 us against 80.9, profiles/r03_f_*), the
+    // sub-transforms on the f32 matrix cores (76.4 against 68.2, profiles/r04_za_*; experiment builds only).
     const int ntiles = nblk * B;
-    const dim3 grid = persist ? dim3(ntiles < resident ? ntiles : resident) : dim3(nblk, B);
-    const int nt_arg = persist ? ntiles : 0;
+    const dim3 grid(ntiles < resident ? ntiles : resident);
     if (wide)
-      TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
-#ifdef TA355_EXPERIMENTS
-    else if (mfma)
-      TA_LAUNCH((logmel_fft_kernel<32, 2, true>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
-#endif
+      TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, 0, mel_ranges, (int*)nullptr, lens, mask, nblk, ntiles);
     else
-      TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, dbg, mel_ranges, arrived, lens, mask, nblk, nt_arg);
+      TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, 0, mel_ranges, (int*)nullptr, lens, mask, nblk, ntiles);
   }
-  if (two_pass) {
+  {
     int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
     TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_ws, lens, mask, n_mels, T);
   }

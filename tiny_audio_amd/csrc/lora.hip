@@ -285,11 +285,9 @@ int ta_i_lora_pack_b(const float* in, void* out, void* outT, int N, int r, int b
 // rows per workgroup: every workgroup ends with 256 x R float atomics, so fewer, longer row chunks are better as long
 // as ~512 workgroups remain (Cn = 6144: 288 rows -> 22 x 24 workgroups and 2.1 M atomics instead of 4.7 M)
 static int lora_tn_rows(int M, int Cn) {
-  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
   int rows = 128;
   const long want = (long)M * ta_cdiv(Cn, 256) / 512;
   if (want > rows) rows = (int)((want + 31) / 32 * 32);
-  if (rows_env > 0) rows = rows_env;
   return rows;
 }
 int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, float* out, long so_c, long so_j, int M, float post,
@@ -302,9 +300,11 @@ int ta_i_lora_skinny_tn(const void* X, int Cn, const void* Y, int ldy, int R, fl
   TA_CHECK_LAUNCH();
   return TA_OK;
 }
-// rows per workgroup of a pair launched with partial buffers: about TA355_LORA_TN_WGS (default 384) workgroups over both problems
+// rows per workgroup of a pair: about 384 workgroups over both problems (45.2 / 45.1 / 44.95 / 45.25 ms per LoRA step at 256 / 320 /
+// 384 / 512, profiles/r03_u_ab_lora_tn_wgs.txt)
+constexpr long LORA_TN_WGS = 384;
 int ta_i_lora_tn2_rows(int M, int Cn0, int Cn1) {
-  static const int wgs_env = [] { const char* e = getenv("TA355_LORA_TN_WGS"); return e && *e && atoi(e) > 0 ? atoi(e) : 384; }();
+  const long wgs_env = LORA_TN_WGS;
   const long gx = ta_cdiv(Cn0, 256) + ta_cdiv(Cn1, 256);
   const long want = ((long)M * gx + wgs_env - 1) / wgs_env;
   return (int)(((want < 32 ? 32 : want) + 31) / 32 * 32);
@@ -348,10 +348,9 @@ int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float*
   // the LoRA step (profiles/r03_t_ab_lora_tn_rows.txt: 47.5 / 46.2 / 45.8 / 47.1 / 51.4 ms at 96 / 192 / 576 / 1152 / 3008 rows)
   // says the launch is bound by them until the chip runs out of workgroups.  TA355_LORA_TN_WGS = the target count (default 384: 45.2 / 45.1 / 44.95 / 45.25 ms at 256 / 320 / 384 / 512, profiles/r03_u_ab_lora_tn_wgs.txt),
   // TA355_LORA_TN_ROWS = a fixed row count as before.
-  static const int rows_env = [] { const char* e = getenv("TA355_LORA_TN_ROWS"); return e && *e ? atoi(e) : 0; }();
-  static const int wgs_env = [] { const char* e = getenv("TA355_LORA_TN_WGS"); return e && *e ? atoi(e) : 384; }();
+  const long wgs_env = LORA_TN_WGS;
   if (part0 || part1) p0.rows = p1.rows = ta_i_lora_tn2_rows(M, Cn0, Cn1);       // (the caller sized the partial buffers with it)
-  else if (rows_env <= 0 && wgs_env > 0) {
+  else {
     const long want = ((long)M * (p0.gx + p1.gx) + wgs_env - 1) / wgs_env;
     const int rows = (int)((want < 32 ? 32 : want) + 31) / 32 * 32;
     p0.rows = p1.rows = rows;
@@ -366,16 +365,11 @@ int ta_i_lora_skinny_tn2(const void* X0, int Cn0, const void* Y0, int R0, float*
 int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, int R, hipStream_t st) {
   if (K % 32 || K <= 0 || R <= 0 || R > 64) return TA_ERR_ARG;
   if (M <= 0) return TA_OK;
-  static const bool full = [] { const char* e = getenv("TA355_LORA_NT_FULL"); return e && *e == '1'; }();   // A/B: all 64 columns
-  const int ncb = full ? 4 : (R + 15) / 16;
-  // 32 rows per workgroup; TA355_LORA_NT_ROWS=16: twice the workgroups (376 instead of 188 for the B = 32 step) -- measured equal to
-  // slightly slower (45.26 vs 45.47 ms per LoRA step, profiles/r03_y_ab_lora_nt_rows.txt): the launch is not short of loads in flight
-  static const int rows_env = [] { const char* e = getenv("TA355_LORA_NT_ROWS"); return e && *e ? atoi(e) : 0; }();
-  const bool r16 = rows_env == 16;
-  const dim3 grid(ta_cdiv(M, r16 ? 16 : 32)), blk(SK_WAVES * 64);
+  const int ncb = (R + 15) / 16;                   // only the 16-column blocks that hold an adapter (r03: 12.5 -> 9.3 us per launch)
+  // 32 rows per workgroup (16 -- twice the workgroups -- measured equal to slightly slower, profiles/r03_y_ab_lora_nt_rows.txt)
+  const dim3 grid(ta_cdiv(M, 32)), blk(SK_WAVES * 64);
 #define SKNT(NCB_, RB_) TA_LAUNCH((lora_skinny_nt_kernel<NCB_, RB_>), grid, blk, 0, st, (const bf16_t*)X, K, (const bf16_t*)W, (bf16_t*)out, M)
-  if (r16) { if (ncb == 1) SKNT(1, 1); else if (ncb == 2) SKNT(2, 1); else if (ncb == 3) SKNT(3, 1); else SKNT(4, 1); }
-  else { if (ncb == 1) SKNT(1, 2); else if (ncb == 2) SKNT(2, 2); else if (ncb == 3) SKNT(3, 2); else SKNT(4, 2); }
+  if (ncb == 1) SKNT(1, 2); else if (ncb == 2) SKNT(2, 2); else if (ncb == 3) SKNT(3, 2); else SKNT(4, 2);
 #undef SKNT
   TA_CHECK_LAUNCH();
   return TA_OK;

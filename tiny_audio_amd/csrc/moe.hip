@@ -452,10 +452,8 @@ template <typename T> long expert_stride(const void* const* ptrs, int E) {
     if ((const T*)ptrs[e + 1] - (const T*)ptrs[e] != s) return 0;
   return s;
 }
-inline bool grouped_enabled() {
-  static const bool on = [] { const char* e = getenv("TA355_MOE_GROUPED"); return !(e && *e == '0'); }();
-  return on;
-}
+// one grouped launch per matrix whenever the experts' buffers sit at a constant stride (one launch per expert otherwise)
+inline bool grouped_enabled() { return true; }
 }  // namespace
 
 // ---- bf16 images of all E + 1 adapters in TWO launches (round 4; they were 20 cast / transpose launches + 10 bias copies per step):

@@ -321,13 +321,11 @@ extern "C" int ta_layernorm_bf16(const void* x_bf16, const float* w, const float
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT || (!y_bf16 && !y_f32)) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
   const float* x = (const float*)x_bf16;
-  // bf16 -> bf16 only, H a multiple of 256 up to 2048: the 16-byte half-wave-per-row variant (TA355_LN_WIDE=0: the generic one)
-  static const bool ln_wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
-  if (ln_wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
+  // bf16 -> bf16 only, H a multiple of 256 up to 2048: the 16-byte half-wave-per-row variant (other shapes: the generic kernel)
+  if (y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
     // rows per half wave: 4 once that still leaves >= 1 workgroup per CU (M = 16000 at B = 32: 500 workgroups; measured 41.62 /
-    // 41.63 / 41.88 ms per step at 4 / 2 / 1, profiles/r03_k_ab_ln_rows.txt), 2 from 4096 rows, else 1; TA355_LN_ROWS=1|2|4
-    static const int rows_env = [] { const char* e = getenv("TA355_LN_ROWS"); return e && *e ? atoi(e) : 0; }();
-    const int rows = rows_env == 1 || rows_env == 2 || rows_env == 4 ? rows_env : (M >= 8 * 4 * 256 ? 4 : (M >= 8 * 2 * 256 ? 2 : 1));
+    // 41.63 / 41.88 ms per step at 4 / 2 / 1, profiles/r03_k_ab_ln_rows.txt), 2 from 4096 rows, else 1
+    const int rows = M >= 8 * 4 * 256 ? 4 : (M >= 8 * 2 * 256 ? 2 : 1);
     dim3 g8(ta_cdiv(M, 8 * rows));
     switch (H / 256) {
 #define LNW(N) case N: if (rows == 4) TA_LAUNCH((layernorm_bf16x8_kernel<N, 4>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
@@ -390,8 +388,7 @@ extern "C" int ta_rmsnorm_fwd_bf16(const void* x_bf16, const float* w, void* y_b
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
   const float* x = (const float*)x_bf16;
-  static const bool wide = [] { const char* e = getenv("TA355_LN_WIDE"); return !(e && *e == '0'); }();
-  if (wide && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
+  if (y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
     dim3 g8(ta_cdiv(M, 8));
     switch (H / 256) {
 #define RFW(N) case N: TA_LAUNCH((rmsnorm_fwd_bf16x8_kernel<N>), g8, blk, 0, st, (const bf16_t*)x_bf16, w, (bf16_t*)y_bf16, rstd, M, eps); break;
@@ -502,56 +499,6 @@ extern "C" int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int 
   else if (dy_is_bf16) TA_LAUNCH((rmsnorm_dw_kernel<true, false>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);
   else if (x_is_bf16) TA_LAUNCH((rmsnorm_dw_kernel<false, true>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);
   else TA_LAUNCH((rmsnorm_dw_kernel<false, false>), grid, blk, 0, st, dy, x, rstd, dw_accum, M, H);
-  TA_CHECK_LAUNCH();
-  return TA_OK;
-}
-
-
-// ---------------------------------------------------------------------------- LayerNorm statistics only
-// stats[row] = (rstd, -mean * rstd): what a GEMM epilogue needs to apply the LayerNorm that was folded into its weights
-// (ta_gemm_opts.lnf_*): y = rstd * (x W'^T) - mean * rstd * c1 + c2.  Reads the row once, writes 8 bytes.
-template <int MAXV, bool IN_BF16>
-__global__ __launch_bounds__(256) void ln_stats_kernel(const void* __restrict__ x, float* __restrict__ stats, int M, int H, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int lane = threadIdx.x & 63, nv = H >> 2;
-  float4 v[MAXV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      if (IN_BF16) {
-        const uint2 u = ((const uint2*)((const bf16_t*)x + (long)row * H))[c];
-        v[i] = make_float4(bf2f((bf16_t)(u.x & 0xffff)), bf2f((bf16_t)(u.x >> 16)), bf2f((bf16_t)(u.y & 0xffff)), bf2f((bf16_t)(u.y >> 16)));
-      } else {
-        v[i] = ((const float4*)((const float*)x + (long)row * H))[c];
-      }
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
-    }
-  }
-  const float mean = wave_sum(s) / (float)H;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      const float a = v[i].x - mean, b = v[i].y - mean, cq = v[i].z - mean, d = v[i].w - mean;
-      q += a * a + b * b + cq * cq + d * d;
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
-  if (lane == 0) ((float2*)stats)[row] = make_float2(rstd, -mean * rstd);
-}
-
-extern "C" int ta_layernorm_stats(const void* x, int x_is_bf16, float* stats, int M, int H, float eps, hipStream_t st) {
-  if (M <= 0) return TA_OK;
-  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
-  dim3 grid(ta_cdiv(M, 4)), blk(256);
-#define LNS_CALL(V)                                                                                       \
-  if (x_is_bf16) TA_LAUNCH((ln_stats_kernel<V, true>), grid, blk, 0, st, x, stats, M, H, eps);            \
-  else TA_LAUNCH((ln_stats_kernel<V, false>), grid, blk, 0, st, x, stats, M, H, eps);
-  DISPATCH_MAXV(H, LNS_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

@@ -113,7 +113,7 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
 
     @torch.no_grad()
     def _derive_fused_qkv(self):
-        """Weight images of the fused q|k|v path (ta355.h, ta_enc_layer.wqk_il): q|k rows with every head's rotary pairs
+        """Weight images of the fused q|k|v path (ta355.h, ta_enc_layer.wqkv_fa): q|k rows with every head's rotary pairs
         interleaved, the v_proj bias folded through o_proj, and the (cos, sin) table in pair order."""
         c, b = self.config, self._bufs
         H, nh = c.hidden_size, c.num_attention_heads
@@ -131,26 +131,9 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         masters = getattr(self, "_q_masters", None) or {}
         for i in range(c.num_hidden_layers):
             q = f"layers.{i}."
-            b[q + "wqk_il"] = b[q + "wqkv"][rows].contiguous()
-            b[q + "bqk_il"] = b[q + "bqkv"][rows].contiguous()
             wq32 = masters[i].to(dev) if i in masters else b[q + "wqkv"][:H].float()
             b[q + "wqkv_fa"] = torch.cat([(wq32[rows[:H]] * qs).to(BF16), b[q + "wqkv"][rows[H:]], b[q + "wqkv"][2 * H:]], 0).contiguous()
             b[q + "bqkv_fa"] = torch.cat([b[q + "bqkv"][rows[:H]] * qs, torch.zeros(H, device=dev), b[q + "bqkv"][2 * H:]], 0).contiguous()
-            b[q + "bo_fold"] = (b[q + "bo"] + b[q + "wo"].float() @ b[q + "bqkv"][2 * H:]).contiguous()
-            if os.environ.get("TA355_ENC_LN_FOLD") != "1":      # experiment (measured slower): images only on request
-                continue
-            # both LayerNorms folded into the GEMMs behind them (ta355.h, ta_enc_layer.wqk_ln ...)
-            g1, be1, g2, be2 = b[q + "ln1_w"], b[q + "ln1_b"], b[q + "ln2_w"], b[q + "ln2_b"]
-            wqk, wv, w1 = b[q + "wqk_il"].float(), b[q + "wqkv"][2 * H:].float(), b[q + "w1"].float()
-            b[q + "wqk_ln"] = (wqk * g1[None, :]).to(BF16).contiguous()
-            b[q + "c1_qk"] = b[q + "wqk_ln"].float().sum(1).contiguous()
-            b[q + "c2_qk"] = (wqk @ be1 + b[q + "bqk_il"]).contiguous()
-            b[q + "wv_ln"] = (wv * g1[None, :]).to(BF16).contiguous()
-            b[q + "c1_v"] = b[q + "wv_ln"].float().sum(1).contiguous()
-            b[q + "bo_fold2"] = (b[q + "bo"] + b[q + "wo"].float() @ (wv @ be1 + b[q + "bqkv"][2 * H:])).contiguous()
-            b[q + "w1_ln"] = (w1 * g2[None, :]).to(BF16).contiguous()
-            b[q + "c1_1"] = b[q + "w1_ln"].float().sum(1).contiguous()
-            b[q + "c2_1"] = (w1 @ be2 + b[q + "b1"]).contiguous()
 
     def _finalize(self):
         c, b = self.config, self._bufs

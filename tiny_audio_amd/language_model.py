@@ -611,8 +611,7 @@ class Qwen3MI355X(torch.nn.Module):
         # A decode step is ~340 tiny launches whose arguments never change (all per-step state is device-resident):
         # run the first one eagerly, capture the second into a hipGraph, replay it for the rest.
         graph = None
-        want_graph = (use_graph and dev.type == "cuda" and not _lib.DRY_RUN and max_new > 3
-                      and os.environ.get("TA355_DECODE_GRAPH", "1") != "0")
+        want_graph = use_graph and dev.type == "cuda" and not _lib.DRY_RUN and max_new > 3      # (``use_graph=False``: eager steps)
         if per_token:
             yield out_seq[:, 0].cpu()
         for t in range(1, max_new):

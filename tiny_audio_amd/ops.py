@@ -35,8 +35,13 @@ def _req(t, dtype=None):
 
 # The GEMM launcher reads its environment knobs once (csrc/gemm.hip GemmKnobs); tests and A/B scripts switch them between launches,
 # so the wrapper re-reads them whenever one of the per-launch knobs of rounds 1-3 has changed since the previous call.
-_KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GEMM_DEBUG", "TA355_GROUP_M", "TA355_EPI_WIDE", "TA355_GELU_LUT", "TA355_GEMM_RES_INIT",
-              "TA355_GEMM_PERSIST", "TA355_GEMM_M32", "TA355_V7_MASK", "TA355_DECODE_FUSED")
+# every run-time knob the library reads ONCE (GemmKnobs::load, the decode switch): a change is followed by ta_gemm_reload_knobs().
+# The product library has exactly these (plus TA355_ENC_QKV_FUSED, read per call); an experiment build (TA355_BUILD_EXPERIMENTS=1)
+# reads the rounds-1-4 GEMM knobs too -- all of them are watched here
+_KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GELU_LUT", "TA355_DECODE_FUSED",
+              "TA355_GEMM_DEBUG", "TA355_GROUP_M", "TA355_GROUP_M_AUTO", "TA355_EPI_WIDE", "TA355_GEMM_RES_INIT", "TA355_GEMM_PERSIST",
+              "TA355_GEMM_PERSIST_KEXT", "TA355_GEMM_M32", "TA355_GEMM_NO96", "TA355_GEMM_RING", "TA355_V5_MINK", "TA355_RATE_256x320",
+              "TA355_RATE_192x128", "TA355_RATE_192x256")
 _knob_state = None
 
 
@@ -83,19 +88,17 @@ class stream_modes:
 
 
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
-            a_map=None, c_map=None, splits=1, k_ext=None, swiglu_bwd=None, residual_bf16=None, rope=None, w_blocked=False, ln_fold=None):
+            a_map=None, c_map=None, splits=1, k_ext=None, residual_bf16=None, rope=None, w_blocked=False):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);
     k_ext=(A2 [M,K2], W2 [N,K2]) adds A2 @ W2^T inside the same launch (the LoRA rank-space tile);
     rope=(table f32 [rows,16,2], rows) with act=2: interleaved partial rotary embedding in the epilogue (ta355.h)."""
     _req(A, BF16); _req(W, BF16)
     sync_gemm_knobs()
     opts = None
-    if residual_bf16 is not None or swiglu_bwd is not None or k_ext is not None or rope is not None or w_blocked or ln_fold is not None:
+    if residual_bf16 is not None or k_ext is not None or rope is not None or w_blocked:
         from ._lib import GemmOpts
         opts = GemmOpts()
         opts.w_blocked = int(bool(w_blocked))      # W given as [N/64][K/64][64][64] blocks (pass N and K explicitly)
-        if ln_fold is not None:                    # (stats f32 [tokens, 2], c1 f32, mode 1 = rows are tokens | 2 = columns)
-            opts.lnf_stats, opts.lnf_c1, opts.lnf_mode = ptr(ln_fold[0]), ptr(ln_fold[1]), int(ln_fold[2])
         if rope is not None:
             _req(rope[0], F32)
             opts.rope_tab, opts.rope_rows = ptr(rope[0]), int(rope[1])
@@ -103,8 +106,6 @@ def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None
         if residual_bf16 is not None:       # bf16 residual with C's row map (may alias `out`)
             _req(residual_bf16, BF16)
             opts.residual_bf16 = ptr(residual_bf16)
-        if swiglu_bwd is not None:          # (gu [M, 2F], dgu [M, 2F]): the result d(act) is consumed in the epilogue
-            opts.swiglu_gu, opts.swiglu_dgu = ptr(swiglu_bwd[0]), ptr(swiglu_bwd[1])
         if k_ext is not None:
             A2, W2 = k_ext
             _req(A2, BF16); _req(W2, BF16)
@@ -260,33 +261,6 @@ def attention_fwd_qkv(qkv0, qn_w, kn_w, cosT, sinT, B, Hq, Hkv, L, scale, eps=1e
     return O, lse, Q, K, V, rq, rk
 
 
-def attention_bwd_gqa(Q, K, V, dO, O, lse, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
-    """Round 4: the same product as ``attn_bwd_prep`` + ``attention_bwd_qkv`` from ONE workgroup per (clip, kv head) (128 < L <= 192,
-    two query heads per kv head): K / V resident in LDS, Delta computed inside from ``O`` (token-major like ``dO``).  Returns
-    d(qkv0) token-major, or None when the shape is outside the kernel's envelope."""
-    B, Hq, _, hd = Q.shape
-    Hkv = K.shape[1]
-    dqkv = torch.empty((B * L, (Hq + 2 * Hkv) * hd), device=Q.device, dtype=BF16)
-    rc = lib().ta_attention_bwd_gqa(ptr(Q), ptr(K), ptr(V), ptr(dO), dO.shape[-1], ptr(O), ptr(lse), ptr(kmask), ptr(qkv0), ptr(rq),
-                                    ptr(rk), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv, L, hd,
-                                    scale, stream())
-    if rc == 1:                                   # TA_ERR_ARG: not served
-        return None
-    check(rc, "ta_attention_bwd_gqa")
-    return dqkv
-
-
-def attention_bwd_qkv_o(Q, K, V, dO, O, lse, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
-    """``attention_bwd_qkv`` with Delta computed inside from ``O`` (token-major like ``dO``): no ``attn_bwd_prep``."""
-    B, Hq, _, hd = Q.shape
-    Hkv, Lp = K.shape[1], pad64(L)
-    dqkv = torch.empty((B * L, (Hq + 2 * Hkv) * hd), device=Q.device, dtype=BF16)
-    check(lib().ta_attention_bwd_qkv_o(ptr(Q), ptr(K), ptr(V), ptr(dO), dO.shape[-1], ptr(O), ptr(lse), ptr(kmask), ptr(qkv0),
-                                       ptr(rq), ptr(rk), ptr(qn_w), ptr(kn_w), ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), B, Hq, Hkv,
-                                       L, Lp, hd, 1, scale, stream()), "ta_attention_bwd_qkv_o")
-    return dqkv
-
-
 def attention_bwd_qkv(Q, K, V, dO, lse, delta, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, L, scale, kmask=None, pos=None):
     """Causal GQA attention backward with the q|k|v post-processing backward in its epilogue: returns d(qkv0) token-major."""
     B, Hq, _, hd = Q.shape
@@ -317,14 +291,6 @@ def lm_qkv_post_bwd(dQ, dK, dV, qkv0, rq, rk, qn_w, kn_w, cosT, sinT, B, Hq, Hkv
                                    ptr(cosT), ptr(sinT), ptr(pos), ptr(dqkv), ptr(dqn), ptr(dkn), B, Hq, Hkv, L, stream()),
           "ta_lm_qkv_post_bwd")
     return dqkv
-
-
-def layernorm_stats(x, eps=1e-5):
-    """-> f32 [M, 2] = (rstd, -mean * rstd) per row of x (f32 or bf16)."""
-    M, H = x.shape
-    st = torch.empty((M, 2), device=x.device, dtype=F32)
-    check(lib().ta_layernorm_stats(ptr(x), int(x.dtype == BF16), ptr(st), M, H, eps, stream()), "ta_layernorm_stats")
-    return st
 
 
 def rmsnorm_dw(dy, x, rstd, dw):
