@@ -8,7 +8,8 @@ Round 3 found two performance bugs that no numerical test can see, both by readi
 
 This test compiles csrc/gemm.hip to assembly (cached under csrc/build/, ~100 s when stale) and asserts, for every instantiation of
 the persistent kernel `gemm_nt_kernel_v4` that the default step launches, that (a) no scratch instruction sits within ten lines of
-a `global_load_lds` and (b) the innermost loop around the MFMAs holds no scratch instruction at all.
+a `global_load_lds`, (b) the innermost loop around the MFMAs holds no scratch instruction at all and (c), since round 5, that the
+kernel has no scratch at all (`ScratchSize == 0`); the one-tile-per-CU kernels of the step (`gemm_nt_kernel_v5`) likewise.
 """
 import os
 import re
@@ -71,4 +72,19 @@ def test_persistent_gemm_has_no_scratch_traffic_around_its_dma_or_in_its_main_lo
         inside = [lines[i].strip() for i in scr if a <= i <= b]
         assert not inside, (name, inside[:3])
         assert vgprs <= 256
+        # round 5: NO scratch at all in the kernels of the default step.  The last one was the 256-VGPR
+        # o_proj / fc2 kernel <320, 0, true, true>: 8 bytes -- the reciprocal of the C row map's divisor, hoisted out of the persistent
+        # tile loop and reloaded at the top of every epilogue (gemm_common.h: opaque_sgpr)
+        assert scratch == 0 and not scr, (name, scratch)
     assert seen == set(STEP_KERNELS), sorted(set(STEP_KERNELS) - seen)
+
+
+@pytest.mark.timeout(900)
+def test_one_tile_per_cu_gemm_of_the_step_has_no_scratch():
+    """gemm_nt_kernel_v5<ACT = 0, bf16 out, +/- residual> (the LM's N = 1024 products; profiles/r04_final4_kernel_steps.md)."""
+    isa = _gemm_isa()
+    seen = 0
+    for m in re.finditer(r"^(_Z\d+gemm_nt_kernel_v5ILi0ELb1ELb[01]ELi0ELb0E[^\n:]*):.*?; ScratchSize: (\d+)", isa, re.S | re.M):
+        seen += 1
+        assert int(m.group(2)) == 0, m.group(1)
+    assert seen == 2, seen

@@ -110,6 +110,7 @@ __device__ __forceinline__ float gelu_lut(float x, const float2* lut) {
 #ifndef TA355_GELU_ALWAYS_LUT
 #define TA355_GELU_ALWAYS_LUT 0     /* gemm_v7.hip: 1 -- its table is always staged, the arithmetic form is not compiled in */
 #endif
+__device__ __forceinline__ int opaque_sgpr(int v) { asm volatile("" : "+s"(v)); return v; }
 template <int NT> struct EpiPre { uint2 r[NT]; };
 // oret != nullptr (bf16 outputs): the strip's packed results are handed back instead of stored (epilogue_tile_full stores them)
 template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
@@ -246,8 +247,11 @@ template <int MI, int NT, int ACT, bool OUT_BF16, bool HAS_RES, int AHEAD = 0, b
 __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const GemmArgs& p, char* Cb, int ml0, int Mact, int rbase, int nb,
                                               int g, bool wide, const float* bias, const float2* lut, const char* els = nullptr,
                                               int ecol0 = 0, int erow0 = 0) {
+  // (the divisor is made opaque per call: left visible, the compiler hoists its reciprocal out of the persistent tile loop and keeps
+  // it live across the main loop -- the one register the 256-VGPR o_proj / fc2 kernel spilled, reloaded at the top of every epilogue)
+  const int c_rpb_o = opaque_sgpr(p.c_rpb);
   auto row_off = [&](int m) -> long {
-    return p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+    return p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / c_rpb_o) * p.c_bs + (long)(m % c_rpb_o) * p.ldc);
   };
   int ncl[NT];
 #pragma unroll
@@ -311,6 +315,7 @@ __device__ __forceinline__ bool residual_is_start(const GemmArgs& p) {
 // accumulators -- each start value moves there as soon as it is converted
 template <int MI, int NT, int HBMAX = 0, int PIN = 0>
 __device__ __forceinline__ void residual_start(f32x4 (*acc)[NT], const GemmArgs& p, int ml0, int Mact, int rbase, int nb, int g) {
+  const int c_rpb_o = opaque_sgpr(p.c_rpb);          // (see epilogue_tile)
   int ncl[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { const int n = nb + j * 16 + g * 4; ncl[j] = n < p.N ? n : p.N - 4; }
@@ -322,7 +327,7 @@ __device__ __forceinline__ void residual_start(f32x4 (*acc)[NT], const GemmArgs&
     for (int i = 0; i < HB; ++i)
       if (i0 + i < MI) {
         const int m = rbase + min(ml0 + (i0 + i) * 16, Mact - 1);
-        const long ro = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / p.c_rpb) * p.c_bs + (long)(m % p.c_rpb) * p.ldc);
+        const long ro = p.c_off + (p.c_plain ? (long)m * p.ldc : (long)(m / c_rpb_o) * p.c_bs + (long)(m % c_rpb_o) * p.ldc);
 #pragma unroll
         for (int j = 0; j < NT; ++j) t[i][j] = *(const uint2*)((const bf16_t*)p.res + ro + ncl[j]);
       }
