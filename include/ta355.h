@@ -507,6 +507,10 @@ int ta_embed_grad_scatter(const long* ids, const int* src_row, const float* dx0,
 int ta_gather_rows_bf16(const void* in, const int* idx, void* out, int n, int D, hipStream_t st);
 int ta_scatter_rows_f32(const float* in, const int* idx, float* out, int n, int D, hipStream_t st);
 int ta_bernoulli_keep(float* keep, long n, float keep_prob, unsigned long long seed, hipStream_t st);
+/* Instrumentation (not on the hot path): `workgroups` x 256 threads stay resident for `micros` microseconds streaming buf [bytes]
+ * (read + write back) -- the footprint of a ring all-reduce's channel workgroups next to the step's kernels.  scripts/allreduce_footprint.py
+ * uses it to choose the N > 1 default (overlapped vs synchronous all-reduce) on a one-GPU box. */
+int ta_debug_occupy(int workgroups, double micros, void* buf, long bytes, hipStream_t st);
 
 int ta_cross_entropy(const void* logits, int logits_bf16, long ldl, const int* rows, const long* targets, int n, int V,
                      float scale, float* nll, float* loss_accum, void* dlogits_bf16, long ldd, hipStream_t st);

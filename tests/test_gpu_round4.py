@@ -164,13 +164,57 @@ def test_gemm_launches_of_a_real_b32_step_replayed_vs_fp32():
 
 
 # ============================================================================ fused decode step (csrc/decode_fused.hip)
+def _oracle_decode_step(w, cfg, ids, pos, kmask, slot, kcache, vcache):
+    """One greedy-decoding step in fp32 numpy (Qwen3 decoder layer with a KV cache: the new token's k / v rows go to cache slot
+    ``slot``, attention runs over the keys kmask allows): -> (logits [B, V], appended k rows [layers, B, Hkv, hd], appended v rows)."""
+    import numpy as np
+    from oracle import qwen3 as OQ
+    from oracle.encoder import apply_rope, rope_tables
+    hq, hkv, hd, eps = cfg["heads"], cfg["kv_heads"], cfg["head_dim"], cfg["rms_eps"]
+    g = hq // hkv
+    B = ids.shape[0]
+    cos_t, sin_t = rope_tables(int(pos.max()) + 1, hd, cfg["rope_theta"])
+    cos, sin = cos_t[pos][:, None], sin_t[pos][:, None]                      # [B, 1, hd]: one position per clip
+    x = w["model.embed_tokens.weight"][ids].astype(np.float32)               # [B, D]
+    new_k, new_v = [], []
+    for i in range(cfg["layers"]):
+        p = f"model.layers.{i}."
+        xn, _ = OQ.rms(x, w[p + "input_layernorm.weight"], eps)
+        q0 = (xn @ w[p + "self_attn.q_proj.weight"].T).reshape(B, 1, hq, hd)
+        k0 = (xn @ w[p + "self_attn.k_proj.weight"].T).reshape(B, 1, hkv, hd)
+        v = (xn @ w[p + "self_attn.v_proj.weight"].T).reshape(B, hkv, hd)
+        qn, _ = OQ.rms(q0, w[p + "self_attn.q_norm.weight"], eps)
+        kn, _ = OQ.rms(k0, w[p + "self_attn.k_norm.weight"], eps)
+        q = apply_rope(qn.transpose(0, 2, 1, 3), cos, sin)[:, :, 0]           # [B, hq, hd]
+        k = apply_rope(kn.transpose(0, 2, 1, 3), cos, sin)[:, :, 0]           # [B, hkv, hd]
+        K = kcache[i].copy(); V = vcache[i].copy()                           # [B, Hkv, Lmax, hd]
+        K[:, :, slot] = k; V[:, :, slot] = v
+        new_k.append(k); new_v.append(v)
+        Kr, Vr = np.repeat(K, g, axis=1), np.repeat(V, g, axis=1)            # [B, hq, Lmax, hd]
+        s = np.einsum("bhd,bhld->bhl", q, Kr) * np.float32(hd ** -0.5)
+        s = np.where(kmask[:, None, :] != 0, s, -np.inf)
+        e = np.exp(s - s.max(-1, keepdims=True))
+        P = e / e.sum(-1, keepdims=True)
+        ao = np.einsum("bhl,bhld->bhd", P, Vr).reshape(B, hq * hd)
+        x1 = x + ao @ w[p + "self_attn.o_proj.weight"].T
+        xn2, _ = OQ.rms(x1, w[p + "post_attention_layernorm.weight"], eps)
+        act = OQ.silu(xn2 @ w[p + "mlp.gate_proj.weight"].T) * (xn2 @ w[p + "mlp.up_proj.weight"].T)
+        x = (x1 + act @ w[p + "mlp.down_proj.weight"].T).astype(np.float32)
+    hn, _ = OQ.rms(x, w["model.norm.weight"], eps)
+    return (hn @ w["model.embed_tokens.weight"].T).astype(np.float32), np.stack(new_k).astype(np.float32), np.stack(new_v).astype(np.float32)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,slot,grp", [(5, 40, 2), (20, 70, 2), (32, 37, 2), (32, 300, 2), (9, 33, 4), (7, 21, 1)])
 def test_decode_step_fused_vs_unfused(B, slot, grp):
     """ta_lm_decode_step on the five fused launches per layer (RMSNorm folded into q|k|v and gate|up, SwiGLU in the epilogue,
     q/k norm + RoPE + cache append + attention in one kernel, 4-column o / down workgroups) against the round-3 nine-launch
     sequence on the same inputs: same logits up to summation order, same rows appended to the cache, ragged key masks,
-    a cache longer than one 256-key pass, every row block (B <= 16, 17..32) and GQA group sizes 1 / 2 / 4."""
+    a cache longer than one 256-key pass, every row block (B <= 16, 17..32) and GQA group sizes 1 / 2 / 4.
+    Fused vs unfused alone would be a self-comparison: the fused step's logits and appended cache rows are also
+    compared with an fp32 numpy restatement of ONE decode step on the same cache (_oracle_decode_step below, built from the
+    oracle's primitives; TF:models/qwen3/modeling_qwen3.py:211-324 with a KV cache), and the token-exact golden generate tests of
+    tests/test_gpu_parity.py run through this fused step by default."""
     import ctypes as C
     from oracle import weights as OW
     from tiny_audio_amd import _lib
@@ -219,6 +263,15 @@ def test_decode_step_fused_vs_unfused(B, slot, grp):
         d = (a[:, :, :, slot].float() - b_[:, :, :, slot].float()).abs()
         assert float(d[0].max()) <= 0.02 * float(a[0, :, :, slot].float().abs().max()) + 1e-3
         assert float(d.max()) <= 0.05 * float(a[:, :, :, slot].float().abs().max()) + 1e-3
+    # ---- against the fp32 restatement of one decode step on the same (random, bf16-valued) cache
+    ref_logits, ref_k, ref_v = _oracle_decode_step(wL, cfg, ids.cpu().numpy(), pos.cpu().numpy(), kmask.cpu().numpy(), slot,
+                                                   kc0.float().cpu().numpy(), vc0.float().cpu().numpy())
+    lo = torch.from_numpy(ref_logits).to(DEV)
+    cos_o = torch.nn.functional.cosine_similarity(lo.flatten(), l1.flatten(), dim=0)
+    assert float(cos_o) > 0.999 and float((lo - l1).abs().max()) < 0.05 * float(lo.abs().max()), (float(cos_o), float((lo - l1).abs().max()))
+    for got, want in ((k1, ref_k), (v1, ref_v)):
+        w_ = torch.from_numpy(want).to(DEV)
+        assert float((got[:, :, :, slot].float() - w_).abs().max()) <= 0.05 * float(w_.abs().max()) + 1e-3
     cos = torch.nn.functional.cosine_similarity(l0.flatten(), l1.flatten(), dim=0)
     scale = float(l0.abs().max())
     assert float(cos) > 0.9999 and float((l0 - l1).abs().max()) < 0.03 * scale, (float(cos), float((l0 - l1).abs().max()), scale)

@@ -94,7 +94,7 @@ class LmWgrads(C.Structure):
 
 
 # ----------------------------------------------------------------------------- header parsing
-_SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "unsigned long long": C.c_ulonglong,
+_SCALARS = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double, "unsigned long long": C.c_ulonglong,
             "hipStream_t": C.c_void_p}
 
 

@@ -364,3 +364,34 @@ extern "C" int ta_bernoulli_keep(float* keep, long n, float keep_prob, unsigned 
   TA_LAUNCH(bernoulli_keep_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, keep, n, keep_prob, seed);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
+
+// ---------------------------------------------------------------------------- instrumentation: the footprint of a collective
+// `workgroups` x 256 threads stay resident for `micros` microseconds, streaming `buf` (read + write back, 16 B per thread per pass) the
+// whole time: what an RCCL ring all-reduce looks like to the kernels beside it (a few channel workgroups, copy traffic, no LDS).
+// Used by scripts/allreduce_footprint.py to choose the N > 1 default (overlapped vs synchronous) on a one-GPU box.
+__global__ __launch_bounds__(256) void occupy_kernel(uint4* __restrict__ buf, long n16, long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  while ((long)(wall_clock64() - t0) < ticks) {
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+      if (i >= n16) i -= (i / n16) * n16;
+      const uint4 v = buf[i];
+      acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+      buf[i] = v;
+      i += stride;
+    }
+  }
+  if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) buf[0] = acc;     // (keeps the loads alive)
+}
+extern "C" int ta_debug_occupy(int workgroups, double micros, void* buf, long bytes, hipStream_t st) {
+  if (workgroups <= 0 || micros <= 0 || !buf || bytes < 4096) return TA_ERR_ARG;
+  int dev = 0, rate_khz = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);     // kHz of wall_clock64()
+  if (rate_khz <= 0) rate_khz = 100000;
+  TA_LAUNCH(occupy_kernel, dim3(workgroups), dim3(256), 0, st, (uint4*)buf, bytes / 16, (long)(micros * rate_khz / 1000.0));
+  TA_CHECK_LAUNCH(); return TA_OK;
+}
