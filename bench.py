@@ -557,7 +557,7 @@ def hbm_kernel_rates(B, L, cfg, fe, wav, lens):
     out = {"layernorm_kernel (encoder, bf16 residual stream in -> bf16 out)": rate(lambda: ops.layernorm(xe, we, be), Me * H * 4),
            "rmsnorm_fwd_kernel (LM, bf16 residual stream in -> bf16 out: the variant the step runs)": rate(lambda: ops.rmsnorm_fwd(xl, wl), Ml * D * 4 + Ml * 4),
            "swiglu_fwd_kernel (LM, bf16 gate|up -> bf16)": rate(lambda: ops.swiglu_fwd(gu, F), Ml * F * 6),
-           "logmel (f32 wav -> f32 [128, 1000]: init + persistent mixed-radix 16x25 FFT / mel kernel + finalize pass, all three launches)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000))}
+           "logmel (f32 wav -> f32 [128, 1000]: persistent mixed-radix 16x25 FFT / mel kernel + finalize pass, both launches)": rate(lambda: fe.extract(wav, lens), B * (640000 + 512000))}
     return out
 
 

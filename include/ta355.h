@@ -38,7 +38,7 @@ int ta_version(void); /* ABI version, currently 3 (round 5: the opt-in paths tha
  * MFMA operand (bf16) and accumulator (fp32) types are the same in both; norms / softmax / CE arithmetic is fp32 in both.
  *   enc_res_f32: encoder residual stream;  lm_res_f32: LM forward residual stream and its tape;  lm_dx_f32: LM backward d(x)
  *   stream (bf16 only together with a bf16 forward stream).
- * Initial values: environment TA355_ENC_RES_F32 / TA355_LM_RES_F32 / TA355_LM_DX_F32 (read once), else 0 / 0 / 0.
+ * Initial values 0 / 0 / 0.
  * Change it BETWEEN steps only: a forward's tape must be read back by a backward in the same mode.  Workspace / tape sizes do not
  * depend on the mode (the fp32 size is always reserved). */
 int ta_set_stream_modes(int enc_res_f32, int lm_res_f32, int lm_dx_f32);
@@ -52,17 +52,18 @@ int ta_get_stream_modes(int* out3 /* host int[3] */);
  *      scripts/train.py:327-333 and tiny_audio/asr_processing.py:74-80
  *      (TF:models/whisper/feature_extraction_whisper.py:135-168,330-339).
  * wav [B, Ls] f32 zero-padded to the longest clip, lens [B] true sample counts.
- * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once (dft is read only by the
- *      exact-DFT variant, TA355_LOGMEL_DFT=1; the default is a 16 x 25 mixed-radix FFT with compiled-in twiddles).
+ * dft [400, 402] / window [400] / melfb [201, n_mels] are host-built constant tables uploaded once (of dft the kernel reads row
+ *      n = 1, the twiddles W400^j of its 16 x 25 mixed-radix FFT).
  * feats [B, n_mels, T] f32, mask [B, T] int32, T = Ls / 160.
- * clip_ws: int[2 * B] scratch (per-clip maxima and arrival counters; no initial contents required).
+ * scratch: float[ta_logmel_scratch_floats(B, Ls, n_mels)] -- every persistent workgroup records the maximum of its tiles per clip
+ *      there (plain stores; no initial contents required, no atomics) and the second launch reduces them into the (max - 8) floor.
+ *      (ABI 2: int[2 * B] behind an init launch, one device-scope atomicMax per workgroup.)
  * mel_ranges: int[2 * n_mels] {first, end} frequency bin of every mel filter, from ta_logmel_mel_ranges -- a function of the
- *      filter bank alone, computed once when the tables are uploaded (ABI 1 recomputed it per call into the scratch).
- * (The arrival counters serve the opt-in single-pass form, TA355_LOGMEL_ONEPASS=1: a clip's workgroups rendezvous before applying
- * the (max - 8) floor and write the features once.  It measured slower than the default second pass over the 512 KB per clip.) */
+ *      filter bank alone, computed once when the tables are uploaded. */
+long ta_logmel_scratch_floats(int B, int Ls, int n_mels);
 int ta_logmel_mel_ranges(const float* melfb, int n_mels, int* mel_ranges, hipStream_t st);
 int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
-                  const float* melfb, int n_mels, float* feats, int* mask, int* clip_ws, const int* mel_ranges, hipStream_t st);
+                  const float* melfb, int n_mels, float* feats, int* mask, float* scratch, const int* mel_ranges, hipStream_t st);
 
 /* ---- frozen GLM-ASR encoder: replaces model.audio_tower(input_features=...).last_hidden_state
  *      (tiny_audio/asr_modeling.py:448-450; TF:models/glmasr/modeling_glmasr.py:313-327). */

@@ -84,7 +84,7 @@ class LogMelFeatureExtractor:
             self._mel_ranges = torch.empty(2 * self.feature_size, device=self.device, dtype=torch.int32)
             _lib.check(_lib.lib().ta_logmel_mel_ranges(ptr(self._mel), self.feature_size, ptr(self._mel_ranges), stream()),
                        "ta_logmel_mel_ranges")
-        cm = torch.empty(2 * B, device=self.device, dtype=torch.int32)                         # clip maxima + arrival counters
+        cm = torch.empty(_lib.lib().ta_logmel_scratch_floats(B, Ls, self.feature_size), device=self.device, dtype=F32)   # per-workgroup clip maxima
         _lib.check(_lib.lib().ta_logmel_f32(ptr(wav), ptr(lens), B, Ls, ptr(self._dft), ptr(self._win), ptr(self._mel),
                                             self.feature_size, ptr(feats), ptr(mask), ptr(cm), ptr(self._mel_ranges), stream()),
                    "ta_logmel_f32")

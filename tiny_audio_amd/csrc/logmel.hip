@@ -5,8 +5,8 @@
 //
 // n_fft = 400 = 16 x 25: a mixed-radix complex FFT ((4.4) x (5.5)), two real frames per transform, f32 throughout (round 2; round
 // 1's exact-f32 DFT-as-GEMM on v_mfma_f32_16x16x4_f32 -- 262-278 us per 32 clips against 42 -- left the library in round 5).
-// The clip maximum is an atomicMax on an order-preserving integer image of the float (one per persistent workgroup); a second
-// tiny kernel applies floor/scale (the only second pass over the 512 KB/clip output).
+// The clip maximum: every persistent workgroup records the maximum of its tiles per clip (plain stores into its own scratch records,
+// round 5); the finalize kernel reduces a clip's records and applies floor/scale (the only second pass over the 512 KB/clip output).
 #include <cstdlib>
 #include "common.h"
 
@@ -14,8 +14,6 @@
 #define HOP 160
 #define NBIN 201
 
-__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
-__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 typedef __attribute__((ext_vector_type(4))) float lm_f32x4;
 
@@ -100,8 +98,8 @@ __device__ __forceinline__ void fft25(cpx* y) {
 template <int LFT, int LF_G, bool MFMA = false>
 __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict__ wav, int Ls, const float* __restrict__ dft,
                                                          const float* __restrict__ window, const float* __restrict__ melfb,
-                                                         int n_mels, float* __restrict__ out, int* __restrict__ clip_max, int T, int dbg,
-                                                         const int* __restrict__ mrange_g, int* __restrict__ arrived,
+                                                         int n_mels, float* __restrict__ out, float* __restrict__ wg_rec, int T, int dbg,
+                                                         const int* __restrict__ mrange_g, int nseg,
                                                          const long* __restrict__ lens, int* __restrict__ mask, int nblk, int ntiles) {
   constexpr int LF_SPAN = (LFT - 1) * HOP + NFFT, LF_SCR = LF_G * NFFT * 2, LF_MELS = LFT + 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -115,9 +113,9 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   // requests the NEXT tile's span -- six 16-byte loads per thread, one round trip -- before it transforms the current one.  Measured
   // (rocprofv3, profiles/r04_za_logmel_kernel_times.txt): the kernel took 48.7 us with neither the transform nor the mel stage in it
   // (68.2 with both): a workgroup that lives for one tile spends its life in four serialized round trips (three span batches, the
-  // tables) and the store drain, two resident per CU, two rounds.  The legacy 2-D launch (`arrived` rendezvous) is one tile per group.
+  // tables) and the store drain, two resident per CU, two rounds.
   const int tid = threadIdx.x;
-  const bool legacy = gridDim.y > 1 || ntiles <= 0;
+  constexpr bool legacy = false;                   // (rounds 2-3 launched one workgroup per tile on a 2-D grid)
   // a persistent workgroup takes CONSECUTIVE tiles (the same clip, mostly): its clip maximum is then ONE device-scope atomic at the
   // end -- the kernel spent 25 of its 65 us waiting on 4 096 atomicMax to 32 addresses, one per wave and tile, each a memory-side
   // round trip that the next barrier waited for (profiles/r04_zc_logmel_floor.txt: 41.1 us without transform and mel taps, 16.3
@@ -365,34 +363,17 @@ __global__ __launch_bounds__(256) void logmel_fft_kernel(const float* __restrict
   if ((tid & 63) == 0) wred[wave] = lmax;
   __syncthreads();
   const float wm = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  if (run_b != b) {                                               // (uniform) a new clip: publish the previous one's maximum
-    if (tid == 0 && run_b >= 0 && run_max > -INFINITY) atomicMax(clip_max + run_b, f2ord(run_max));
+  // Round 5: the workgroup's maximum over its tiles of a clip goes to ITS OWN record -- a plain store, no atomic, nothing to
+  // initialise (round 4 published it with one device-scope atomicMax per workgroup into a per-clip word that a separate launch had to
+  // reset).  A workgroup's tiles are consecutive, so its records are its clips in order: record j belongs to clip (tile0 / nblk) + j;
+  // the finalize kernel reduces the records of the workgroups that touched a clip (logmel_clip_floor).
+  if (run_b != b) {                                               // (uniform) a new clip
+    if (tid == 0 && run_b >= 0) wg_rec[(long)blockIdx.x * nseg + (run_b - tile0 / nblk)] = run_max;
     run_b = b; run_max = -INFINITY;
   }
   run_max = fmaxf(run_max, wm);
-  if (arrived || tile + 1 >= tend) {                              // the rendezvous form needs it before the arrival; else: the last tile
-    if (tid == 0 && run_max > -INFINITY) atomicMax(clip_max + b, f2ord(run_max));
-    run_max = -INFINITY;
-  }
-  // Single pass (round 3 experiment, `arrived` != NULL, opt-in: it measured slower): the tile stays in LDS until every workgroup of the clip has contributed its
-  // maximum -- an arrival counter per clip, released after this workgroup's atomicMax, polled by one lane -- and is written ONCE
-  // with the (max - 8) floor and the (x + 4) / 4 map applied: no second kernel re-reading and re-writing the 512 KB per clip.
-  // The workgroups of a clip have consecutive ids, so they are resident together (the host falls back to the two-pass form when
-  // a clip has more workgroups than a quarter of the resident slots).
-  float floorv = -INFINITY, add = 0.f, mul = 1.f;
-  if (arrived) {
-    float& fl_s = *(float*)(mrange + 2 * n_mels);             // one float behind the mel ranges (sized by the host)
-    if (tid == 0) {
-      __hip_atomic_fetch_add(arrived + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const int need = nblk;
-      while (__hip_atomic_load(arrived + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
-      fl_s = ord2f(__hip_atomic_load(clip_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - 8.0f;
-    }
-    __syncthreads();
-    floorv = fl_s; add = 4.0f; mul = 0.25f;
-    if (mask && t0 == 0)
-      for (int t = tid; t < T; t += 256) mask[(long)b * T + t] = ((long)t * HOP < lens[b]) ? 1 : 0;
-  }
+  if (tile + 1 >= tend && tid == 0) wg_rec[(long)blockIdx.x * nseg + (b - tile0 / nblk)] = run_max;
+  const float floorv = -INFINITY, add = 0.f, mul = 1.f;           // (floor and scale are applied by the finalize pass)
   for (int i = tid; i < ((dbg & 8) ? 0 : n_mels * LFT); i += 256) {                 // one mel row = LFT consecutive frames per store
     const int r = i / LFT, f = i - r * LFT;
     if (t0 + f < T) out[((long)b * n_mels + r) * T + t0 + f] = (fmaxf(melbuf[r * LF_MELS + f], floorv) + add) * mul;
@@ -411,16 +392,23 @@ __global__ __launch_bounds__(256) void logmel_ranges_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) { mrange[2 * m] = lo_s; mrange[2 * m + 1] = hi_s; }
 }
-// per call: clip maxima := -inf, arrival counters := 0
-__global__ void logmel_init_kernel(int* clip_max, int B) {
-  for (int i = threadIdx.x; i < B; i += blockDim.x) { clip_max[i] = f2ord(-INFINITY); clip_max[B + i] = 0; }
-}
-
-// x = (max(x, clipmax - 8) + 4) / 4 in place; also the frame mask [B, T]: 1 iff t*160 < len[b]
-__global__ void logmel_finalize_kernel(float* __restrict__ out, const int* __restrict__ clip_max, const long* __restrict__ lens,
-                                       int* __restrict__ mask, int n_mels, int T) {
+// x = (max(x, clipmax - 8) + 4) / 4 in place; also the frame mask [B, T]: 1 iff t*160 < len[b].
+// The (max - 8) floor of clip b comes from the records of the workgroups that worked on it (logmel_fft_kernel): workgroup g covers tiles
+// [g * per, (g + 1) * per), clip b the tiles [b * nblk, (b + 1) * nblk); record j of workgroup g is its j-th clip.  One wave loads the
+// records (one per lane, independent loads) and reduces them.
+__global__ void logmel_finalize_kernel(float* __restrict__ out, const float* __restrict__ wg_rec, const long* __restrict__ lens,
+                                       int* __restrict__ mask, int n_mels, int T, int nblk, int per, int nseg, int ntiles) {
   const int b = blockIdx.y;
-  const float floorv = ord2f(clip_max[b]) - 8.0f;
+  __shared__ float floor_s;
+  if (threadIdx.x < 64) {
+    const int g_lo = (b * nblk) / per, last = min((b + 1) * nblk, ntiles) - 1, g_hi = last / per;
+    float m = -INFINITY;
+    for (int g = g_lo + (int)threadIdx.x; g <= g_hi; g += 64) m = fmaxf(m, wg_rec[(long)g * nseg + (b - (g * per) / nblk)]);
+    m = wave_max(m);
+    if (threadIdx.x == 0) floor_s = m - 8.0f;
+  }
+  __syncthreads();
+  const float floorv = floor_s;
   const long n = (long)n_mels * T;
   float* o = out + (long)b * n;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -436,41 +424,62 @@ extern "C" int ta_logmel_mel_ranges(const float* melfb, int n_mels, int* mel_ran
   return TA_OK;
 }
 
+// launch geometry of ta_logmel_f32 for (B, Ls, n_mels): tiles of LFT frames, persistent workgroups over consecutive tiles
+namespace {
+struct LogmelGeom { int T, wide, lft, nblk, ntiles, grid, per, nseg; };
+LogmelGeom logmel_geom(int B, int Ls, int n_mels) {
+  static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  LogmelGeom g;
+  g.T = Ls / HOP;
+  // the mel stage works on groups of 16 frames per thread: LFT / (256 / n_mels) >= 16 holds for <32, 2> only at n_mels = 128
+  g.wide = n_mels != 128; g.lft = g.wide ? 64 : 32;
+  g.nblk = ta_cdiv(g.T > 0 ? g.T : 1, g.lft);
+  g.ntiles = g.nblk * B;
+  const int resident = ncu * (g.wide ? 1 : 2);
+  g.grid = g.ntiles < resident ? g.ntiles : resident;
+  g.per = ta_cdiv(g.ntiles, g.grid > 0 ? g.grid : 1);
+  g.nseg = (g.per + g.nblk - 2) / g.nblk + 2;          // clips a run of `per` consecutive tiles can touch (upper bound)
+  return g;
+}
+}  // namespace
+// floats of scratch ta_logmel_f32 needs for this shape (per-workgroup clip maxima; no initial contents required)
+extern "C" long ta_logmel_scratch_floats(int B, int Ls, int n_mels) {
+  if (B <= 0 || Ls <= 0) return 1;
+  const LogmelGeom g = logmel_geom(B, Ls, n_mels);
+  return (long)g.grid * g.nseg;
+}
+
 // wav f32 [B, Ls] (zero-padded to the longest clip), lens int64 [B] -> feats f32 [B, n_mels, T], mask i32 [B, T],
-// T = Ls / 160.  clip_ws: int[2 * B] scratch (clip maxima, arrival counters: no initial contents required);
+// T = Ls / 160.  scratch: float[ta_logmel_scratch_floats(B, Ls, n_mels)] (per-workgroup clip maxima: no initial contents required, no
+// atomics, TWO launches -- round 4: int[2 B] behind an init launch, one device-scope atomicMax per workgroup);
 // mel_ranges: int[2 * n_mels] from ta_logmel_mel_ranges (computed once per filter bank).
 extern "C" int ta_logmel_f32(const float* wav, const long* lens, int B, int Ls, const float* dft, const float* window,
-                             const float* melfb, int n_mels, float* feats, int* mask, int* clip_ws, const int* mel_ranges,
+                             const float* melfb, int n_mels, float* feats, int* mask, float* scratch, const int* mel_ranges,
                              hipStream_t st) {
   if (B <= 0) return TA_OK;
   const int T = Ls / HOP;
-  if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256) || !clip_ws || !mel_ranges) return TA_ERR_ARG;
-  TA_LAUNCH(logmel_init_kernel, dim3(1), dim3(256), 0, st, clip_ws, B);
+  if (T <= 0 || Ls <= NFFT / 2 || (n_mels != 64 && n_mels != 128 && n_mels != 256) || !scratch || !mel_ranges) return TA_ERR_ARG;
+  const LogmelGeom g = logmel_geom(B, Ls, n_mels);
   {
-    auto lds_of = [&](int lft, int g) { return (size_t)((lft - 1) * HOP + NFFT + 4 * g * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 32; };
+    auto lds_of = [&](int lft, int gq) { return (size_t)((lft - 1) * HOP + NFFT + 4 * gq * NFFT * 2 + lft * LF_PWS + 3 * NFFT) * 4 + (size_t)n_mels * 2 * 4 + 32; };
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64, 4));
       (void)hipFuncSetAttribute((const void*)logmel_fft_kernel<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(32, 2));
       attr = true;
     }
-    static const int ncu = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    // the mel stage works on groups of 16 frames per thread: LFT / (256 / n_mels) >= 16 holds for <32, 2> only at n_mels = 128
-    const bool wide = n_mels != 128;
-    const int nblk = ta_cdiv(T, wide ? 64 : 32), resident = ncu * (wide ? 1 : 2);
     // persistent workgroups over the tiles of all clips (round 4).  Measured and removed in round 5: one workgroup per tile (rounds 2-3:
     // 68 us against 42), a single-pass form whose workgroups rendezvous per clip (113.7 us against 80.9, profiles/r03_f_*), the
     // sub-transforms on the f32 matrix cores (76.4 against 68.2, profiles/r04_za_*; experiment builds only).
-    const int ntiles = nblk * B;
-    const dim3 grid(ntiles < resident ? ntiles : resident);
-    if (wide)
-      TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, 0, mel_ranges, (int*)nullptr, lens, mask, nblk, ntiles);
+    const dim3 grid(g.grid);
+    if (g.wide)
+      TA_LAUNCH((logmel_fft_kernel<64, 4>), grid, dim3(256), lds_of(64, 4), st, wav, Ls, dft, window, melfb, n_mels, feats, scratch, T, 0, mel_ranges, g.nseg, lens, mask, g.nblk, g.ntiles);
     else
-      TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, clip_ws, T, 0, mel_ranges, (int*)nullptr, lens, mask, nblk, ntiles);
+      TA_LAUNCH((logmel_fft_kernel<32, 2>), grid, dim3(256), lds_of(32, 2), st, wav, Ls, dft, window, melfb, n_mels, feats, scratch, T, 0, mel_ranges, g.nseg, lens, mask, g.nblk, g.ntiles);
   }
   {
     int gx = ta_cdiv((long)n_mels * T, 256 * 4); if (gx < 1) gx = 1;
-    TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, clip_ws, lens, mask, n_mels, T);
+    TA_LAUNCH(logmel_finalize_kernel, dim3(gx, B), dim3(256), 0, st, feats, (const float*)scratch, lens, mask, n_mels, T, g.nblk, g.per, g.nseg, g.ntiles);
   }
   TA_CHECK_LAUNCH();
   return TA_OK;
