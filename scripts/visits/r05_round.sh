@@ -19,9 +19,9 @@ cd /tmp && export TMPDIR=/tmp
 P=$OUT/prof_$TAG; rm -rf $P; mkdir -p $P
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P -o b -- python $REPO/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-logits-full > $P/run.log 2>&1; echo "rocprof rc=$?"
 TR=$(find $P -name "*kernel_trace.csv" | head -1)
-python $REPO/scripts/summarize_trace_steps.py $TR $OUT/${TAG}_kernel_steps.md --skip 1 --note "bench.py --steps 4 --warmup 1 (configs[1], B = 32), rocprofv3 --kernel-trace --stats; round-5 head" | head -30
+[ -n "$TR" ] && python $REPO/scripts/summarize_trace_steps.py $TR $OUT/${TAG}_kernel_steps.md --skip 1 --note "bench.py --steps 4 --warmup 1 (configs[1], B = 32), rocprofv3 --kernel-trace --stats; round-5 head" | head -30
 ST=$(find $P -name "*kernel_stats.csv" | head -1)
-python $REPO/scripts/summarize_rocprof.py $ST $OUT/${TAG}_kernel_stats.md --steps 5 --note "rocprofv3 --kernel-trace --stats of bench.py --steps 4 --warmup 1 (includes model construction)" > /dev/null
+[ -n "$ST" ] && python $REPO/scripts/summarize_rocprof.py $ST $OUT/${TAG}_kernel_stats.md --steps 5 --note "rocprofv3 --kernel-trace --stats of bench.py --steps 4 --warmup 1 (includes model construction)" > /dev/null
 find $P -name "*kernel_trace.csv" -delete
 cd $REPO
 PMC_CMD="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-logits-full" bash scripts/gpu_pmc.sh ${TAG}_in_situ 2>&1 | tail -8
