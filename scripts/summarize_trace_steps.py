@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-STEP kernel table from a rocprofv3 --kernel-trace CSV of bench.py: model construction and warm-up are cut off (a step
-starts at its logmel_init_kernel / logmel_power_kernel launch), so the table holds exactly what one training step launches.
+starts at its logmel_fft_kernel launch; rounds 1-4: logmel_init_kernel / logmel_power_kernel), so the table holds exactly what one training step launches.
 
 usage: summarize_trace_steps.py <kernel_trace.csv> <out.md> [--skip N] [--note "..."]"""
 import csv
@@ -28,6 +28,8 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     starts = [i for i, r in enumerate(rows) if "logmel_init_kernel" in r[2] or "logmel_power_kernel" in r[2]]
+    if not starts:                                         # round 5: the init launch is gone; a step's first kernel is the FFT kernel
+        starts = [i for i, r in enumerate(rows) if "logmel_fft_kernel" in r[2]]
     if len(starts) <= skip + 1:
         raise SystemExit(f"only {len(starts)} steps in the trace")
     lo, hi = starts[skip], starts[-1]                      # whole steps only: from step `skip` to the start of the last one
