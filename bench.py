@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--sync-allreduce", action="store_true", help="N > 1: all-reduce synchronously on the compute stream")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--step-times", action="store_true", help="diagnostic: per-step GPU times of the timed region (events) in the line")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: torch.distributed backend.  'gloo' (CUDA tensors through the host) + --share-gpu run the whole N > 1 path -- "
+                         "real kernels, flat all-reduce, deferred update, replica check -- on a ONE-GPU box; only the transport is not RCCL")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (validation on a one-GPU box; the timings mean nothing)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT a GPU: tiny model on the CPU, every kernel launch a marshalling-only stub, gloo instead "
                          "of RCCL.  Exercises the N > 1 control flow of this script (tests/test_host_logic.py); its numbers mean nothing")
@@ -176,7 +180,7 @@ def relaunch_if_needed(a):
         return
     import socket
     import subprocess
-    n = a.gpus if getattr(a, "dry_run", False) else torch.cuda.device_count()
+    n = a.gpus if (getattr(a, "dry_run", False) or getattr(a, "share_gpu", False)) else torch.cuda.device_count()
     if n < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n} GPU(s) visible on this node")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -205,6 +209,8 @@ def run(a):
     if dry:
         dev = torch.device("cpu")
     else:
+        if a.share_gpu:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     sync = (lambda: None) if dry else torch.cuda.synchronize
@@ -213,6 +219,12 @@ def run(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
         probe = torch.ones(1)
+        dist.all_reduce(probe)
+        rccl_ranks = int(probe.item())
+    elif world > 1 and a.dist_backend == "gloo":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)
         rccl_ranks = int(probe.item())
     elif world > 1:
@@ -465,6 +477,8 @@ def run(a):
         rec = {"metric": "training audio-sec/sec on 10s@16kHz clips", "value": round(value, 1), "unit": "audio-s/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", **({"dry_run": True} if dry else {}),
+               **({"validation_only": "ranks share one GPU over gloo: the N > 1 control flow with real kernels, not a measurement"}
+                  if (a.share_gpu or (world > 1 and a.dist_backend == "gloo" and not dry)) else {}),
                "data": "synthetic (0.1*N(0,1) waveforms, random-init weights at true shapes; the same batch every step)",
                "config": {"workload": ("embedded.yaml: full decoder fine-tuning, MLP projector (H=%d) + every LM weight" % a.proj_hidden if a.full_ft else
                                        "configs[4]: stage 2, frozen MLP projector + LoRA r=8 alpha=32 on q,k,v,o,gate,up,down" if a.lora
@@ -491,7 +505,8 @@ def run(a):
                "logits_full": logits_full, "streams_other": streams_other, "host_inputs": host_inputs, "roofline": roofline,
                "cpu_baseline": cpu, "parity": parity, "numerics": numerics_contract(a.streams)}
         if replicas is not None:
-            replicas["rccl_version"] = "gloo (dry run)" if dry else ".".join(str(x) for x in torch.cuda.nccl.version())
+            replicas["rccl_version"] = ("gloo (dry run)" if dry else "gloo (--dist-backend gloo: not RCCL)" if a.dist_backend == "gloo"
+                                        else ".".join(str(x) for x in torch.cuda.nccl.version()))
             if rccl_log and os.path.exists(rccl_log):
                 with open(rccl_log, errors="replace") as fh:
                     replicas["rccl"] = parse_rccl_log(fh.read())

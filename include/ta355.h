@@ -518,7 +518,11 @@ int ta_cross_entropy(const void* logits, int logits_bf16, long ldl, const int* r
 int ta_label_rows(const long* labels, int B, int L, int* rows, long* targets, int* n_out, hipStream_t st);
 
 /* optimizer: clip_grad_norm_(max_norm) + AdamW on fp32 masters (configs/training/production.yaml:5-9) */
-int ta_grad_sqnorm(const float* g, long n, float* accum, hipStream_t st);
+/* accum[0] += sum(g^2), DETERMINISTICALLY (two launches: per-block partials into scratch, then one block adds them in index order):
+ * data-parallel ranks that hold the same all-reduced gradient must compute bit-identical clip coefficients, or their replicas
+ * drift apart.  scratch: float[TA_SQNORM_SCRATCH_FLOATS], no initial contents required. */
+#define TA_SQNORM_SCRATCH_FLOATS 1024
+int ta_grad_sqnorm(const float* g, long n, float* accum, float* scratch, hipStream_t st);
 int ta_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, const float* sqnorm, float max_norm, float grad_scale,
                   const float* denom, hipStream_t st);

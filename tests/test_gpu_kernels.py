@@ -465,6 +465,26 @@ def test_adamw_and_clip():
     assert float(d.mean()) < 1e-7 and float(d.max()) < 3e-4
 
 
+def test_grad_sqnorm_is_bit_reproducible():
+    """ta_grad_sqnorm must give the SAME float for the same gradient whatever order its blocks finish in: data-parallel ranks compute
+    the clip coefficient from it independently, and a last-bit difference makes their replicas drift apart (rounds 1-4 used one float
+    atomicAdd per block).  6.3 M elements (the MLP projector's flat gradient), 40 launches with other kernels in between."""
+    g = rnd(6293504 + 12, seed=3, scale=2.0)
+    junk = torch.empty(32 * 1024 * 1024, device=DEV, dtype=torch.int16)
+    seen = set()
+    for it in range(40):
+        if it % 3 == 0:
+            junk.fill_(it)
+        sq = torch.zeros(1, device=DEV)
+        ops.grad_sqnorm(g, sq)
+        seen.add(float(sq))
+    assert len(seen) == 1, sorted(seen)
+    v = seen.pop()
+    assert abs(v - float((g.double() ** 2).sum())) < 1e-5 * v
+    sq = torch.full((1,), 5.0, device=DEV); ops.grad_sqnorm(g, sq)                # accumulates
+    assert abs(float(sq) - (v + 5.0)) < 1e-6 * v
+
+
 def test_adamw_multi_matches_per_segment():
     """One launch over a flat buffer of segments with their own (lr, weight decay) == one ta_adamw_step per segment, bit for bit."""
     sizes = [1024, 12, 40000, 4, 5120 * 4, 8]

@@ -2,8 +2,14 @@
 // (configs/training/production.yaml:5-9: adamw_torch_fused, max_grad_norm 1.0; decay groups of
 // scripts/train.py:427-432).  The clip coefficient is read from device memory so the step needs no host sync.
 #include "common.h"
+#include "../../include/ta355.h"
 
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ accum) {
+// Round 5: DETERMINISTIC.  Every block writes its partial sum to part[blockIdx.x]; a one-block kernel adds the partials in index
+// order.  (Rounds 1-4 ended every block with atomicAdd(accum, ...): the order of up to 1 024 float additions depended on which block
+// finished first, so two data-parallel ranks holding the SAME all-reduced gradient computed clip coefficients that differed in the
+// last bits and their replicas drifted apart bit by bit -- found by tests/test_gpu_round5.py::
+// test_trainer_two_ranks_real_kernels_on_one_gpu, the first time the N > 1 path ran on real kernels.)
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
   __shared__ float red[4];
   float s = 0.f;
   const long n4 = n / 4;
@@ -15,7 +21,16 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(accum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ accum) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) accum[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // one element of the update; contraction off so that the scalar and the float4 kernel round identically
@@ -84,10 +99,12 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(float* __restrict__ p,
   }
 }
 
-extern "C" int ta_grad_sqnorm(const float* g, long n, float* accum, hipStream_t st) {
+extern "C" int ta_grad_sqnorm(const float* g, long n, float* accum, float* scratch, hipStream_t st) {
   if (n <= 0) return TA_OK;
-  long b = (n / 4 + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
-  TA_LAUNCH(sqnorm_kernel, dim3((int)b), dim3(256), 0, st, g, n, accum);
+  if (!accum || !scratch) return TA_ERR_ARG;
+  long b = (n / 4 + 255) / 256; if (b > TA_SQNORM_SCRATCH_FLOATS) b = TA_SQNORM_SCRATCH_FLOATS; if (b < 1) b = 1;
+  TA_LAUNCH(sqnorm_kernel, dim3((int)b), dim3(256), 0, st, g, n, scratch);
+  TA_LAUNCH(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, (int)b, accum);
   TA_CHECK_LAUNCH(); return TA_OK;
 }
 extern "C" int ta_adamw_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,

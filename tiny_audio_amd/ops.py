@@ -393,8 +393,11 @@ def bernoulli_keep(n, keep_prob, seed, device):
     return keep
 
 
-def grad_sqnorm(g, accum):
-    check(lib().ta_grad_sqnorm(ptr(g), g.numel(), ptr(accum), stream()), "ta_grad_sqnorm")
+def grad_sqnorm(g, accum, scratch=None):
+    """accum[0] += sum(g ** 2), bit-reproducibly (``scratch``: f32 [1024], allocated here when not given)."""
+    if scratch is None:
+        scratch = torch.empty(1024, device=g.device, dtype=F32)
+    check(lib().ta_grad_sqnorm(ptr(g), g.numel(), ptr(accum), ptr(scratch), stream()), "ta_grad_sqnorm")
 
 
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_norm=0.0, grad_scale=1.0, denom=None):

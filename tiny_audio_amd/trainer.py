@@ -241,6 +241,7 @@ class ASRTrainer:
         if lm is not None and getattr(lm, "train_base", False):
             lm.accumulate_into_grad = True      # d(loss) is 1 here: weight gradients go straight into the flat buffer
         self.sqnorm = torch.zeros(1, device=self.flat.flat_p.device, dtype=torch.float32)
+        self._sq_scratch = torch.empty(1024, device=self.flat.flat_p.device, dtype=torch.float32)   # ta_grad_sqnorm's per-block partials
         self._adam_table = None
         self.global_step = 0
         self._micro = 0
@@ -343,7 +344,7 @@ class ASRTrainer:
                 for n in f.shadow_names:
                     f.grad_of(n).addcmul_(f.shadow(n), nm1.expand_as(f.shadow(n)))
         self.sqnorm.zero_()
-        ops.grad_sqnorm(f.grads, self.sqnorm)
+        ops.grad_sqnorm(f.grads, self.sqnorm, self._sq_scratch)
         mult = lr_multiplier(self.global_step - 1, a)
         if self._adam_table is None:              # per-parameter (learning rate, weight decay) as a device table: ONE launch per step
             hp = [self.group_hparams(name, dec) for name, dec in zip(f.names, f.decay)]
