@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL fails with `hipIpcGetMemHandle: invalid argument`.  Set BEFORE the HIP
+# runtime comes up (it reads the environment when the first device call initialises it), i.e. before torch touches a GPU
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
