@@ -289,6 +289,34 @@ def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
     assert cosine(grads["float32"][0], grads["bfloat16"][0]) > 0.995
 
 
+def test_backward_reads_its_tape_in_the_mode_it_was_recorded_in():
+    """The stream storage mode is process-wide state (ta_set_stream_modes) and the tape's residual rows are stored in it: a
+    backward that runs after ANOTHER model's forward changed the mode must still read its tape as recorded (language_model.py keeps
+    the mode per tape).  Forward in bf16 streams, mode switched to fp32 before the backward: same gradient as undisturbed."""
+    enc, lmc = OW.enc_config(256, 512, 2, 4), OW.lm_config(1024, 256, 512, 2, 4, 2, 128)
+    grads = []
+    for disturb in (False, True):
+        cfg = ASRConfig(audio_config=enc, text_config=lmc, projector_hidden_dim=128, audio_token_id=1023, pad_token_id=1000,
+                        eos_token_id=1001, model_dtype="bfloat16", audio_token_dropout=0.0)
+        torch.manual_seed(0)
+        m = ASRModel(cfg, device=DEV, init="random", seed=0)
+        f = LogMelFeatureExtractor(128, DEV)([OW.synthetic_wave(0, 32000)], sampling_rate=16000)
+        ids, att, lab, counts = OW.synthetic_tokens(1, 25, 1024, 1023, 1000, 1001, n_text=10, n_suffix=4)
+        T = torch.from_numpy
+        m.train()
+        out = m(input_ids=T(ids), input_features=f["input_features"], attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts))
+        if disturb:
+            ops.set_stream_modes(True, True, True)                        # what a float32 model's forward would leave behind
+        out.loss.backward()
+        if disturb:
+            assert ops.get_stream_modes() == dict(enc_res_f32=True, lm_res_f32=True, lm_dx_f32=True)    # ... and is left as found
+        g = npy(m.projector.linear_1.weight.grad)
+        assert np.isfinite(g).all()
+        grads.append(g)
+    assert cosine(grads[0], grads[1]) > 0.999999
+    np.testing.assert_allclose(grads[1], grads[0], rtol=0, atol=1e-5 * float(np.abs(grads[0]).max()))
+
+
 # ============================================================================ (d) ADVICE r4: the MoE auxiliary shadow, numerically
 def _moe_model(seed=0):
     enc, lmc = OW.enc_config(256, 512, 1, 4), OW.lm_config(1024, 256, 512, 2, 4, 2, 128)

@@ -459,6 +459,15 @@ class Qwen3MI355X(torch.nn.Module):
                    "ta_lm_forward_loss")
         ctx = dict(tape=tape, ws=ws, B=B, L=L, src_row=src_row, kmask=kmask, pos=pos, label_rows=label_rows,
                    n_label_rows=n_label_rows, ids=input_ids)
+        # The tape's residual-stream rows are in the storage dtype that was set NOW (ta_set_stream_modes is process-wide state): the
+        # backward must read them as that, whatever another model's forward has set in between.  Keyed by the tape's address, since
+        # the custom operator hands the backward only tensors.
+        if not _lib.DRY_RUN:
+            from . import ops as _ops
+            self._tape_modes = {k: v for k, v in getattr(self, "_tape_modes", {}).items() if k != tape.data_ptr()}
+            if len(self._tape_modes) > 64:
+                self._tape_modes.clear()
+            self._tape_modes[tape.data_ptr()] = _ops.get_stream_modes()
         return loss, nll, logits, ctx
 
     def backward_from_ctx(self, ctx, n_audio_rows, want_d_embeds=False, want_d_audio=True):
@@ -496,11 +505,23 @@ class Qwen3MI355X(torch.nn.Module):
             wg = _lib.LmWgrads(layers=C.cast(arr, C.POINTER(_lib.LmLayerWgrads)), dnorm=bufs[8].data_ptr(), dembed=bufs[9].data_ptr())
             keep = (arr, bufs)
             lg = [None] * len(ps) if direct else bufs
-        _lib.check(_lib.lib().ta_lm_backward(C.byref(self._w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
-                                             ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
-                                             ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr,
-                                             None if wg is None else C.byref(wg), ptr(ctx.get("ids")), ptr(ctx["tape"]),
-                                             ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
+        recorded = getattr(self, "_tape_modes", {}).get(ctx["tape"].data_ptr())
+        restore = None
+        if recorded is not None and not _lib.DRY_RUN:
+            from . import ops as _ops
+            now = _ops.get_stream_modes()
+            if now != recorded:
+                restore = now
+                _ops.set_stream_modes(**recorded)
+        try:
+            _lib.check(_lib.lib().ta_lm_backward(C.byref(self._w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
+                                                 ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
+                                                 ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr,
+                                                 None if wg is None else C.byref(wg), ptr(ctx.get("ids")), ptr(ctx["tape"]),
+                                                 ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
+        finally:
+            if restore is not None:
+                _ops.set_stream_modes(**restore)
         del keep
         return d_audio, d_emb, lg
 
