@@ -24,25 +24,24 @@ typedef struct ihipStream_t* hipStream_t;
 #define TA_ERR_ARG 1
 #define TA_ERR_LAUNCH 2
 
-int ta_version(void); /* ABI version, currently 3 (round 5: the opt-in paths that measured slower left the library -- ta_enc_layer lost its
+int ta_version(void); /* ABI version, currently 4 (round 6: the residual-stream storage mode left process-wide state -- ta_set_stream_modes /
+                          ta_get_stream_modes are gone, ta_encoder_weights.res_f32 and ta_lm_weights.res_f32 / dx_f32 carry it per handle.
+                          Version 3 was round 5's: the opt-in paths that measured slower left the library -- ta_enc_layer lost its
                           wqk_il / *_ln image fields, ta_gemm_opts its swiglu_* / lnf_* fields, ta_layernorm_stats / ta_attention_bwd_gqa /
-                          ta_attention_bwd_qkv_o are gone; ta_set_stream_modes / ta_get_stream_modes are new.  Version 2 was round 3's:
-                          ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa, ta_attention_enc_fwd, ta_logmel_f32's scratch contract) */
+                          ta_attention_bwd_qkv_o went.  Version 2 was round 3's: ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa,
+                          ta_attention_enc_fwd, ta_logmel_f32's scratch contract) */
 
-/* ---- storage dtype of the residual streams (round 5; the numerics contract of DESIGN.md section 6).  Process-wide.
+/* ---- storage dtype of the residual streams (the numerics contract of DESIGN.md section 6): a field of the weights handle
+ * each call receives (ta_encoder_weights.res_f32; ta_lm_weights.res_f32 / dx_f32), so two models of different model_dtype -- or a
+ * decoding thread beside a training step (tiny_audio/asr_modeling.py:733-734) -- share the library without sharing a mode.
  * The reference runs its frozen models either as bf16 MODULES (ASRConfig default model_dtype="bfloat16",
  * tiny_audio/asr_config.py:41: every residual add / norm input is bf16) or -- the training recipe of BASELINE configs[1] -- as
  * fp32 modules under bf16 autocast (configs/config.yaml:14-18 + configs/training/production.yaml:49; loaders
  * tiny_audio/asr_modeling.py:203-254: residual stream, norm in/out and embeddings stay fp32, only Linear / attention run in bf16).
- * 0 = bf16 storage (the first regime), 1 = fp32 storage (the second); a negative argument leaves that stream unchanged.
+ * 0 = bf16 storage (the first regime), 1 = fp32 storage (the second).
  * MFMA operand (bf16) and accumulator (fp32) types are the same in both; norms / softmax / CE arithmetic is fp32 in both.
- *   enc_res_f32: encoder residual stream;  lm_res_f32: LM forward residual stream and its tape;  lm_dx_f32: LM backward d(x)
- *   stream (bf16 only together with a bf16 forward stream).
- * Initial values 0 / 0 / 0.
- * Change it BETWEEN steps only: a forward's tape must be read back by a backward in the same mode.  Workspace / tape sizes do not
+ * A forward's tape must be read back by a backward whose handle carries the same res_f32 / dx_f32.  Workspace / tape sizes do not
  * depend on the mode (the fp32 size is always reserved). */
-int ta_set_stream_modes(int enc_res_f32, int lm_res_f32, int lm_dx_f32);
-int ta_get_stream_modes(int* out3 /* host int[3] */);
 
 /* ============================================================================================
  * Composite ops (what a binding would call)
@@ -100,6 +99,7 @@ typedef struct {
   const float *rope_cos, *rope_sin; /* [max_pos, 16] (partial rotary: 32 of 64 dims) */
   const ta_enc_layer* layers;       /* host array [n_layers] */
   const float* rope_il;             /* [max_pos, 16, 2] (cos, sin) interleaved, or NULL (see ta_enc_layer.wqkv_fa) */
+  int res_f32;                      /* storage of the residual stream: 0 = bf16, 1 = fp32 (see the top of this file) */
 } ta_encoder_weights;
 
 long ta_encoder_workspace_bytes(const ta_encoder_weights* w, int B, int T);
@@ -220,6 +220,9 @@ typedef struct {
                                        a bit costs nothing (no rank-space GEMM, no K extension, gradients left at zero); inside
                                        a group, members that are not targeted keep A = B = 0 in the masters and so get exactly
                                        zero gradients (dA = s (dy B)^T x, dB = dy^T (x A^T)). */
+  int res_f32;                      /* storage of the forward residual stream and of its rows in the tape: 0 = bf16, 1 = fp32 */
+  int dx_f32;                       /* storage of the backward d(x) stream: 0 = follows res_f32, 1 = fp32 even over a bf16 forward
+                                       stream (rounds 1-3) */
 } ta_lm_weights;
 
 /* Gradients of the LM's own weights (full decoder fine-tuning).  All f32, ACCUMULATED (+=) into the caller's buffers, which

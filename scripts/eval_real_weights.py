@@ -74,7 +74,7 @@ def main():
                                      lm_state_dict=hub_weights.lm_state_dict(a.text_model_dir))
     model.eval()
     fe = LogMelFeatureExtractor(128, "cuda")
-    proc = ASRProcessor(fe, model.projector)
+    proc = model.get_processor()
     rows = [json.loads(l) for l in open(a.manifest) if l.strip()]
     norm = make_normalizer(a.whisper_dir)
     eos = [tok.convert_tokens_to_ids("<|im_end|>"), tok.convert_tokens_to_ids("<|endoftext|>")]

@@ -29,9 +29,6 @@ def golden():
     return load
 
 
-_STREAM_DEFAULT = None
-
-
 @pytest.fixture(autouse=True)
 def _poison_free_gpu_memory(request):
     """-m gpu tests: fill the allocator's free pool with NaN bit patterns before every test, so that a kernel reading memory
@@ -42,11 +39,4 @@ def _poison_free_gpu_memory(request):
             blocks = [torch.full((64 * 1024 * 1024,), float("nan"), device="cuda") for _ in range(4)]    # 4 x 256 MB
             small = [torch.full((n,), float("nan"), device="cuda") for n in (256, 4096, 65536, 1 << 20) for _ in range(8)]
             del blocks, small
-            # the residual-stream storage mode is process-wide (ta_set_stream_modes): every test starts from the default (bf16, or
-            # whatever TA355_*_F32 asked for at load) whatever the previous test's ASRConfig.model_dtype left behind
-            from tiny_audio_amd import ops
-            global _STREAM_DEFAULT
-            if _STREAM_DEFAULT is None:
-                _STREAM_DEFAULT = ops.get_stream_modes()
-            ops.set_stream_modes(**_STREAM_DEFAULT)
     yield

@@ -13,6 +13,11 @@ from oracle import weights as OW
 from tiny_audio_amd import _lib
 
 
+class _StubTok:
+    def convert_tokens_to_ids(self, t):
+        return 999
+
+
 @pytest.fixture()
 def dry():
     _lib.DRY_RUN = True
@@ -39,7 +44,7 @@ def test_full_training_step_plumbing(dry):
     fe = LogMelFeatureExtractor(128, "cpu")
     f = fe([OW.synthetic_wave(0, 16000), OW.synthetic_wave(1, 12000)], sampling_rate=16000)
     assert f["input_features"].shape == (2, 128, 100) and f["attention_mask"].shape == (2, 100)
-    proc = ASRProcessor(fe, m.projector)
+    proc = ASRProcessor(fe, _StubTok(), m.projector)
     assert proc.audio_token_counts(torch.ones(2, 100, dtype=torch.int32)).tolist() == [12, 12]
     ids, att, lab, counts = OW.synthetic_tokens(2, [12, 9], 1000, 999, 990, 991, n_text=10, n_suffix=4, ragged=True)
     batch = dict(input_ids=torch.from_numpy(ids), input_features=f["input_features"], attention_mask=torch.from_numpy(att),

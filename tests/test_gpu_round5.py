@@ -98,7 +98,7 @@ def test_benchmarked_model_vs_reference_recipe_fixture(golden, streams):
     f = LogMelFeatureExtractor(128, DEV)([OW.synthetic_wave(0)], sampling_rate=16000)
     out = m(input_ids=torch.from_numpy(ids), input_features=f["input_features"], attention_mask=torch.from_numpy(att),
             labels=torch.from_numpy(lab), audio_token_counts=torch.from_numpy(counts), return_logits=True)
-    assert ops.get_stream_modes() == dict(enc_res_f32=streams == "f32", lm_res_f32=streams == "f32", lm_dx_f32=streams == "f32")
+    assert (m.audio_tower.res_f32, m.language_model.res_f32, m.language_model.dx_f32) == (streams == "f32",) * 3
     out.loss.backward()
     torch.cuda.synchronize()
     rows = g["rows"]
@@ -168,7 +168,6 @@ def test_full_depth_one_clip_vs_oracle_f32_streams(kind, monkeypatch):
         orig_record(name + "_f32_streams", rec)
     monkeypatch.setattr(T3, "_record_drift", record)
     T3.test_full_depth_one_clip_vs_oracle(kind)
-    assert ops.get_stream_modes()["lm_res_f32"] and ops.get_stream_modes()["enc_res_f32"]
     _record(kind + "_vs_oracle_f32_streams", seen.get("rec", {}), fname="r05_full_depth_drift_both_modes.json")
 
 
@@ -263,7 +262,7 @@ def test_forward_refuses_hf_decoding_arguments(kw):
 
 
 def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
-    """ta_set_stream_modes / ASRConfig.model_dtype (include/ta355.h): both storage modes run the same model in one process and
+    """ta_encoder_weights.res_f32 / ta_lm_weights.res_f32, dx_f32 <- ASRConfig.model_dtype (include/ta355.h): both storage modes run the same model in one process and
     agree to bf16-storage rounding; the tape / workspace sizes do not depend on the mode."""
     enc, lmc = OW.enc_config(256, 512, 2, 4), OW.lm_config(1024, 256, 512, 2, 4, 2, 128)
     losses, grads = {}, {}
@@ -279,7 +278,7 @@ def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
         out = m(input_ids=T(ids), input_features=f["input_features"], attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts))
         out.loss.backward()
         want = dt == "float32"
-        assert ops.get_stream_modes() == dict(enc_res_f32=want, lm_res_f32=want, lm_dx_f32=want)
+        assert (m.audio_tower._w.res_f32, m.language_model._w.res_f32, m.language_model._w.dx_f32) == (int(want),) * 3
         losses.setdefault(dt, []).append(float(out.loss))
         grads.setdefault(dt, []).append(npy(m.projector.linear_1.weight.grad))
     # switching back restores the bf16-stream result (up to the float atomics of the loss sum / split-K weight gradients: ~1e-7)
@@ -290,9 +289,9 @@ def test_stream_modes_follow_model_dtype_and_do_not_change_sizes():
 
 
 def test_backward_reads_its_tape_in_the_mode_it_was_recorded_in():
-    """The stream storage mode is process-wide state (ta_set_stream_modes) and the tape's residual rows are stored in it: a
-    backward that runs after ANOTHER model's forward changed the mode must still read its tape as recorded (language_model.py keeps
-    the mode per tape).  Forward in bf16 streams, mode switched to fp32 before the backward: same gradient as undisturbed."""
+    """The tape's residual rows are stored in the mode the handle carried at the forward: a backward that runs after the owner
+    flipped ``res_f32`` must still read its tape as recorded (language_model.py keeps the mode per tape).  Forward in bf16 streams,
+    handle switched to fp32 before the backward: same gradient as undisturbed."""
     enc, lmc = OW.enc_config(256, 512, 2, 4), OW.lm_config(1024, 256, 512, 2, 4, 2, 128)
     grads = []
     for disturb in (False, True):
@@ -306,15 +305,79 @@ def test_backward_reads_its_tape_in_the_mode_it_was_recorded_in():
         m.train()
         out = m(input_ids=T(ids), input_features=f["input_features"], attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts))
         if disturb:
-            ops.set_stream_modes(True, True, True)                        # what a float32 model's forward would leave behind
+            m.language_model.res_f32 = m.language_model.dx_f32 = True      # what the owner's next float32 forward would set
         out.loss.backward()
         if disturb:
-            assert ops.get_stream_modes() == dict(enc_res_f32=True, lm_res_f32=True, lm_dx_f32=True)    # ... and is left as found
+            assert m.language_model.res_f32 and m.language_model._w.res_f32 == 1      # ... and is left as found
         g = npy(m.projector.linear_1.weight.grad)
         assert np.isfinite(g).all()
         grads.append(g)
     assert cosine(grads[0], grads[1]) > 0.999999
     np.testing.assert_allclose(grads[1], grads[0], rtol=0, atol=1e-5 * float(np.abs(grads[0]).max()))
+
+
+def test_two_models_of_different_stream_modes_interleaved_from_two_threads():
+    """a bf16-stream and an f32-stream model in ONE process, forward / backward of both interleaved from two
+    Python threads (the reference's generate_streaming runs its LM on a second thread, tiny_audio/asr_modeling.py:733-734): each
+    model's loss and projector gradients equal its own single-model run (to the 1e-6 of the loss sum's float atomics; the two modes
+    differ from each other by ~1e-3 ... 1e-2, four orders above that).  With the process-wide mode of rounds 1-5 the two forwards
+    raced on it."""
+    import threading
+    enc, lmc = OW.enc_config(256, 512, 2, 4), OW.lm_config(1024, 256, 512, 2, 4, 2, 128)
+    T = torch.from_numpy
+
+    def build(dt):
+        cfg = ASRConfig(audio_config=enc, text_config=lmc, projector_hidden_dim=128, audio_token_id=1023, pad_token_id=1000,
+                        eos_token_id=1001, model_dtype=dt, audio_token_dropout=0.0)
+        torch.manual_seed(0)
+        m = ASRModel(cfg, device=DEV, init="random", seed=0)
+        m.train()
+        return m
+    f = LogMelFeatureExtractor(128, DEV)([OW.synthetic_wave(0, 32000), OW.synthetic_wave(1, 32000)], sampling_rate=16000)
+    ids, att, lab, counts = OW.synthetic_tokens(2, 25, 1024, 1023, 1000, 1001, n_text=10, n_suffix=4)
+    feats = f["input_features"].clone()
+
+    def step(m):
+        m.zero_grad(set_to_none=True)
+        out = m(input_ids=T(ids), input_features=feats, attention_mask=T(att), labels=T(lab), audio_token_counts=T(counts),
+                return_logits=False)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        return float(out.loss), {k: p.grad.clone() for k, p in m.projector.named_parameters()}
+    models = {dt: build(dt) for dt in ("bfloat16", "float32")}
+    alone = {dt: step(m) for dt, m in models.items()}
+    assert alone["bfloat16"][0] != alone["float32"][0]                         # the two modes are different functions
+    got, errs = {dt: [] for dt in models}, []
+    gate = threading.Barrier(2)
+
+    def worker(dt):
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.default_stream())
+            with torch.cuda.stream(s):
+                for _ in range(6):
+                    gate.wait(timeout=120)                                     # both threads enter a step together, every time
+                    got[dt].append(step(models[dt]))
+        except Exception as e:  # noqa: BLE001
+            errs.append((dt, repr(e)))
+            gate.abort()
+    threads = [threading.Thread(target=worker, args=(dt,)) for dt in models]
+    [t.start() for t in threads]
+    [t.join(timeout=600) for t in threads]
+    assert not errs, errs
+    for dt in models:
+        assert len(got[dt]) == 6
+        for loss, grads in got[dt]:
+            assert abs(loss - alone[dt][0]) <= 2e-6 * abs(alone[dt][0]), (dt, loss, alone[dt][0])
+            for k, g in grads.items():
+                ref = alone[dt][1][k]
+                assert float((g - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (dt, k)
+    other = {"bfloat16": "float32", "float32": "bfloat16"}
+    for dt in models:                                                          # ... and a step run in the OTHER mode would have been seen
+        k = "linear_1.weight"
+        d = float((alone[dt][1][k] - alone[other[dt]][1][k]).abs().max()) / float(alone[dt][1][k].abs().max())
+        assert d > 1e-4, d
+    assert (models["bfloat16"].language_model._w.res_f32, models["float32"].language_model._w.res_f32) == (0, 1)
 
 
 # ============================================================================ (d) ADVICE r4: the MoE auxiliary shadow, numerically
@@ -521,3 +584,29 @@ def test_bench_two_ranks_real_kernels_on_one_gpu():
     ar = d["allreduce"]
     assert ar["bytes"] == 4 * (6293504 + 2) and ar["other_mode"]["mode"] == "synchronous"
     assert d["validation_only"] and 11.0 < d["final_loss"] < 13.0
+    assert ar["collectives_per_step"] == 1.0
+
+
+@pytest.mark.parametrize("flags,elements", [(["--projector", "moe"], None), (["--lora"], 5046272 + 2),
+                                             (["--full-ft", "--batch", "8"], None)], ids=["moe", "lora", "fullft"])
+def test_bench_two_ranks_other_configs_on_one_gpu(flags, elements):
+    """the N > 1 product path of configs[3] (MoE: the auxiliary-loss shadow segment rides in the same buffer),
+    configs[4] (LoRA stage 2: adapter gradients only) and the full-decoder fine-tune (2.4 GB of gradients), two ranks on this box's
+    one GPU over gloo with the real kernels: replicas identical after the steps, ONE collective per optimizer step, exit code 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--steps", "3",
+                        "--warmup", "2", "--no-cpu-baseline", "--no-logits-full", "--no-roofline", *flags], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-800:], r.stderr[-800:])
+    d = json.loads(lines[-1])
+    assert d.get("error") is None and d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["validation_only"]
+    rep, ar = d["replicas"], d["allreduce"]
+    assert rep["replicas_identical"] is True and rep["global_step"]["min"] == rep["global_step"]["max"] > 0
+    assert rep["weight_checksum"]["sum_min"] == rep["weight_checksum"]["sum_max"]
+    assert ar["collectives_per_step"] == 1.0 and ar["other_mode"]["mode"] == "synchronous"
+    if elements is not None:
+        assert ar["elements"] == elements
+    assert ar["bytes"] == 4 * ar["elements"] and np.isfinite(d["final_loss"])

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     handle = _lib.lib()                      # binds every prototype; AttributeError if one is not exported
     for name in protos:
         assert hasattr(handle, name), name
-    assert handle.ta_version() == 3
+    assert handle.ta_version() == 4
     # every extern "C" ta_* symbol the library exports is declared in the header (no undocumented entry points)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True).stdout
@@ -256,7 +256,8 @@ def test_collator_contract(dry_lib_for_features):
     rng = np.random.RandomState(0)
     mk = lambda text, sec: {"audio": {"array": (0.1 * rng.standard_normal(int(sec * 16000))).astype(np.float32), "sampling_rate": 16000}, "text": text}
     batch = col([mk("Hello World this is a TEST <comma>", 1.0), mk("second clip", 2.0)])
-    assert set(batch) == {"input_ids", "attention_mask", "labels", "input_features", "audio_attention_mask", "audio_token_counts"}
+    assert set(batch) == {"input_ids", "attention_mask", "labels", "prompts", "prompt_attention_mask", "input_features",
+                          "audio_attention_mask", "audio_token_counts"}          # trl's collation also emits the two prompt tensors
     assert batch["audio_token_counts"].tolist() == [12, 25]                       # 100 / 200 mel frames -> 50 / 100 -> 12 / 25
     ids, lab, att = batch["input_ids"], batch["labels"], batch["attention_mask"]
     for i, n_audio in enumerate([12, 25]):

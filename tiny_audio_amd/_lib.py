@@ -40,7 +40,7 @@ class EncoderWeights(C.Structure):
                 ("n_mels", C.c_int), ("max_pos", C.c_int), ("ln_eps", C.c_float),
                 ("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
                 ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("layers", C.POINTER(EncLayer)), ("rope_il", C.c_void_p)]
+                ("layers", C.POINTER(EncLayer)), ("rope_il", C.c_void_p), ("res_f32", C.c_int)]
 
 
 class MlpWeights(C.Structure):
@@ -82,7 +82,7 @@ class LmWeights(C.Structure):
                 ("embed_f32", C.c_void_p), ("embed_bf16", C.c_void_p), ("embed_t_bf16", C.c_void_p),
                 ("norm_w", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("layers", C.POINTER(LmLayer)), ("lora_rank", C.c_int), ("lora_scale", C.c_float), ("train_base", C.c_int),
-                ("lora_groups", C.c_int)]
+                ("lora_groups", C.c_int), ("res_f32", C.c_int), ("dx_f32", C.c_int)]
 
 
 class LmLayerWgrads(C.Structure):
@@ -189,7 +189,7 @@ class _DryLib:
 
     def __getattr__(self, name):
         fn = getattr(self._h, name)
-        if name.endswith("_bytes") or name in ("ta_version", "ta_set_stream_modes", "ta_get_stream_modes"):      # host-only calls
+        if name.endswith(("_bytes", "_floats")) or name == "ta_version":      # host-only calls (sizes, the ABI version)
             return fn
 
         def stub(*args):

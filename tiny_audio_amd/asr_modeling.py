@@ -161,6 +161,9 @@ class ASRModel(nn.Module):
             if tid is not None and int(tid) >= 0:
                 self.audio_token_id = config.audio_token_id = int(tid)
         self.system_prompt = getattr(config, "system_prompt", None)
+        # the reference builds its WhisperFeatureExtractor here (tiny_audio/asr_modeling.py:146, :190-201; padding disabled for
+        # GLM-ASR); this one computes the log-mel on the device.  ``feature_extractor=`` hands in another one.
+        self.feature_extractor = kwargs.get("feature_extractor") or self._create_feature_extractor(config)
 
     def _apply_stream_modes(self):
         """``config.model_dtype`` decides where the residual streams are STORED, as it does in the reference: "bfloat16" (the
@@ -169,15 +172,73 @@ class ASRModel(nn.Module):
         both (the reference's ``bf16: true``); the trainable masters are fp32 in both.  ``config.residual_dtype`` overrides."""
         rd = getattr(self.config, "residual_dtype", None) or getattr(self.config, "model_dtype", "bfloat16")
         f32 = str(rd).replace("torch.", "") in ("float32", "fp32", "float")
-        if self.__dict__.get("_stream_f32") != f32 or ops.get_stream_modes()["lm_res_f32"] != f32:
-            ops.set_stream_modes(f32, f32, f32)
-            self.__dict__["_stream_f32"] = f32
+        # per-model state since round 6 (fields of the two weights handles, include/ta355.h ABI 4): another ASRModel of another
+        # model_dtype in the same process, or a decoding thread, is not affected
+        if self.audio_tower.res_f32 != f32:
+            self.audio_tower.res_f32 = f32
+        lm = self.language_model
+        if lm.res_f32 != f32 or lm.dx_f32 != f32:
+            lm.res_f32 = lm.dx_f32 = f32
 
     def _setup_lora(self, config, seed=0):
         """Stage-2 adapters on the LM (tiny_audio/asr_modeling.py:289-301: LoraConfig(r, lora_alpha,
         target_modules, lora_dropout, bias="none", task_type="CAUSAL_LM"))."""
         self.language_model.enable_lora(rank=config.lora_rank, alpha=config.lora_alpha, dropout=config.lora_dropout,
                                         target_modules=config.lora_target_modules, seed=seed + 2)
+
+    def _create_feature_extractor(self, config):
+        from .asr_processing import LogMelFeatureExtractor
+        return LogMelFeatureExtractor(int(getattr(config.audio_config, "num_mel_bins", 128)), self.device_)
+
+    def get_processor(self):
+        """tiny_audio/asr_modeling.py:384-396: the processor that pairs with this model (its feature extractor, its tokenizer, its
+        projector's length rule, its encoder's conv geometry)."""
+        from .asr_processing import ASRProcessor
+        if self.tokenizer is None:
+            raise ValueError("get_processor needs a tokenizer: construct ASRModel(..., tokenizer=tok) or set model.tokenizer")
+        return ASRProcessor(feature_extractor=self.feature_extractor, tokenizer=self.tokenizer, projector=self.projector,
+                            encoder_conv_layers=self.config.encoder_conv_layers)
+
+    # ---- the PreTrainedModel surface HF tooling touches (tiny_audio/asr_modeling.py:359-382, :535-546)
+    def get_input_embeddings(self):
+        """A frozen ``nn.Embedding`` VIEW of the LM's fp32 lookup table (no copy); the training forward does not go through it
+        (the lookup is fused with the <audio> scatter, ``ta_embed_scatter``)."""
+        w = self.language_model.ft_embed if self.language_model.train_base else self.language_model.get_input_embeddings_weight()
+        emb = nn.Embedding(w.shape[0], w.shape[1], _weight=w.detach(), _freeze=True)
+        return emb
+
+    def set_input_embeddings(self, value):
+        """Replace the (tied) token embedding: the lookup table and both lm_head images are rebuilt from ``value.weight``."""
+        self.language_model.set_embedding_weight(value.weight if hasattr(value, "weight") else value)
+
+    def get_output_embeddings(self):
+        """The tied lm_head as a bias-free ``nn.Linear`` VIEW of the same table (Qwen3 ties them: SURVEY section 8)."""
+        w = self.language_model.ft_embed if self.language_model.train_base else self.language_model.get_input_embeddings_weight()
+        head = nn.Linear(w.shape[1], w.shape[0], bias=False, device="meta")
+        head.weight = nn.Parameter(w.detach(), requires_grad=False)
+        return head
+
+    def set_output_embeddings(self, value):
+        self.set_input_embeddings(value)
+
+    def _set_gradient_checkpointing(self, enable: bool = True, gradient_checkpointing_func=None):
+        """The reference forwards this to the LM so that its activations are recomputed in the backward (:359-370).  Here the LM
+        keeps a 40 KB-per-token tape (7.4 GB at B = 32) out of 288 GB and nothing is recomputed: accepted and
+        recorded, so ``TrainingArguments(gradient_checkpointing=True)`` runs unchanged; results are identical either way."""
+        self.gradient_checkpointing = bool(enable)
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        self._set_gradient_checkpointing(True)
+
+    def gradient_checkpointing_disable(self):
+        self._set_gradient_checkpointing(False)
+
+    def prepare_inputs_for_generation(self, *args, **kwargs):
+        """HF's ``GenerationMixin`` protocol (:535-546: audio features only on the step with ``cache_position[0] == 0``).  This
+        model owns its KV cache and decode loop (``generate`` / ``generate_streaming``), so there is no per-step ``forward`` for
+        the protocol to feed -- raising beats silently returning inputs that ``forward`` would refuse."""
+        raise NotImplementedError("ASRModel on MI355X decodes with its own device-resident loop: call generate() / "
+                                  "generate_streaming(); HF's step-wise GenerationMixin protocol is not spoken")
 
     def _create_projector(self, config):
         projector_type = getattr(config, "projector_type", "mlp")
@@ -280,6 +341,12 @@ class ASRModel(nn.Module):
                 pos = pos[None, :]
             if pos.dim() != 2 or pos.shape[1] != L or pos.shape[0] not in (1, B):
                 raise ValueError(f"position_ids must be [B, L] (or [1, L] / [L]); got {tuple(pos.shape)} for input_ids {tuple(ids.shape)}")
+            # the RoPE kernels index the cos / sin tables with these: a position outside [0, max_position_embeddings) would read past
+            # them (the reference raises an index error there).  One host check on this opt-in path; the default arange needs none.
+            max_pos = int(self.config.text_config.max_position_embeddings)
+            lo, hi = (int(v) for v in torch.aminmax(pos)) if pos.numel() else (0, 0)
+            if lo < 0 or hi >= max_pos:
+                raise ValueError(f"position_ids must lie in [0, {max_pos}) (max_position_embeddings); got [{lo}, {hi}]")
             pos = pos.expand(B, L).contiguous().reshape(-1)
         audio, src_row = None, None
         if input_features is None and after_encoder is not None:
@@ -394,18 +461,9 @@ class ASRModel(nn.Module):
         if input_ids is None:
             if self.tokenizer is None:
                 raise ValueError("input_ids required: no tokenizer is attached to build the chat prompt")
-            n_audio = self._get_num_audio_tokens(amask)
-            messages = []
-            sp = system_prompt or self.system_prompt
-            if sp:
-                messages.append({"role": "system", "content": sp})
-            content = "<audio>" * n_audio + (" " + self.TRANSCRIBE_PROMPT if self.TRANSCRIBE_PROMPT else "")
-            messages.append({"role": "user", "content": content})
-            chat = self.tokenizer.apply_chat_template(messages, tokenize=True, add_generation_prompt=True,
-                                                      return_tensors="pt", enable_thinking=False)
-            input_ids = chat.input_ids if hasattr(chat, "input_ids") else chat
-            if input_ids.dim() == 1:
-                input_ids = input_ids.unsqueeze(0)
+            from .asr_processing import ASRProcessor
+            messages = ASRProcessor.build_messages(self._get_num_audio_tokens(amask), None, system_prompt or self.system_prompt)
+            input_ids = ASRProcessor.tokenize_messages(self.tokenizer, messages, add_generation_prompt=True)
             if input_ids.shape[0] == 1 and B > 1:
                 input_ids = input_ids.expand(B, -1)
             attention_mask = torch.ones_like(input_ids)

@@ -6,8 +6,9 @@ raw 16 kHz waveforms are uploaded once and the log-mel + frame mask are computed
 (``ta_logmel_f32``) instead of in CPU dataloader workers -- the stage the reference itself flags as its
 bottleneck (configs/experiments/embedded.yaml:37-41).
 
-``ASRProcessor`` mirrors tiny_audio/asr_processing.py:51-128 for the token-count contract
-(mel mask -> conv formula -> projector.get_output_length -> number of ``<audio>`` placeholders).
+``ASRProcessor`` is the drop-in for tiny_audio/asr_processing.py:17-128: audio (+ optional transcript / system prompt) ->
+``input_features, audio_attention_mask, input_ids, attention_mask`` through the token-count contract
+(mel mask -> conv formula -> projector.get_output_length -> number of ``<audio>`` placeholders) and the tokenizer's chat template.
 """
 from __future__ import annotations
 
@@ -110,25 +111,74 @@ class LogMelFeatureExtractor:
 
 
 class ASRProcessor:
-    """Token-count / prompt contract of tiny_audio/asr_processing.py:51-128 (tokenizer-free part)."""
+    """Drop-in for ``tiny_audio.asr_processing.ASRProcessor`` (tiny_audio/asr_processing.py:17-128; built by
+    ``ASRModel.get_processor()``, tiny_audio/asr_modeling.py:384-396): same constructor arguments, same ``__call__`` arguments,
+    same returned keys -- ``input_features`` / ``audio_attention_mask`` (only with audio), ``input_ids``, ``attention_mask``.
 
+    The feature extractor is whatever the caller hands in; ``LogMelFeatureExtractor`` computes the log-mel on the GPU.  The
+    ``<audio>`` placeholder count follows the LONGEST clip's real mel length (attention-mask sum -> conv formulas ->
+    ``projector.get_output_length``, :84-87), the chat prompt is rendered by the tokenizer's own template with Qwen3's thinking
+    mode off, and a generation prompt is appended exactly when no target text is given (:104-112)."""
+
+    attributes = ["feature_extractor", "tokenizer"]
+    feature_extractor_class = "AutoFeatureExtractor"
+    tokenizer_class = "AutoTokenizer"
     AUDIO_TOKEN = "<audio>"
     TRANSCRIBE_PROMPT = "Transcribe the speech to text"
 
-    def __init__(self, feature_extractor, projector, encoder_conv_layers=None):
+    def __init__(self, feature_extractor, tokenizer, projector=None, encoder_conv_layers=None):
         self.feature_extractor = feature_extractor
+        self.tokenizer = tokenizer
+        self.audio_token_id = tokenizer.convert_tokens_to_ids(self.AUDIO_TOKEN)
         self.projector = projector
         self.encoder_conv_layers = encoder_conv_layers or DEFAULT_ENCODER_CONV_LAYERS
 
+    # ---- length bookkeeping
+    def _compute_encoder_output_length(self, mel_length):
+        return compute_encoder_output_length(mel_length, self.encoder_conv_layers)
+
     def audio_token_counts(self, frame_mask: torch.Tensor) -> torch.Tensor:
-        mel_lengths = frame_mask.sum(dim=-1)                                                   # scripts/train.py:335
-        enc_lengths = compute_encoder_output_length(mel_lengths, self.encoder_conv_layers)
+        """Per-clip ``<audio>`` counts from the mel frame mask (what scripts/train.py:335-342 computes in the collator)."""
+        enc_lengths = self._compute_encoder_output_length(frame_mask.sum(dim=-1))
         return self.projector.get_output_length(enc_lengths).to(torch.long)
 
-    def __call__(self, audio, sampling_rate=16000):
-        f = self.feature_extractor(audio, sampling_rate=sampling_rate, padding="longest", return_attention_mask=True)
-        real_mel_len = int(f["attention_mask"].sum(dim=-1).max().item())                      # asr_processing.py:85
-        n_tok = int(self.projector.get_output_length(compute_encoder_output_length(real_mel_len, self.encoder_conv_layers)))
-        prompt = self.AUDIO_TOKEN * n_tok + " " + self.TRANSCRIBE_PROMPT                       # :92-95
-        return {"input_features": f["input_features"], "audio_attention_mask": f["attention_mask"],
-                "num_audio_tokens": n_tok, "user_content": prompt}
+    # ---- prompt
+    @classmethod
+    def build_messages(cls, num_audio_tokens: int, text=None, system_prompt=None):
+        """The chat turns of one request (:89-102): optional system turn, the user turn carrying the placeholders (+ the
+        instruction), and the transcript as the assistant turn when training text is given."""
+        user = cls.AUDIO_TOKEN * int(num_audio_tokens) if num_audio_tokens > 0 else ""
+        if cls.TRANSCRIBE_PROMPT:
+            user = user + " " + cls.TRANSCRIBE_PROMPT if user else cls.TRANSCRIBE_PROMPT
+        turns = [{"role": "system", "content": system_prompt}] if system_prompt else []
+        turns.append({"role": "user", "content": user})
+        if text is not None:
+            turns.append({"role": "assistant", "content": text})
+        return turns
+
+    @staticmethod
+    def tokenize_messages(tokenizer, messages, add_generation_prompt: bool, return_tensors="pt") -> torch.Tensor:
+        """-> ``input_ids`` [1, L] through the tokenizer's chat template (thinking mode off, :104-123); tokenizers differ in what
+        ``apply_chat_template`` returns (a tensor, or a BatchEncoding / dict holding one)."""
+        out = tokenizer.apply_chat_template(messages, tokenize=True, add_generation_prompt=add_generation_prompt,
+                                            return_tensors=return_tensors, enable_thinking=False)
+        if not isinstance(out, torch.Tensor):
+            out = out["input_ids"] if isinstance(out, dict) else out.get("input_ids", getattr(out, "input_ids", None))
+        ids = torch.as_tensor(out)
+        return ids[None, :] if ids.dim() == 1 else ids
+
+    def __call__(self, audio=None, text=None, system_prompt=None, return_tensors: str = "pt", **kwargs) -> dict:
+        result = {}
+        n_tok = 0
+        if audio is not None:
+            f = self.feature_extractor(audio, sampling_rate=getattr(self.feature_extractor, "sampling_rate", 16000),
+                                       return_attention_mask=True, return_tensors=return_tensors, **kwargs)
+            result["input_features"] = f["input_features"]
+            result["audio_attention_mask"] = f["attention_mask"]
+            real_mel_len = int(f["attention_mask"].sum(dim=-1).max().item())               # :85 (one host sync, as the reference)
+            n_tok = self.projector.get_output_length(self._compute_encoder_output_length(real_mel_len))
+        messages = self.build_messages(n_tok, text, system_prompt)
+        ids = self.tokenize_messages(self.tokenizer, messages, add_generation_prompt=text is None, return_tensors=return_tensors)
+        result["input_ids"] = ids
+        result["attention_mask"] = torch.ones_like(ids)
+        return result

@@ -6,8 +6,9 @@ audio_attention_mask, audio_token_counts``.  Differences by design: the log-mel 
 the device (the reference computes them in CPU dataloader workers and names that its bottleneck,
 configs/experiments/embedded.yaml:37-41), and the chat-ML text collation -- which the reference delegates to
 ``trl.DataCollatorForChatML`` (not installed here) -- is restated in ``ChatMLTextCollator`` against any tokenizer that
-offers ``apply_chat_template``: prompt = all messages but the last rendered with the generation prompt, completion =
-the rest of the full rendering; prompt tokens are masked.
+offers ``apply_chat_template``: prompt = all messages but the last rendered with the generation prompt, the message = all of
+them; the first len(prompt tokens) labels are masked; everything is left-padded; trl's ``prompts`` / ``prompt_attention_mask``
+keys are emitted too.
 """
 from __future__ import annotations
 
@@ -40,41 +41,62 @@ def normalize_label(raw_text: Optional[str]) -> str:
 
 
 class ChatMLTextCollator:
-    """messages -> input_ids / attention_mask / labels with the prompt masked (trl DataCollatorForChatML semantics)."""
+    """messages -> ``input_ids, attention_mask, labels, prompts, prompt_attention_mask``: the batch of trl 0.29.1's
+    ``DataCollatorForChatML`` (pinned in the reference's poetry.lock:7213-7214, called at scripts/train.py:265,344), restated
+    step by step since trl is not installable here:
 
-    def __init__(self, tokenizer, max_length: int = 2048, padding_side: str = "left", ignore_index: int = -100):
+    1. prompt text  = chat template over all messages but the last, WITH the generation prompt, rendered to a string;
+       message text = chat template over all messages, without it;
+    2. both strings are tokenised separately with ``add_special_tokens=False`` (message truncated to ``max_length``, prompt to the
+       message's token count);
+    3. labels = ``ignore_index`` for the first ``len(prompt tokens)`` positions, the message's own ids after it -- the split is
+       the prompt's TOKEN COUNT, not a search for a common prefix;
+    4. all five tensors are LEFT-padded (ids with ``pad_token_id``, masks with 0, labels with ``ignore_index``), whatever the
+       tokenizer's ``padding_side`` says.
+
+    The extra keys ``prompts`` / ``prompt_attention_mask`` reach ``ASRModel.forward`` through ``**kwargs`` and are ignored there,
+    as in the reference.  A tokenizer object that cannot be called on a string (the whitespace stub of the host tests) is driven
+    through ``apply_chat_template(tokenize=True)`` instead; same steps 3-4.  Pinned on ``tests/golden/chatml_collation.json``
+    (transformers' own ``apply_chat_template`` + fast-tokenizer outputs for a ChatML template)."""
+
+    def __init__(self, tokenizer, max_length: Optional[int] = 2048, padding_side: str = "left", ignore_index: int = -100):
         self.tok, self.max_length, self.padding_side, self.ignore_index = tokenizer, max_length, padding_side, ignore_index
         if getattr(tokenizer, "pad_token_id", None) is None:
             raise ValueError("tokenizer needs a pad token")
 
-    def _render(self, messages, add_generation_prompt):
-        ids = self.tok.apply_chat_template(messages, tokenize=True, add_generation_prompt=add_generation_prompt)
-        ids = ids["input_ids"] if isinstance(ids, dict) else ids
-        return list(ids)
+    def _encode(self, messages, add_generation_prompt, max_length):
+        """-> (ids, attention mask) of one rendering."""
+        tok = self.tok
+        if callable(tok):
+            text = tok.apply_chat_template(messages, tokenize=False, add_generation_prompt=add_generation_prompt)
+            enc = tok(text, truncation=True, max_length=max_length, padding=False, return_tensors=None, add_special_tokens=False)
+            ids = list(enc["input_ids"])
+            return ids, list(enc["attention_mask"]) if "attention_mask" in enc else [1] * len(ids)
+        ids = tok.apply_chat_template(messages, tokenize=True, add_generation_prompt=add_generation_prompt)
+        ids = list(ids["input_ids"] if isinstance(ids, dict) else ids)
+        if max_length is not None:
+            ids = ids[:max_length]
+        return ids, [1] * len(ids)
+
+    def _pad(self, rows, value):
+        L = max(len(r) for r in rows)
+        out = torch.full((len(rows), L), value, dtype=torch.int64)
+        for i, r in enumerate(rows):
+            if r:
+                out[i, (L - len(r) if self.padding_side == "left" else 0):(L if self.padding_side == "left" else len(r))] = torch.tensor(r)
+        return out
 
     def __call__(self, examples):
-        rows = []
+        ids, att, p_ids, p_att, lab = [], [], [], [], []
         for ex in examples:
             msgs = ex["messages"]
-            prompt = self._render(msgs[:-1], True)
-            full = self._render(msgs, False)
-            if full[: len(prompt)] != prompt:                      # template re-renders the prefix differently: find the split
-                n = 0
-                while n < min(len(prompt), len(full)) and prompt[n] == full[n]:
-                    n += 1
-                prompt = full[:n]
-            full = full[: self.max_length]
-            labels = [self.ignore_index] * min(len(prompt), len(full)) + full[len(prompt):]
-            rows.append((full, labels))
-        L = max(len(r[0]) for r in rows)
+            full, full_mask = self._encode(msgs, False, self.max_length)
+            prompt, prompt_mask = self._encode(msgs[:-1], True, len(full))
+            ids.append(full); att.append(full_mask); p_ids.append(prompt); p_att.append(prompt_mask)
+            lab.append([self.ignore_index] * min(len(prompt), len(full)) + full[len(prompt):])
         pad = int(self.tok.pad_token_id)
-        ids = torch.full((len(rows), L), pad, dtype=torch.int64)
-        att = torch.zeros((len(rows), L), dtype=torch.int64)
-        lab = torch.full((len(rows), L), self.ignore_index, dtype=torch.int64)
-        for i, (full, labels) in enumerate(rows):
-            sl = slice(L - len(full), L) if self.padding_side == "left" else slice(0, len(full))
-            ids[i, sl] = torch.tensor(full); att[i, sl] = 1; lab[i, sl] = torch.tensor(labels)
-        return {"input_ids": ids, "attention_mask": att, "labels": lab}
+        return {"input_ids": self._pad(ids, pad), "attention_mask": self._pad(att, 0), "labels": self._pad(lab, self.ignore_index),
+                "prompts": self._pad(p_ids, pad), "prompt_attention_mask": self._pad(p_att, 0)}
 
 
 class DataCollator:

@@ -6,37 +6,17 @@
 #include "internal.h"
 #include "../../include/ta355.h"
 
-extern "C" int ta_version(void) { return 3; }
+extern "C" int ta_version(void) { return 4; }
 
 #include <algorithm>
-#include <atomic>
 #include "host_util.h"
 
 // ============================================================================ residual-stream dtypes (the numerics contract)
-// Process-wide: which dtype the encoder's residual stream, the LM's forward residual stream (+ tape) and the LM's backward d(x)
-// stream are STORED in.  bf16 (default) is what a bf16-module reference keeps (ASRConfig model_dtype="bfloat16"); fp32 is what the
-// training recipe keeps (fp32 modules under bf16 autocast: configs/config.yaml:14-18 + configs/training/production.yaml:49).
-// MFMA operands (bf16) and accumulators (fp32) are the same in both.  Initially bf16 / bf16 / bf16; ta_set_stream_modes changes them
-// between calls (not while a composite is being enqueued).
-namespace {
-struct StreamModes {
-  std::atomic<int> enc_f32{0}, lm_f32{0}, dx_f32{0};
-};
-StreamModes& stream_modes() { static StreamModes m; return m; }
-}  // namespace
-extern "C" int ta_set_stream_modes(int enc_res_f32, int lm_res_f32, int lm_dx_f32) {
-  StreamModes& m = stream_modes();
-  if (enc_res_f32 >= 0) m.enc_f32 = enc_res_f32 ? 1 : 0;
-  if (lm_res_f32 >= 0) m.lm_f32 = lm_res_f32 ? 1 : 0;
-  if (lm_dx_f32 >= 0) m.dx_f32 = lm_dx_f32 ? 1 : 0;
-  return TA_OK;
-}
-extern "C" int ta_get_stream_modes(int* out3) {
-  if (!out3) return TA_ERR_ARG;
-  StreamModes& m = stream_modes();
-  out3[0] = m.enc_f32; out3[1] = m.lm_f32; out3[2] = m.dx_f32;
-  return TA_OK;
-}
+// Which dtype the encoder's residual stream, the LM's forward residual stream (+ tape) and the LM's backward d(x) stream are STORED
+// in travels with the weights handle of each call (ta_encoder_weights.res_f32, ta_lm_weights.res_f32 / dx_f32; ABI 4) -- rounds 1-5
+// kept it in process-wide state, which two models of different model_dtype in one process raced on.  bf16 (0) is what a bf16-module
+// reference keeps (ASRConfig model_dtype="bfloat16"); fp32 (1) is what the training recipe keeps (fp32 modules under bf16 autocast:
+// configs/config.yaml:14-18 + configs/training/production.yaml:49).  MFMA operands (bf16) and accumulators (fp32) are the same in both.
 
 // ============================================================================ encoder
 namespace {
@@ -86,8 +66,8 @@ extern "C" int ta_encoder_forward(const ta_encoder_weights* w, const float* feat
                      w->conv1_b, nullptr, 1, 1, 1, nullptr, st));
   // Residual stream: bf16, the dtype the reference's encoder runs in (model_dtype bfloat16: every residual add and
   // LayerNorm input is bf16 there).  It halves the bytes of the two residual GEMM epilogues and of the LayerNorm reads
-  // per layer -- HBM time that nothing overlaps.  ta_set_stream_modes(1, ., .) keeps an fp32 stream instead.
-  const bool res_f32 = stream_modes().enc_f32 != 0;
+  // per layer -- HBM time that nothing overlaps.  ta_encoder_weights.res_f32 = 1 keeps an fp32 stream instead.
+  const bool res_f32 = w->res_f32 != 0;
   const int rb = res_f32 ? 0 : 1;
   auto ln = [&](const float* gw, const float* gb, void* yb, float* yf, const float* rowscale) -> int {
     return rb ? ta_layernorm_bf16(e.xr, gw, gb, yb, yf, rowscale, M, H, w->ln_eps, st)
@@ -222,8 +202,8 @@ extern "C" int ta_mlp_projector_backward(const ta_mlp_weights* w, const void* x,
 namespace {
 // Residual stream of the LM (x_in / x1 of every layer, kept in the tape): bf16, the dtype the reference's LM runs in
 // (model_dtype bfloat16).  Halves the bytes of the o / down GEMM epilogues, of the RMSNorm reads (forward and
-// backward) and of the tape.  TA355_LM_RES_F32=1 keeps fp32 instead.  The gradient stream d(x) stays fp32.
-inline bool lm_res_bf16() { return stream_modes().lm_f32 == 0; }
+// backward) and of the tape.  ta_lm_weights.res_f32 = 1 keeps fp32 instead; the gradient stream d(x) follows it unless dx_f32 = 1.
+inline bool lm_res_bf16(const ta_lm_weights* w) { return w->res_f32 == 0; }
 struct LmLayerTape {
   float *x_in, *r_in, *rq, *rk, *lse, *x1, *r_post;
   bf16_t *qkv0, *q, *k, *v, *qt, *kt, *vt, *ao, *gu;
@@ -441,7 +421,7 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     float* x_next = (l + 1 < w->n_layers) ? store[alias ? 0 : l + 1].x_in : x_final;
     const bool keep = lora || (w->train_base && !alias);
     bf16_t* xn = keep ? p.xn_s : s.xn;
-    const bool rb = lm_res_bf16();
+    const bool rb = lm_res_bf16(w);
     auto norm = [&](const float* x, const float* gw, bf16_t* y, float* r) -> int {
       return rb ? ta_rmsnorm_fwd_bf16(x, gw, y, nullptr, r, M, d.D, w->eps, st) : ta_rmsnorm_fwd(x, gw, y, nullptr, r, M, d.D, w->eps, 0, st);
     };
@@ -498,10 +478,10 @@ extern "C" int ta_lm_forward_loss(const ta_lm_weights* w, const long* ids, const
   if ((long)s.bytes > ws_bytes) return TA_ERR_ARG;
   float* x = store[0].x_in;
   // inputs_embeds = embed_tokens(ids) with the <audio> rows replaced by projector rows (asr_modeling.py:498,511-515)
-  if (lm_res_bf16()) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, x, M, d.D, w->vocab, st));
+  if (lm_res_bf16(w)) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, x, M, d.D, w->vocab, st));
   else RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, x, nullptr, M, d.D, w->vocab, st));
   RC(lm_layers_forward(w, d, B, L, kmask, pos, store, false, t.x_final, s, nullptr, nullptr, nullptr, 0, st));
-  if (lm_res_bf16()) RC(ta_rmsnorm_fwd_bf16(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, st));
+  if (lm_res_bf16(w)) RC(ta_rmsnorm_fwd_bf16(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, st));
   else RC(ta_rmsnorm_fwd(t.x_final, w->norm_w, t.hn, nullptr, t.r_f, M, d.D, w->eps, 0, st));
   if (logits_out)   // the reference's outputs.logits (bf16 under autocast), all positions
     RC(gemm(t.hn, w->embed_bf16, logits_out, M, w->vocab_pad, d.D, nullptr, nullptr, 0, 1, st));
@@ -553,11 +533,11 @@ extern "C" int ta_lm_prefill(const ta_lm_weights* w, const long* ids, const int*
   if ((long)p.bytes > ws_bytes) return TA_ERR_ARG;
   ta_i_lora_layer_imgs imgs[MAX_LM_LAYERS];
   if (w->lora_rank > 0) lora_imgs_carve(w, lora_img, imgs);
-  if (lm_res_bf16()) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, p.layer[0].x_in, M, d.D, w->vocab, st));
+  if (lm_res_bf16(w)) RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, nullptr, p.layer[0].x_in, M, d.D, w->vocab, st));
   else RC(ta_embed_scatter(ids, src_row, w->embed_f32, audio, p.layer[0].x_in, nullptr, M, d.D, w->vocab, st));
   RC(lm_layers_forward(w, d, B, L, kmask, pos, p.layer, true, p.t.x_final, p.s, w->lora_rank > 0 ? imgs : nullptr,
                        (bf16_t*)kcache, (bf16_t*)vcache, Lmax, st));
-  if (lm_res_bf16()) RC(ta_rmsnorm_fwd_bf16(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, st));
+  if (lm_res_bf16(w)) RC(ta_rmsnorm_fwd_bf16(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, st));
   else RC(ta_rmsnorm_fwd(p.t.x_final, w->norm_w, p.t.hn, nullptr, p.t.r_f, M, d.D, w->eps, 0, st));
   RC(ta_gather_rows_bf16(p.t.hn, last_rows, p.s.hl, B, d.D, st));
   RC(gemm(p.s.hl, w->embed_bf16, logits, B, w->vocab_pad, d.D, nullptr, nullptr, 0, 0, st));
@@ -667,22 +647,22 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
       RC(ta_gemm_bf16_nt(s.tA, s.tB, wg->dembed, w->vocab, d.D, Kl, Kl, 0, 0, d.D, 0, 0, 0, nullptr, wg->dembed, 0, 0, 1,
                          nullptr, st));
     }
-    if (wg->dnorm) RC(ta_rmsnorm_dw(s.dhn, 0, t.x_final, lm_res_bf16(), t.r_f, wg->dnorm, M, d.D, st));
+    if (wg->dnorm) RC(ta_rmsnorm_dw(s.dhn, 0, t.x_final, lm_res_bf16(w), t.r_f, wg->dnorm, M, d.D, st));
   }
   float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
   float* dx_alt = s.dxb32;
   // dyb: the incoming gradient is bf16 (the two dX GEMMs that feed an RMSNorm backward write bf16 in that mode: it is
   // read exactly once, so fp32 there only doubles epilogue and read bytes; the accumulating d(x) stream stays fp32)
-  const int gb = lm_res_bf16() ? 1 : 0;
-  // round 4: with the bf16 forward stream the d(x) stream is bf16 as well (TA355_LM_DX_F32=1: fp32 as in rounds 1-3) -- the
+  const int gb = lm_res_bf16(w) ? 1 : 0;
+  // round 4: with the bf16 forward stream the d(x) stream is bf16 as well (ta_lm_weights.dx_f32 = 1: fp32 as in rounds 1-3) -- the
   // reference's bf16 model back-propagates bf16 gradients of its bf16 activations; s.dxb then IS the stream (updated in place by
   // every RMSNorm backward) and the two f32 images are written only by the last call, for the f32 consumers below the stack:
   // 50 MB instead of 88 MB per RMSNorm backward
-  const bool dx_bf16 = lm_res_bf16() && stream_modes().dx_f32 == 0;
+  const bool dx_bf16 = lm_res_bf16(w) && w->dx_f32 == 0;
   auto norm_bwd = [&](const float* dy, int dyb, const float* x, const float* r, const float* gw, const float* dres, float* dxf,
                       bool last = false) -> int {
     if (dx_bf16) return ta_rmsnorm_bwd_bf16s(dy, dyb, x, r, gw, dres ? s.dxb : nullptr, last ? dxf : nullptr, s.dxb, M, d.D, st);
-    return lm_res_bf16() ? ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
+    return lm_res_bf16(w) ? ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
                          : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
   };
   RC(norm_bwd(s.dhn, 0, t.x_final, t.r_f, w->norm_w, nullptr, dx, w->n_layers == 0));
@@ -700,7 +680,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (lgm & 4) RC(lora_bwd(s.dgu, 2 * d.F, p.xn2_s, d.D, p.xa_gu, p.i_gu, lora_grads[l].dla_gu, lora_grads[l].dlb_gu, 2, d.F, 1 << 30, l, 2));
     if (g) RC(wgrad(s.dgu, 2 * d.F, p.xn2_s, d.D, g->dwgu));
     RC(gemm_opt(s.dgu, Lw.wgu_t, s.dxn, M, d.D, 2 * d.F, nullptr, nullptr, 0, gb, take_ext(), st));
-    if (g && g->dln_post) RC(ta_rmsnorm_dw(s.dxn, gb, p.x1, lm_res_bf16(), p.r_post, g->dln_post, M, d.D, st));
+    if (g && g->dln_post) RC(ta_rmsnorm_dw(s.dxn, gb, p.x1, lm_res_bf16(w), p.r_post, g->dln_post, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x1, p.r_post, Lw.ln_post_w, dx, dx_alt));
     // ---- attention: x1 = x + o_proj(attn)
     if (lgm & 2) RC(lora_bwd(s.dxb, d.D, p.ao, bq, p.xa_o, p.i_o, lora_grads[l].dla_o, lora_grads[l].dlb_o, 1, 1 << 30, 1 << 30, l, 1));
@@ -724,7 +704,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     if (g) RC(wgrad(s.dqkv, d.NQKV, p.xn_s, d.D, g->dwqkv));
     if (lgm & 1) RC(lora_bwd(s.dqkv, d.NQKV, p.xn_s, d.D, p.xa_qkv, p.i_qkv, lora_grads[l].dla_qkv, lora_grads[l].dlb_qkv, 3, bq, bk, l, 0));
     RC(gemm_opt(s.dqkv, Lw.wqkv_t, s.dxn, M, d.D, d.NQKV, nullptr, nullptr, 0, gb, take_ext(), st));
-    if (g && g->dln_in) RC(ta_rmsnorm_dw(s.dxn, gb, p.x_in, lm_res_bf16(), p.r_in, g->dln_in, M, d.D, st));
+    if (g && g->dln_in) RC(ta_rmsnorm_dw(s.dxn, gb, p.x_in, lm_res_bf16(w), p.r_in, g->dln_in, M, d.D, st));
     RC(norm_bwd(s.dxn, gb, p.x_in, p.r_in, Lw.ln_in_w, dx_alt, dx, l == 0));
   }
   if (d_embeds && hipMemcpyAsync(d_embeds, dx, (size_t)M * d.D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -617,11 +617,23 @@ __global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restri
   }
   const float total = part[1023];
   const float u = philox_uniform(seed, (unsigned)*step_p, blockIdx.x) * total;
-  // thread t's lower bound IS thread t - 1's upper bound (the same float, read back from the scan): `part[tid] - s` is a different
-  // rounding of it, and then two chunks could both claim u (a race on `pick`) or neither (a biased fall-back) -- ADVICE r4
-  const float before = tid ? part[tid - 1] : 0.f;
-  if (s > 0.f && before <= u && (u < part[tid] || tid == 1023)) {
-    float c = before; int choice = last;
+  // The claim must be UNIQUE: part[] comes from a Hillis-Steele scan whose prefixes are summed in different association orders per
+  // index, so it is not guaranteed non-decreasing and the intervals [part[t-1], part[t]) can overlap by a rounding when a chunk's
+  // mass is tiny -- two owners would then race on `pick`.  The owner is the SMALLEST chunk index t with mass whose
+  // inclusive prefix exceeds u (a block-wide minimum), and only that thread walks its chunk.
+  __shared__ int owner;
+  if (tid == 0) owner = 1024;
+  __syncthreads();
+  {
+    int mine = (s > 0.f && u < part[tid]) ? tid : 1024;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
+    if ((tid & 63) == 0 && mine < 1024) atomicMin(&owner, mine);
+  }
+  __syncthreads();
+  if (tid == owner) {
+    // the walk starts from the previous chunk's inclusive prefix as read from the scan (the same float its owner compared with u)
+    float c = tid ? part[tid - 1] : 0.f; int choice = last;
     for (int j = j0; j < j1; ++j) { const float p = __expf(row[j] - mx); c += p; if (p > 0.f && u < c) { choice = j; break; } }
     pick = choice;
   }

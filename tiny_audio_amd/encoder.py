@@ -41,6 +41,19 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
         self._ws = None
         self._ws_key = None
         self.out_dtype = BF16
+        self._res_f32 = False    # storage of the residual stream (ta_encoder_weights.res_f32): bf16 unless the owner asks for fp32
+
+    @property
+    def res_f32(self) -> bool:
+        """True = the residual stream is stored in fp32 (the training recipe's fp32 modules under bf16 autocast), False = bf16
+        (bf16 modules).  A field of THIS encoder's weights handle (include/ta355.h, ABI 4): no process-wide state."""
+        return self._res_f32
+
+    @res_f32.setter
+    def res_f32(self, v):
+        self._res_f32 = bool(v)
+        if self._w is not None:
+            self._w.res_f32 = int(self._res_f32)
 
     # ------------------------------------------------------------------ weights
     def _rope_tables(self):
@@ -147,7 +160,8 @@ class GlmAsrEncoderMI355X(torch.nn.Module):
             for f, _ in _lib.EncLayer._fields_:
                 setattr(arr[i], f, b[p + f].data_ptr() if (p + f) in b else None)
         w = _lib.EncoderWeights(hidden=c.hidden_size, ffn=c.intermediate_size, n_layers=L, heads=c.num_attention_heads,
-                                n_mels=c.num_mel_bins, max_pos=c.max_position_embeddings, ln_eps=c.layer_norm_eps)
+                                n_mels=c.num_mel_bins, max_pos=c.max_position_embeddings, ln_eps=c.layer_norm_eps,
+                                res_f32=int(self._res_f32))
         for f in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "norm_w", "norm_b", "rope_cos", "rope_sin"):
             setattr(w, f, b[f].data_ptr())
         w.rope_il = b["rope_il"].data_ptr() if "rope_il" in b else None

@@ -47,8 +47,32 @@ class Qwen3MI355X(torch.nn.Module):
         self._ft_bound = None
         self._ft_versions = None
         self.accumulate_into_grad = False   # trainer opt-in: weight gradients are added straight into Parameter.grad
+        self._res_f32 = self._dx_f32 = False   # storage of the residual / d(x) streams (ta_lm_weights.res_f32 / dx_f32): bf16
+        self._tape_modes = {}
 
     # ------------------------------------------------------------------ LoRA (stage 2; asr_modeling.py:289-301)
+    # storage of the forward residual stream (+ its tape rows) and of the backward d(x) stream: fields of THIS model's weights handle
+    # (include/ta355.h, ABI 4) -- rounds 1-5 kept them in process-wide library state
+    @property
+    def res_f32(self) -> bool:
+        return self._res_f32
+
+    @res_f32.setter
+    def res_f32(self, v):
+        self._res_f32 = bool(v)
+        if self._w is not None:
+            self._w.res_f32 = int(self._res_f32)
+
+    @property
+    def dx_f32(self) -> bool:
+        return self._dx_f32
+
+    @dx_f32.setter
+    def dx_f32(self, v):
+        self._dx_f32 = bool(v)
+        if self._w is not None:
+            self._w.dx_f32 = int(self._dx_f32)
+
     def _lora_dims(self):
         """group -> [(peft target, out_features)], in_features"""
         c = self.config
@@ -400,7 +424,8 @@ class Qwen3MI355X(torch.nn.Module):
                     setattr(arr[i], f, b[f"layers.{i}.{f}"].data_ptr())
         w = _lib.LmWeights(vocab=c.vocab_size, vocab_pad=self.vocab_pad, hidden=c.hidden_size, ffn=c.intermediate_size,
                            n_layers=L, heads=c.num_attention_heads, kv_heads=c.num_key_value_heads, head_dim=c.head_dim,
-                           max_pos=c.max_position_embeddings, eps=c.rms_norm_eps)
+                           max_pos=c.max_position_embeddings, eps=c.rms_norm_eps, res_f32=int(self._res_f32),
+                           dx_f32=int(self._dx_f32))
         for f in ("embed_f32", "embed_bf16", "embed_t_bf16", "norm_w", "rope_cos", "rope_sin"):
             setattr(w, f, b[f].data_ptr())
         w.layers = C.cast(arr, C.POINTER(_lib.LmLayer))
@@ -435,6 +460,21 @@ class Qwen3MI355X(torch.nn.Module):
     def get_input_embeddings_weight(self):
         return self._bufs["embed_f32"]
 
+    @torch.no_grad()
+    def set_embedding_weight(self, weight):
+        """Replace the tied token embedding (``set_input_embeddings`` / ``set_output_embeddings`` of the reference,
+        tiny_audio/asr_modeling.py:372-382): the fp32 lookup table and both bf16 lm_head images are rebuilt and the weights
+        handle re-pointed.  With a trainable base LM the fp32 master takes the values and the images follow at the next forward."""
+        w = torch.as_tensor(weight).detach()
+        if self.train_base:
+            self.ft_embed.copy_(w[: self.config.vocab_size].to(self.ft_embed))
+            self._ft_versions = None
+            return
+        self._set_embedding(w)
+        if self._w is not None:
+            for f in ("embed_f32", "embed_bf16", "embed_t_bf16"):
+                setattr(self._w, f, self._bufs[f].data_ptr())
+
     # ------------------------------------------------------------------ raw forward / backward (no autograd)
     def forward_loss(self, input_ids, src_row, audio, kmask, label_rows, label_targets, n_label_rows, loss_scale,
                      want_logits=False, pos=None):
@@ -459,15 +499,12 @@ class Qwen3MI355X(torch.nn.Module):
                    "ta_lm_forward_loss")
         ctx = dict(tape=tape, ws=ws, B=B, L=L, src_row=src_row, kmask=kmask, pos=pos, label_rows=label_rows,
                    n_label_rows=n_label_rows, ids=input_ids)
-        # The tape's residual-stream rows are in the storage dtype that was set NOW (ta_set_stream_modes is process-wide state): the
-        # backward must read them as that, whatever another model's forward has set in between.  Keyed by the tape's address, since
-        # the custom operator hands the backward only tensors.
-        if not _lib.DRY_RUN:
-            from . import ops as _ops
-            self._tape_modes = {k: v for k, v in getattr(self, "_tape_modes", {}).items() if k != tape.data_ptr()}
-            if len(self._tape_modes) > 64:
-                self._tape_modes.clear()
-            self._tape_modes[tape.data_ptr()] = _ops.get_stream_modes()
+        # The tape's residual-stream rows are in the storage dtype this handle carried NOW: the backward must read them as that even
+        # if the owner flips ``res_f32`` in between.  Keyed by the tape's address, since the custom operator hands the backward only
+        # tensors.
+        if len(self._tape_modes) > 64:
+            self._tape_modes.clear()
+        self._tape_modes[tape.data_ptr()] = (int(self._w.res_f32), int(self._w.dx_f32))
         return loss, nll, logits, ctx
 
     def backward_from_ctx(self, ctx, n_audio_rows, want_d_embeds=False, want_d_audio=True):
@@ -505,23 +542,16 @@ class Qwen3MI355X(torch.nn.Module):
             wg = _lib.LmWgrads(layers=C.cast(arr, C.POINTER(_lib.LmLayerWgrads)), dnorm=bufs[8].data_ptr(), dembed=bufs[9].data_ptr())
             keep = (arr, bufs)
             lg = [None] * len(ps) if direct else bufs
-        recorded = getattr(self, "_tape_modes", {}).get(ctx["tape"].data_ptr())
-        restore = None
-        if recorded is not None and not _lib.DRY_RUN:
-            from . import ops as _ops
-            now = _ops.get_stream_modes()
-            if now != recorded:
-                restore = now
-                _ops.set_stream_modes(**recorded)
-        try:
-            _lib.check(_lib.lib().ta_lm_backward(C.byref(self._w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
-                                                 ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
-                                                 ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr,
-                                                 None if wg is None else C.byref(wg), ptr(ctx.get("ids")), ptr(ctx["tape"]),
-                                                 ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
-        finally:
-            if restore is not None:
-                _ops.set_stream_modes(**restore)
+        w = self._w
+        recorded = self._tape_modes.pop(ctx["tape"].data_ptr(), None)
+        if recorded is not None and recorded != (int(w.res_f32), int(w.dx_f32)):
+            w = _lib.LmWeights.from_buffer_copy(self._w)          # same pointers, the modes the forward ran in
+            w.res_f32, w.dx_f32 = recorded
+        _lib.check(_lib.lib().ta_lm_backward(C.byref(w), ptr(ctx["src_row"]), ptr(ctx["kmask"]), ptr(ctx["pos"]),
+                                             ctx["B"], ctx["L"], ptr(ctx["label_rows"]), ctx["n_label_rows"],
+                                             ptr(d_audio), n_audio_rows, ptr(d_emb), lg_arr,
+                                             None if wg is None else C.byref(wg), ptr(ctx.get("ids")), ptr(ctx["tape"]),
+                                             ptr(ctx["ws"]), ctx["ws"].numel(), stream()), "ta_lm_backward")
         del keep
         return d_audio, d_emb, lg
 

@@ -55,38 +55,6 @@ def sync_gemm_knobs():
         _knob_state = cur
 
 
-def set_stream_modes(enc_res_f32=None, lm_res_f32=None, lm_dx_f32=None):
-    """Storage dtype of the residual streams (include/ta355.h ``ta_set_stream_modes``): False = bf16 (bf16-module reference,
-    tiny_audio/asr_config.py:41), True = fp32 (the training recipe: fp32 modules + bf16 autocast, configs/config.yaml:14-18).
-    None leaves a stream unchanged.  Process-wide; change it between steps only."""
-    f = lambda v: -1 if v is None else int(bool(v))
-    check(lib().ta_set_stream_modes(f(enc_res_f32), f(lm_res_f32), f(lm_dx_f32)), "ta_set_stream_modes")
-
-
-def get_stream_modes():
-    """-> dict(enc_res_f32, lm_res_f32, lm_dx_f32) of booleans."""
-    import ctypes
-    out = (ctypes.c_int * 3)()
-    check(lib().ta_get_stream_modes(ctypes.cast(out, ctypes.c_void_p)), "ta_get_stream_modes")
-    return dict(enc_res_f32=bool(out[0]), lm_res_f32=bool(out[1]), lm_dx_f32=bool(out[2]))
-
-
-class stream_modes:
-    """``with ops.stream_modes(f32=True): ...`` -- all three streams in fp32 (the recipe's storage) or bf16, restored on exit."""
-
-    def __init__(self, f32: bool):
-        self.f32 = bool(f32)
-
-    def __enter__(self):
-        self.prev = get_stream_modes()
-        set_stream_modes(self.f32, self.f32, self.f32)
-        return self
-
-    def __exit__(self, *exc):
-        set_stream_modes(**self.prev)
-        return False
-
-
 def gemm_nt(A, W, M=None, N=None, K=None, *, out=None, out_dtype=BF16, bias=None, residual=None, act=0,
             a_map=None, c_map=None, splits=1, k_ext=None, residual_bf16=None, rope=None, w_blocked=False):
     """C[M,N] = epilogue(A[M,K] @ W[N,K]^T).  a_map=(ld, rpb, batch_stride); c_map=(ld, rpb, batch_stride, offset);

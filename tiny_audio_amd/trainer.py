@@ -153,10 +153,14 @@ def _distributed(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+COLLECTIVES = {"allreduce_flat": 0}      # data-path collectives issued by this process (bench.py reports them per step)
+
+
 def allreduce_flat(flat: torch.Tensor, group=None, async_op: bool = False):
     """SUM all-reduce of the flat [grads | count | loss] buffer (RCCL on GPUs, gloo in the CPU tests).
     ``async_op``: returns the collective's Work handle (None on a single rank) instead of waiting for it."""
     if _distributed(group):
+        COLLECTIVES["allreduce_flat"] += 1
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return work if async_op else flat
     return None if async_op else flat
