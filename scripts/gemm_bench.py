@@ -69,11 +69,8 @@ if only in ("all", "gemm"):
         shapes = [s_ for s_ in shapes if sys.argv[sys.argv.index("--match") + 1] in s_[0]]
     for name, M, N, K, obf, act, hasres in shapes:
       for var in variants:
-        os.environ["TA355_GROUP_M"] = var.split("g")[1] if "g" in var else ""
-        var = var.split("g")[0]
-        os.environ["TA355_GEMM_VARIANT"] = var.split("w")[0]
-        os.environ["TA355_EPI_WIDE"] = "0" if var.endswith("w0") else "1"
-        name_v = name + (":v" + var if var else "") + (":g" + os.environ["TA355_GROUP_M"] if os.environ["TA355_GROUP_M"] else "")
+        os.environ["TA355_GEMM_VARIANT"] = var                    # the one tile knob the library has (0-5, 10, 12; "" = automatic)
+        name_v = name + (":v" + var if var else "")
         A = (torch.randn(M, K, device=DEV) * 1.0).to(BF16)
         W = (torch.randn(N, K, device=DEV) / K ** 0.5).to(BF16)
         out = torch.empty(M, N, device=DEV, dtype=BF16 if obf else F32)

@@ -140,8 +140,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950's file is unified).  The default AGPR form made
     # the attention kernels shuttle every score / output fragment through v_accvgpr_read/write around the softmax.
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-fPIC"]
-    if os.environ.get("TA355_BUILD_EXPERIMENTS") == "1":      # the GEMM's experiment variants (ring, stamped builds, v6): not in the product library
-        flags.append("-DTA355_EXPERIMENTS")
     # attention_enc.hip: no NaN can reach its row maxima (scores are finite MFMA sums; masked keys are -1e30, not -inf), and
     # without this every fmaxf on an MFMA result is preceded by a canonicalising v_max_f32 x, x (12 extra VALU per key tile)
     extra = {"attention_enc.hip": ["-fno-honor-nans"]}

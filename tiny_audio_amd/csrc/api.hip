@@ -651,9 +651,12 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   }
   float* dx = s.dxa;      // gradient w.r.t. the residual stream (f32) + its bf16 image for the GEMMs
   float* dx_alt = s.dxb32;
-  // dyb: the incoming gradient is bf16 (the two dX GEMMs that feed an RMSNorm backward write bf16 in that mode: it is
-  // read exactly once, so fp32 there only doubles epilogue and read bytes; the accumulating d(x) stream stays fp32)
-  const int gb = lm_res_bf16(w) ? 1 : 0;
+  // dyb: the gradient of an RMSNorm OUTPUT is bf16 in both stream modes.  It is read exactly once, so fp32 there only doubles the
+  // producing dX GEMM's epilogue bytes and this read (the accumulating d(x) stream keeps its own storage mode).  That is also the
+  // recipe's arithmetic: under bf16 autocast the Linear behind the norm takes a bf16 copy of its input, so autograd's gradient for it
+  // is a bf16 tensor that is only cast up on its way into the norm's backward (round 6; rounds 4-5 wrote fp32 here in the
+  // fp32-stream mode: 64.4 us per dX GEMM against 62.9, 20.6 us per RMSNorm backward against ~18).
+  const int gb = 1;
   // round 4: with the bf16 forward stream the d(x) stream is bf16 as well (ta_lm_weights.dx_f32 = 1: fp32 as in rounds 1-3) -- the
   // reference's bf16 model back-propagates bf16 gradients of its bf16 activations; s.dxb then IS the stream (updated in place by
   // every RMSNorm backward) and the two f32 images are written only by the last call, for the f32 consumers below the stack:
@@ -662,8 +665,9 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
   auto norm_bwd = [&](const float* dy, int dyb, const float* x, const float* r, const float* gw, const float* dres, float* dxf,
                       bool last = false) -> int {
     if (dx_bf16) return ta_rmsnorm_bwd_bf16s(dy, dyb, x, r, gw, dres ? s.dxb : nullptr, last ? dxf : nullptr, s.dxb, M, d.D, st);
-    return lm_res_bf16(w) ? ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
-                         : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
+    if (lm_res_bf16(w)) return ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st);
+    return dyb ? ta_i_rmsnorm_bwd_dyb(dy, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
+               : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
   };
   RC(norm_bwd(s.dhn, 0, t.x_final, t.r_f, w->norm_w, nullptr, dx, w->n_layers == 0));
   for (int l = w->n_layers - 1; l >= 0; --l) {

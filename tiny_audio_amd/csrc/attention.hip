@@ -27,6 +27,18 @@
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
 
+// Experiment builds only (-DTA355_ATTN_STAMPS, scripts/attn_stamps.py): s_memtime stamps at the phase boundaries of the LM attention
+// kernels, 16 per workgroup, read back with ta_debug_attn_stamps.  The product library compiles none of it.
+#ifdef TA355_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[8192 * 16];
+#define ATTN_STAMP(blk, i, who) do { if (threadIdx.x == (who)) g_attn_stamps[(long)(blk) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ta_debug_attn_stamps(unsigned long long* host_out, int nblocks) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)nblocks * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#else
+#define ATTN_STAMP(blk, i, who) do { } while (0)
+#endif
+
 // Row tiles are unpadded [64][HD] with the 16-B chunk index XOR-swizzled by the row: conflict-free ds_read_b128
 // fragments under either lane grouping of the instruction (same scheme the GEMM uses; measured 0 conflicts there).
 template <int HD> struct RowTile {
@@ -35,6 +47,14 @@ template <int HD> struct RowTile {
   static __device__ __forceinline__ int swz(int r) { return HD == 64 ? ((r >> 1) & 7) : (r & 15); }
   // byte offset of 16-B chunk c of row r
   static __device__ __forceinline__ int off(int r, int c) { return r * STRIDE + ((c ^ swz(r)) << 4); }
+  // Round 6: tiles that are ALSO read transposed (ds_read_b64_tr_b16: V in the forward; K, Q, dO in the backward) take this swizzle.
+  // A transposed read's 32-lane group covers 8 consecutive rows x 32 B (chunks ca, ca ^ 1 of every row); under `r & 15` rows r and
+  // r ^ 1 put (ca ^ r) and (ca ^ 1 ^ (r ^ 1)) in the SAME 16-B bank slot -- a 2-way conflict on every transposed read (PMC r05:
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.27 in attn_bwd_kernel).  XOR by 2 * (r & 7) spreads the 16 (row, chunk) pairs over
+  // all 16 slots, and the ds_read_b128 fragment pattern (16 rows x one chunk column per lane group) stays conflict-free under it:
+  // rows {0-3, 12-15} at chunk c and rows {4-11} at chunk c + 1 land on the even and the odd slots.  (Same idea as attention_enc's vswz.)
+  static __device__ __forceinline__ int swz_tr(int r) { return HD == 64 ? ((r >> 1) & 7) : ((r & 7) << 1); }
+  static __device__ __forceinline__ int off_tr(int r, int c) { return r * STRIDE + ((c ^ swz_tr(r)) << 4); }
 };
 template <int HD> struct ColTile { static constexpr int BYTES = HD * CT_STRIDE; };
 
@@ -138,9 +158,9 @@ __device__ __forceinline__ bf16x8 read_colfrag_tr(const char* rowtile, int dt, i
   const int chunk = dcol >> 3, half = (dcol >> 2) & 1;
   const int r0 = c0 + (l15 >> 2), r1 = c1 + (l15 >> 2);
   const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off(r0, chunk) + half * 8));
+      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off_tr(r0, chunk) + half * 8));
   const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off(r1, chunk) + half * 8));
+      (__attribute__((address_space(3))) bf16x4_t*)(rowtile + RowTile<HD>::off_tr(r1, chunk) + half * 8));
   return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
@@ -493,6 +513,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
       }
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 6 + 3 * pass, 0);                                   // tile loop done
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
     const int qrow = q0 + sub * 16 + l15;
@@ -513,7 +534,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
       if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 7 + 3 * pass, 0);                                   // output stores issued
   }   // pass
+#ifdef TA355_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(blockIdx.x + 6144, 11, 0);                                             // ... and acknowledged
+#endif
 }
 
 // ---- round 3: global -> LDS DMA staging of [64][128] row tiles for the backward (double-buffered LDS, no staging registers).
@@ -532,7 +558,7 @@ __device__ __forceinline__ void dma_rowtile128(const bf16_t* base, long row_stri
   for (int i = 0; i < 4; ++i) {
     const int blk = wave + 4 * i, r = blk * 4 + (lane >> 4);
     int gr = row0 + r; if (gr > nrows - 1) gr = nrows - 1; if (gr < 0) gr = 0;
-    const int c = (lane & 15) ^ RowTile<128>::swz(r);
+    const int c = (lane & 15) ^ RowTile<128>::swz_tr(r);       // the backward's tiles: every one is read with both patterns
     dma16_asm(base + (long)gr * row_stride + c * 8, __builtin_amdgcn_readfirstlane(lds_tile + blk * 1024));   // (wave-uniform by construction)
   }
 }
@@ -576,6 +602,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   // normalised and rotated IN PLACE in LDS, with the cos / sin rows of the next pass requested while the current one is
   // computed.  (The r02 form also sat behind an s_waitcnt per 16-B load: each load lived under its own bounds branch.)
   constexpr int PER = (MAXT * 64 * (HD / 8) + NT_ - 1) / NT_;
+  ATTN_STAMP(blockIdx.x + 6144, 0, 0);
   {
     const unsigned ldsK = lds_addr_of(Ks), ldsV = lds_addr_of(Vs);
     const bf16_t* kbase = qkv0 + (long)b * L * ld + (long)(Hq + hk) * HD;
@@ -584,10 +611,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
     for (int blk = wave; blk < ntiles * 16; blk += NW) {
       const int t = blk >> 4, rb4 = (blk & 15) * 4, r = rb4 + (lane >> 4);
       int gr = t * KV_TILE + r; if (gr > L - 1) gr = L - 1;
-      const int c = (lane & 15) ^ RowTile<HD>::swz(r);
+      const int c = (lane & 15) ^ RowTile<HD>::swz(r), cv = (lane & 15) ^ RowTile<HD>::swz_tr(r);   // V is read transposed
       const unsigned off = __builtin_amdgcn_readfirstlane((unsigned)(t * RowTile<HD>::BYTES + rb4 * 256));
       dma16_asm(kbase + (long)gr * ld + c * 8, ldsK + off);
-      dma16_asm(vbase + (long)gr * ld + c * 8, ldsV + off);
+      dma16_asm(vbase + (long)gr * ld + cv * 8, ldsV + off);
     }
   }
   {
@@ -605,8 +632,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
     };
     rope_rows(0, cc[0]);
     for (int i = tid; i < ntiles * 64; i += NT_) Ms[i] = (i < L) ? (kmask ? kmask[(long)b * L + i] : 1) : 0;
+    ATTN_STAMP(blockIdx.x + 6144, 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA instructions (and the loads above) have landed
     __syncthreads();                                  // ... everyone's
+    ATTN_STAMP(blockIdx.x + 6144, 2, 0);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int ch = tid + i * NT_, t = ch / (64 * (HD / 8)), w = ch % (64 * (HD / 8));
@@ -617,7 +646,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
         const long tok = (long)b * L + gr;
         char* kp = Ks + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c);
         const uint4 kin = *(const uint4*)kp;
-        const uint4 vin = *(const uint4*)(Vs + t * RowTile<HD>::BYTES + RowTile<HD>::off(r, c));
+        const uint4 vin = *(const uint4*)(Vs + t * RowTile<HD>::BYTES + RowTile<HD>::off_tr(r, c));
         const uint32_t u[4] = {kin.x, kin.y, kin.z, kin.w};
         float x[8], ss = 0.f;
 #pragma unroll
@@ -646,7 +675,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
       }
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 3, 0);
   __syncthreads();
+  ATTN_STAMP(blockIdx.x + 6144, 4, 0);
   const bf16x8 ones = (bf16x8){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 zeros = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
   const bf16x8 one_row = l15 == 0 ? ones : zeros;     // row 0 of the extra block is all ones: it accumulates l = sum_k P[q, k]
@@ -721,6 +752,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) m_run[sub] = NEG_BIG;
   const int my_tiles = min(ntiles, (q0 + 16 * QSUB - 1) / KV_TILE + 1);      // causal: keys beyond the wave's last query never count
+  ATTN_STAMP(blockIdx.x + 6144, 5 + 3 * pass, 0);                                   // wave 0: queries staged (pass 0: 1 tile, pass 1: 3 tiles)
   for (int t = 0; t < my_tiles; ++t) {
     const int key0 = t * KV_TILE;
     const char* Kt = Ks + t * RowTile<HD>::BYTES;
@@ -945,6 +977,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     dma_rowtile128(Vb, HD, t * KV_TILE, L, dst + RowTile<HD>::BYTES, wave, lane);
     if (tid < 64) { const int kk = t * KV_TILE + tid; pm = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
   };
+  ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 0, 0);   // (dq blocks are stamped from 4096 up, by their distance from the grid's end)
   if (ntiles > 0) issue(0);
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * KV_TILE;
@@ -954,6 +987,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
     if (tid < 64) Ms[tid] = pm;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // tile t has landed; every wave is done with tile t - 1 (the other buffer)
+    if (t == 0) ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 1, 0);
     if (t + 1 < ntiles) issue(t + 1);
     f32x4 s[4], dp[4];
 #pragma unroll
@@ -962,7 +996,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
       dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < HD / 32; ++ks) {
-        const int off = RowTile<HD>::off(kt * 16 + l15, ks * 4 + g);
+        const int off = RowTile<HD>::off_tr(kt * 16 + l15, ks * 4 + g);
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Ks + off), qf[ks], s[kt], 0, 0, 0);
         dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Vs + off), dof[ks], dp[kt], 0, 0, 0);
       }
@@ -990,6 +1024,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
       }
     }
   }
+  ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 2, 0);
   __syncthreads();                                     // the tiles are free for the fused epilogue's image
   if (F.qkv0) {
     if constexpr (HD == 128) {
@@ -997,6 +1032,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
       __syncthreads();
       qkv_post_bwd_tile(smem, F, 0, b, qt * 64, L, h, Hq, Hkv, tid);
     }
+#ifdef TA355_ATTN_STAMPS
+    ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 3, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 4, 0);
+    if (threadIdx.x == 0) { g_attn_stamps[(long)(gridDim.x - 1 - blockIdx.x + 4096) * 16 + 5] = ntiles; g_attn_stamps[(long)(gridDim.x - 1 - blockIdx.x + 4096) * 16 + 6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); }
+#endif
     return;
   }
   if (qrow < L) {
@@ -1062,6 +1103,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
     }
   };
+  ATTN_STAMP(blockIdx.x + 6144, 0, 0);
   if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
   for (int hh = 0; hh < grp; ++hh) {
     for (int qt = qt_begin; qt < nq; ++qt, ++it) {
@@ -1073,6 +1115,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       if (tid < 64) { Ls[tid] = pl * LOG2E; Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (it == 0) ATTN_STAMP(blockIdx.x + 6144, 1, 0);
       if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
       else if (hh + 1 < grp) issue(hh + 1, qt_begin, (it + 1) & 1);
       f32x4 s[4], dp[4];
@@ -1082,7 +1125,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
         dp[qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
-          const int off = RowTile<HD>::off(qs * 16 + l15, ks * 4 + g);
+          const int off = RowTile<HD>::off_tr(qs * 16 + l15, ks * 4 + g);
           s[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(Qs + off), kf[ks], s[qs], 0, 0, 0);
           dp[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dOs + off), vf[ks], dp[qs], 0, 0, 0);
         }
@@ -1117,6 +1160,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       }
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 2, 0);
   __syncthreads();                                     // the tiles are free for the fused epilogue's image
   if (F.qkv0) {
     if constexpr (HD == 128) {
@@ -1128,6 +1172,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       __syncthreads();
       qkv_post_bwd_tile(smem, F, 2, b, kt_idx * 64, L, hk, Hq, Hkv, tid);
     }
+#ifdef TA355_ATTN_STAMPS
+    ATTN_STAMP(blockIdx.x + 6144, 3, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(blockIdx.x + 6144, 4, 0);
+    if (threadIdx.x == 0) { g_attn_stamps[(long)blockIdx.x * 16 + 5] = it; g_attn_stamps[(long)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); }
+#endif
     return;
   }
   if (krow < L) {

@@ -117,7 +117,7 @@ template <int NT, int ACT, bool OUT_BF16, bool HAS_RES, bool ELS = false>
 __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs& p, char* Cb, long roff, int nb, int g, bool wide,
                                                int m, const float* bias, const float2* lut = nullptr, const EpiPre<NT>* pre = nullptr,
                                                bool pre_r = false, const char* els = nullptr, int ecol0 = 0, int erow = 0,
-                                               uint2* oret = nullptr) {
+                                               uint2* oret = nullptr, const float4* pref = nullptr) {
   // ACT: 0 none, 1 erf-GELU, 2 partial rotary embedding.  (Rounds 1-4 also carried a folded-LayerNorm form (ACT 3 / 4 / 5) and a fused
   // SwiGLU-backward form (ACT 6) as separate instantiations; both measured slower in the step than the streaming kernels they
   // replaced -- DESIGN.md section 8 -- and left the library in round 5.)
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue_strip(const f32x4* acc, const GemmArgs&
     }
     if (HAS_RES) {
       if (p.res_bf16) rb[j] = pre_r ? pre->r[j] : *(const uint2*)((const bf16_t*)p.res + roff + nn);
-      else rf[j] = *(const float4*)(p.res + roff + nn);
+      else rf[j] = pref ? pref[j] : *(const float4*)(p.res + roff + nn);
     }
   }
   uint2 o[NT];
@@ -278,7 +278,63 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
       epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, pre, pre_r, els, ecol0, erow0 + i * 16);
     }
   };
-  if constexpr (AHEAD == 1) {
+  if constexpr (AHEAD == 3 && HAS_RES && !OUT_BF16) {
+    // the one-wave-per-SIMD kernel (v5: registers to spare), f32 residual: every strip's residual in ONE batch of loads
+    float4 r[MI][NT];
+    if (!p.res_bf16) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        int ml = ml0 + i * 16; if (ml >= Mact) ml = Mact - 1;
+        const long ro = row_off(rbase + ml);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) r[i][j] = *(const float4*)(p.res + ro + ncl[j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int ml = ml0 + i * 16;
+      if (ml < Mact) {
+        const int m = rbase + ml;
+        epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, nullptr, false, els, ecol0,
+                                                        erow0 + i * 16, nullptr, r[i]);
+      }
+    }
+  } else if constexpr (AHEAD == 1 && HAS_RES && !OUT_BF16) {
+    // Round 6, the fp32-stream mode (f32 residual, f32 out, in place: x += A W^T + b): the residual of TWO strips in one batch of
+    // loads (the residual aliases C, so the compiler cannot hoist a strip's loads over the
+    // previous strip's stores by itself)
+    static_assert(MI % 2 == 0, "pairs of strips");
+    auto fetch_f = [&](int i, float4* dst) {
+      int ml = ml0 + i * 16; if (ml >= Mact) ml = Mact - 1;
+      const long ro = row_off(rbase + ml);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dst[j] = *(const float4*)(p.res + ro + ncl[j]);
+    };
+    auto strip_f = [&](int i, const float4* r) {
+      const int ml = ml0 + i * 16;
+      if (ml < Mact) {
+        const int m = rbase + ml;
+        epilogue_strip<NT, ACT, OUT_BF16, HAS_RES, ELS>(acc[i], p, Cb, row_off(m), nb, g, wide, m, bias, lut, nullptr, false, els, ecol0,
+                                                        erow0 + i * 16, nullptr, r);
+      }
+    };
+    // the first two strips alone: a pair's second batch of loads lives in the registers of accumulator strips that are already
+    // stored (with all 8 strips live a batch of 2 x NT float4 spilled: 96 bytes of scratch per lane) -- 5 round trips instead of 8
+    static_assert(MI >= 4, "two single strips, then pairs");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 r0[NT];
+      if (!p.res_bf16) fetch_f(i, r0);
+      strip_f(i, r0);
+    }
+#pragma unroll
+    for (int i = 2; i < MI; i += 2) {
+      float4 r0[NT], r1[NT];
+      if (!p.res_bf16) { fetch_f(i, r0); fetch_f(i + 1, r1); }
+      strip_f(i, r0);
+      strip_f(i + 1, r1);
+    }
+  } else if constexpr (AHEAD == 1) {
     static_assert(MI % 2 == 0, "pairs of strips");
 #pragma unroll
     for (int i = 0; i < MI; i += 2) {
@@ -307,6 +363,11 @@ __device__ __forceinline__ void epilogue_tile(const f32x4 (*acc)[NT], const Gemm
 // whatever tile the launch-time model picks (the B = 32 step and the same clips at B = 4 run different variants and are compared
 // in the tests), and the kernels' epilogues have no residual load left to wait for.  Loads in batches of <= 4 strips.
 // TA355_GEMM_RES_INIT=0 (p.dbg bit 20): the r02 form, residual added in the epilogue.
+// (Round 6 tried the same for an f32 residual with an f32 output -- the fp32-stream mode: float4 loads straight into the accumulator
+// registers behind the first K tile's DMA.  Same-box A/B, profiles/r06_b_ab_f32.txt: the encoder's o_proj / fc2 launches 133.8 us
+// against 130.2, the LM's one-wave-per-SIMD tiles 65.2 against 43.2: the start values must have landed before the first MFMA, so
+// the read is as exposed at the top of the tile as it was in the epilogue, and 96-160 registers of loads per lane queue in front
+// of the first K tile.  Removed.)
 template <int ACT, bool OUT_BF16, bool HAS_RES>
 __device__ __forceinline__ bool residual_is_start(const GemmArgs& p) {
   return HAS_RES && ACT == 0 && OUT_BF16 && p.res_bf16 && p.splits == 1 && !(p.dbg & (1 << 20));
@@ -428,4 +489,3 @@ __device__ __forceinline__ TileCtx tile_ctx(const GemmArgs& p, int h, int total)
   c.ok = 1;
   return c;
 }
-

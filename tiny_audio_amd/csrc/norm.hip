@@ -7,6 +7,7 @@
 //   rmsnorm_bwd_kernel   its backward (dx, optional dw, optional GELU' prologue, optional residual add)
 #include <cstdlib>
 #include "common.h"
+#include "internal.h"
 
 #define MAXV_LIMIT 20   // float4 per lane -> rows up to 64*4*20 = 5120 columns
 // MAXV (float4 per lane held in registers) is a template parameter: 4 (H<=1024), 8 (<=2048), 20 (<=5120)
@@ -433,6 +434,21 @@ extern "C" int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* 
   else TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, true, false, true>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, dx_f32,       \
                  (bf16_t*)dx_bf16, (float*)nullptr, M, H);
   DISPATCH_MAXV(H, RBS_CALL);
+  TA_CHECK_LAUNCH();
+  return TA_OK;
+}
+
+// fp32 residual stream, bf16 incoming gradient (internal: ta_lm_backward in the fp32-stream mode -- under the recipe's bf16 autocast
+// the gradient of a Linear's bf16 input IS a bf16 tensor, cast up afterwards, so nothing is lost by keeping its 2 bytes)
+int ta_i_rmsnorm_bwd_dyb(const void* dy_bf16, const float* x, const float* rstd, const float* w, const float* dres, float* dx_f32,
+                         void* dx_bf16, int M, int H, hipStream_t st) {
+  if (M <= 0) return TA_OK;
+  if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  const float* dyf = (const float*)dy_bf16;
+#define RBD_CALL(V)                                                                                                              \
+  TA_LAUNCH((rmsnorm_bwd_kernel<V, 0, false, true, false>), dim3(ta_cdiv(M, 4)), dim3(256), 0, st, dyf, x, rstd, w, dres, dx_f32, \
+            (bf16_t*)dx_bf16, (float*)nullptr, M, H);
+  DISPATCH_MAXV(H, RBD_CALL);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

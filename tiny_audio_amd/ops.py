@@ -33,15 +33,10 @@ def _req(t, dtype=None):
     return t
 
 
-# The GEMM launcher reads its environment knobs once (csrc/gemm.hip GemmKnobs); tests and A/B scripts switch them between launches,
-# so the wrapper re-reads them whenever one of the per-launch knobs of rounds 1-3 has changed since the previous call.
-# every run-time knob the library reads ONCE (GemmKnobs::load, the decode switch): a change is followed by ta_gemm_reload_knobs().
-# The product library has exactly these (plus TA355_ENC_QKV_FUSED, read per call); an experiment build (TA355_BUILD_EXPERIMENTS=1)
-# reads the rounds-1-4 GEMM knobs too -- all of them are watched here
-_KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GELU_LUT", "TA355_DECODE_FUSED",
-              "TA355_GEMM_DEBUG", "TA355_GROUP_M", "TA355_GROUP_M_AUTO", "TA355_EPI_WIDE", "TA355_GEMM_RES_INIT", "TA355_GEMM_PERSIST",
-              "TA355_GEMM_PERSIST_KEXT", "TA355_GEMM_M32", "TA355_GEMM_NO96", "TA355_GEMM_RING", "TA355_V5_MINK", "TA355_RATE_256x320",
-              "TA355_RATE_192x128", "TA355_RATE_192x256")
+# The library reads its environment knobs once (csrc/gemm.hip GemmKnobs::load, the decode switch of generate.hip); tests and A/B
+# scripts switch them between launches, so the wrapper calls ta_gemm_reload_knobs() whenever one has changed since the previous call.
+# These three are all the library has (plus TA355_ENC_QKV_FUSED, read per call).
+_KNOB_KEYS = ("TA355_GEMM_VARIANT", "TA355_GELU_LUT", "TA355_DECODE_FUSED")
 _knob_state = None
 
 
