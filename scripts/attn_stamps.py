@@ -77,10 +77,7 @@ def main():
         rows = rows[rows[:, 0] > 0]
         if not len(rows):
             lines.append(f"{name}: no stamps"); return
-        t0 = rows[:, 0].astype(np.int64)
-        lines.append(f"{name}: {len(rows)} workgroups; launch span (first start -> last end) "
-                     f"{(rows[:, phases[-1][2]].astype(np.int64).max() - t0.min()) * tick_us:.1f} k; "
-                     f"start skew p50 / max {np.percentile(t0 - t0.min(), 50) * tick_us:.1f} / {(t0.max() - t0.min()) * tick_us:.1f}")
+        lines.append(f"{name}: {len(rows)} workgroups (differences inside a workgroup only: s_memtime is not synchronised across XCDs)")
         for label, i0, i1 in phases:
             d = (rows[:, i1].astype(np.int64) - rows[:, i0].astype(np.int64)) * tick_us
             d = d[(rows[:, i0] > 0) & (rows[:, i1] > 0)]
@@ -106,10 +103,6 @@ def main():
         report(f"attn_bwd dQ body, {nt} key tiles", sel, [
             ("first K / V tile landed (+ q, dO fragments)", 0, 1), ("tiles", 1, 2), ("epilogue: stage + q post backward", 2, 3),
             ("stores acknowledged", 3, 4), ("whole workgroup", 0, 4)])
-    allb = np.concatenate([dkv[dkv[:, 0] > 0], dq[dq[:, 0] > 0]])
-    if len(allb):
-        lines.append(f"attn_bwd_kernel launch span: {(allb[:, 4].astype(np.int64).max() - allb[:, 0].astype(np.int64).min()) * tick_us:.1f} k "
-                     f"({len(allb)} workgroups)")
     text = "\n".join(lines)
     print(text)
     if a.out:

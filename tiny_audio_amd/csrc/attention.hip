@@ -513,7 +513,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
       }
     }
   }
-  ATTN_STAMP(blockIdx.x + 6144, 6 + 3 * pass, 0);                                   // tile loop done
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
     const int qrow = q0 + sub * 16 + l15;
@@ -534,12 +533,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_kernel(const bf16_t* __r
       if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
     }
   }
-  ATTN_STAMP(blockIdx.x + 6144, 7 + 3 * pass, 0);                                   // output stores issued
   }   // pass
-#ifdef TA355_ATTN_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  ATTN_STAMP(blockIdx.x + 6144, 11, 0);                                             // ... and acknowledged
-#endif
 }
 
 // ---- round 3: global -> LDS DMA staging of [64][128] row tiles for the backward (double-buffered LDS, no staging registers).
@@ -577,7 +571,12 @@ constexpr int BWD_BUF = 2 * 64 * 128 * 2 + 512;      // one staging buffer of th
 //   staging: 16 lanes per key row (one 16-B chunk of 8 dims each; chunk c and c + 8 are RoPE partners, 8 lanes apart)
 //   queries: in the MFMA fragment layout (lane = row l15, dims ks * 32 + g * 8 ..): the 4 g lanes share a row, dims d and d + 64 are
 //            fragments ks and ks + 2 of the same lane
-template <int HD, int MAXT, int QSUB, int NW>
+// PAIR (round 6, GQA groups of two query heads): a wave's two 16-row sub-tiles are the SAME 16 rows of the group's two heads instead of
+// 32 consecutive rows of one head, so the rows' cos / sin table entries (512 B per row) are fetched once for both heads.  The phase
+// stamps of this kernel (scripts/attn_stamps.py, profiles/r06_d_attn_stamps_f32.txt) show it moving ~784 KB per workgroup through the
+// CU's vector-memory path at ~10 B per cycle for its whole life -- it is bound by that path, not by latency or MFMA -- and 196 KB of
+// it were query-side table rows.  Results are bit-identical (each row's arithmetic and its order over the keys do not change).
+template <int HD, int MAXT, int QSUB, int NW, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t* __restrict__ qkv0, const float* __restrict__ qn_w,
                                                                const float* __restrict__ kn_w, const float* __restrict__ cosT,
                                                                const float* __restrict__ sinT, const int* __restrict__ pos,
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   int* Ms = (int*)(Vs + MAXT * RowTile<HD>::BYTES);  // key mask, MAXT * 64
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x / Hkv, hk = blockIdx.x % Hkv;
-  const int grp = Hq / Hkv, cph = (L + 16 * QSUB - 1) / (16 * QSUB), nchunk = grp * cph;
+  const int grp = Hq / Hkv, cph = PAIR ? (L + 15) / 16 : (L + 16 * QSUB - 1) / (16 * QSUB), nchunk = PAIR ? cph : grp * cph;
   const long ld = (long)(Hq + 2 * Hkv) * HD;
   const float sl2 = scale * LOG2E;
   const int ntiles = (L + KV_TILE - 1) / KV_TILE;
@@ -684,26 +683,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   for (int pass = 0; pass < 2; ++pass) {
   const int chunk = pass == 0 ? wave : nchunk - 1 - wave;
   if (chunk >= nchunk || (pass == 1 && chunk < NW)) continue;          // wave-uniform
-  const int h = hk * grp + chunk / cph;
-  const int q0 = (chunk % cph) * 16 * QSUB;
+  const int h0 = PAIR ? hk * grp : hk * grp + chunk / cph;             // head of sub-tile 0 (PAIR: sub-tile s is head h0 + s)
+  const int q0 = PAIR ? chunk * 16 : (chunk % cph) * 16 * QSUB;
+  constexpr int RSTEP = PAIR ? 0 : 16;                                  // row offset between the sub-tiles
   bf16x8 qf[QSUB][HD / 32];
+  float4 tc[2][2], ts[2][2];                                            // cos / sin rows of the current sub-tile (PAIR: of both)
   // (Round 3: the loads of a query sub-tile -- its 4 row chunks and the cos / sin rows of both dim halves -- are issued as ONE batch;
   // the r02 form waited for the row, then per dim half for eight dependent table loads.)
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
-    const int qrow = q0 + sub * 16 + l15, qr = qrow > L - 1 ? L - 1 : qrow;
+    const int h = PAIR ? h0 + sub : h0;
+    const int qrow = q0 + sub * RSTEP + l15, qr = qrow > L - 1 ? L - 1 : qrow;
     const long tok = (long)b * L + qr;
     const bf16_t* src = qkv0 + tok * ld + (long)h * HD;
-    const int p = pos ? pos[tok] : qr;
     uint4 raw[HD / 32];
-    float4 tc[2][2], ts[2][2];
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) raw[ks] = *(const uint4*)(src + ks * 32 + g * 8);
+    if (!PAIR || sub == 0) {
+      const int p = pos ? pos[tok] : qr;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int d0 = ks * 32 + g * 8;
-      tc[ks][0] = *(const float4*)(cosT + (long)p * 64 + d0); tc[ks][1] = *(const float4*)(cosT + (long)p * 64 + d0 + 4);
-      ts[ks][0] = *(const float4*)(sinT + (long)p * 64 + d0); ts[ks][1] = *(const float4*)(sinT + (long)p * 64 + d0 + 4);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        tc[ks][0] = *(const float4*)(cosT + (long)p * 64 + d0); tc[ks][1] = *(const float4*)(cosT + (long)p * 64 + d0 + 4);
+        ts[ks][0] = *(const float4*)(sinT + (long)p * 64 + d0); ts[ks][1] = *(const float4*)(sinT + (long)p * 64 + d0 + 4);
+      }
     }
     float x[HD / 32][8], ss = 0.f;
 #pragma unroll
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
   float m_run[QSUB];
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) m_run[sub] = NEG_BIG;
-  const int my_tiles = min(ntiles, (q0 + 16 * QSUB - 1) / KV_TILE + 1);      // causal: keys beyond the wave's last query never count
+  const int my_tiles = min(ntiles, (q0 + (PAIR ? 16 : 16 * QSUB) - 1) / KV_TILE + 1);      // causal: keys beyond the wave's last query never count
   ATTN_STAMP(blockIdx.x + 6144, 5 + 3 * pass, 0);                                   // wave 0: queries staged (pass 0: 1 tile, pass 1: 3 tiles)
   for (int t = 0; t < my_tiles; ++t) {
     const int key0 = t * KV_TILE;
@@ -773,8 +776,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
     }
 #pragma unroll
     for (int sub = 0; sub < QSUB; ++sub) {
-      const int qrow = q0 + sub * 16 + l15;
-      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (key0 + KV_TILE - 1 <= q0 + sub * 16);
+      const int qrow = q0 + sub * RSTEP + l15;
+      const bool full = (key0 + KV_TILE <= L) && (kmask == nullptr) && (key0 + KV_TILE - 1 <= q0 + sub * RSTEP);
       if (!full) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -824,9 +827,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
       }
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 6 + 3 * pass, 0);                                   // tile loop done
 #pragma unroll
   for (int sub = 0; sub < QSUB; ++sub) {
-    const int qrow = q0 + sub * 16 + l15;
+    const int h = PAIR ? h0 + sub : h0;
+    const int qrow = q0 + sub * RSTEP + l15;
     const float l_run = __shfl(o[sub][ND][0], l15, 64);
     if (qrow < L) {
       const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -842,7 +847,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
       if (LSE && g == 0) LSE[(long)(b * Hq + h) * L + qrow] = l_run > 0.f ? m_run[sub] * scale + __logf(l_run) : 1.0e30f;
     }
   }
+  ATTN_STAMP(blockIdx.x + 6144, 7 + 3 * pass, 0);                                   // output stores issued
   }   // pass
+#ifdef TA355_ATTN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(blockIdx.x + 6144, 11, 0);                                             // ... and acknowledged
+#endif
 }
 
 // ---- optional fused epilogue of the backward: the q|k|v post-processing backward (RoPE^T, per-head RMSNorm backward, head-major ->
@@ -1103,7 +1113,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       pd = Delta[(long)(b * Hq + h) * L + q0 + tid];
     }
   };
-  ATTN_STAMP(blockIdx.x + 6144, 0, 0);
+  ATTN_STAMP(blockIdx.x, 0, 0);
   if (grp > 0 && qt_begin < nq) issue(0, qt_begin, 0);
   for (int hh = 0; hh < grp; ++hh) {
     for (int qt = qt_begin; qt < nq; ++qt, ++it) {
@@ -1115,7 +1125,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       if (tid < 64) { Ls[tid] = pl * LOG2E; Ds[tid] = pd; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (it == 0) ATTN_STAMP(blockIdx.x + 6144, 1, 0);
+      if (it == 0) ATTN_STAMP(blockIdx.x, 1, 0);
       if (qt + 1 < nq) issue(hh, qt + 1, (it + 1) & 1);
       else if (hh + 1 < grp) issue(hh + 1, qt_begin, (it + 1) & 1);
       f32x4 s[4], dp[4];
@@ -1160,7 +1170,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       }
     }
   }
-  ATTN_STAMP(blockIdx.x + 6144, 2, 0);
+  ATTN_STAMP(blockIdx.x, 2, 0);
   __syncthreads();                                     // the tiles are free for the fused epilogue's image
   if (F.qkv0) {
     if constexpr (HD == 128) {
@@ -1173,9 +1183,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
       qkv_post_bwd_tile(smem, F, 2, b, kt_idx * 64, L, hk, Hq, Hkv, tid);
     }
 #ifdef TA355_ATTN_STAMPS
-    ATTN_STAMP(blockIdx.x + 6144, 3, 0);
+    ATTN_STAMP(blockIdx.x, 3, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ATTN_STAMP(blockIdx.x + 6144, 4, 0);
+    ATTN_STAMP(blockIdx.x, 4, 0);
     if (threadIdx.x == 0) { g_attn_stamps[(long)blockIdx.x * 16 + 5] = it; g_attn_stamps[(long)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20); }
 #endif
     return;
@@ -1308,9 +1318,17 @@ extern "C" int ta_attention_fwd_qkv(const void* qkv0, const float* qn_w, const f
   constexpr int MAXT = 3, QS = 2, NW = 6;
   const size_t lds = 2 * MAXT * RowTile<128>::BYTES + MAXT * 64 * 4;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  TA_LAUNCH((attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>), dim3(B * Hkv), dim3(NW * 64), lds, st, (const bf16_t*)qkv0, qn_w, kn_w, cosT, sinT,
-            pos, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, rq, rk, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, scale, eps);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (grp == 2)     // Qwen3 (16 / 8): both heads of the group on the same 16 rows per wave (one fetch of the rows' cos / sin entries)
+    TA_LAUNCH((attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW, true>), dim3(B * Hkv), dim3(NW * 64), lds, st, (const bf16_t*)qkv0, qn_w, kn_w, cosT, sinT,
+              pos, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, rq, rk, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, scale, eps);
+  else
+    TA_LAUNCH((attn_fwd_gqa_qkv_kernel<128, MAXT, QS, NW>), dim3(B * Hkv), dim3(NW * 64), lds, st, (const bf16_t*)qkv0, qn_w, kn_w, cosT, sinT,
+              pos, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V, rq, rk, (bf16_t*)O, LSE, kmask, B, Hq, Hkv, L, scale, eps);
   TA_CHECK_LAUNCH();
   return TA_OK;
 }

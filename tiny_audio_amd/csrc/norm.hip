@@ -142,6 +142,75 @@ __global__ __launch_bounds__(256) void layernorm_bf16x8_kernel(const bf16_t* __r
 }
 
 
+// f32 -> bf16 LayerNorm, the fp32-stream mode of the encoder (round 6): the same half-wave-per-row walk as layernorm_bf16x8_kernel
+// -- gamma / beta columns in registers, the next row's chunks requested before the current row's arithmetic, two 16-byte loads and one
+// 16-byte store per chunk and lane.  The generic wave-per-row kernel it replaces there re-read gamma and beta (10 KB) for every
+// 5-KB row: 24.4 us per launch at B = 32 (123 MB: 5.0 TB/s).
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_f32x8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, bf16_t* __restrict__ y,
+                                                              const float* __restrict__ rowscale, int M, float eps) {
+  constexpr int H = NCH * 256;
+  const int l = threadIdx.x & 31;
+  const int row0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * ROWS;
+  if (row0 >= M) return;
+  float ww[NCH][8], bb[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (l + i * 32) * 8;
+    const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + c + 4);
+    const float4 b0 = *(const float4*)(b + c), b1 = *(const float4*)(b + c + 4);
+    ww[i][0] = w0.x; ww[i][1] = w0.y; ww[i][2] = w0.z; ww[i][3] = w0.w; ww[i][4] = w1.x; ww[i][5] = w1.y; ww[i][6] = w1.z; ww[i][7] = w1.w;
+    bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+  }
+  float4 nx[NCH][2];
+  {
+    const float4* xr = (const float4*)(x + (long)row0 * H);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { nx[i][0] = xr[(l + i * 32) * 2]; nx[i][1] = xr[(l + i * 32) * 2 + 1]; }
+  }
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = row0 + rr;
+    if (row >= M) break;                               // (uniform per half wave: the shuffles below stay inside it)
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      v[i][0] = nx[i][0].x; v[i][1] = nx[i][0].y; v[i][2] = nx[i][0].z; v[i][3] = nx[i][0].w;
+      v[i][4] = nx[i][1].x; v[i][5] = nx[i][1].y; v[i][6] = nx[i][1].z; v[i][7] = nx[i][1].w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+    if (rr + 1 < ROWS && row + 1 < M) {
+      const float4* xr = (const float4*)(x + (long)(row + 1) * H);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { nx[i][0] = xr[(l + i * 32) * 2]; nx[i][1] = xr[(l + i * 32) * 2 + 1]; }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);          // lanes 0-31 / 32-63 reduce separately
+    const float mean = s / (float)H;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q2 += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, 64);
+    const float rstd = rsqrtf(q2 / (float)H + eps);
+    const float rs = rowscale ? rowscale[row] : 1.0f;
+    uint4* yr = (uint4*)(y + (long)row * H);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = ((v[i][j] - mean) * rstd * ww[i][j] + bb[i][j]) * rs;
+      yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+    }
+  }
+}
+
+
 // bf16 -> bf16 RMSNorm (the LM's residual stream) with 16-byte accesses, half a wave per row: same layout idea as
 // layernorm_bf16x8_kernel.  H = 256 * NCH.
 template <int NCH>
@@ -355,6 +424,20 @@ extern "C" int ta_layernorm_f32(const float* x, const float* w, const float* b, 
   if (M <= 0) return TA_OK;
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT || (!y_bf16 && !y_f32)) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
+  // f32 -> bf16 only, H a multiple of 256 up to 2048: the half-wave-per-row variant (as ta_layernorm_bf16; other shapes: the generic kernel)
+  if (y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {
+    const int rows = M >= 8 * 4 * 256 ? 4 : (M >= 8 * 2 * 256 ? 2 : 1);
+    dim3 g8(ta_cdiv(M, 8 * rows));
+    switch (H / 256) {
+#define LNF(N) case N: if (rows == 4) TA_LAUNCH((layernorm_f32x8_kernel<N, 4>), g8, blk, 0, st, x, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
+               else if (rows == 2) TA_LAUNCH((layernorm_f32x8_kernel<N, 2>), g8, blk, 0, st, x, w, b, (bf16_t*)y_bf16, rowscale, M, eps); \
+               else TA_LAUNCH((layernorm_f32x8_kernel<N, 1>), g8, blk, 0, st, x, w, b, (bf16_t*)y_bf16, rowscale, M, eps); break;
+      LNF(1) LNF(2) LNF(3) LNF(4) LNF(5) LNF(6) LNF(7) LNF(8)
+#undef LNF
+    }
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
 #define LN_CALL(V)                                                                                               \
   if (y_bf16 && y_f32)                                                                                           \
     TA_LAUNCH((layernorm_kernel<V, true, true>), grid, blk, 0, st, x, w, b, (bf16_t*)y_bf16, y_f32, rowscale, M, H, eps);  \
