@@ -460,7 +460,9 @@ int ta_attention_fwd_ex(const void* Q, const void* K, const void* VT, void* O, f
 /* ta_lm_qkv_post_fwd + ta_attention_fwd in ONE launch for short causal sequences (head_dim 128, L <= 192, (Hq / Hkv) * ceil(L / 32)
  * <= 12; otherwise TA_ERR_ARG and nothing is launched): qkv0 is the pre-norm q | k | v GEMM output [B*L, (Hq + 2 Hkv) * 128]; writes
  * O [B*L, Hq*128], LSE and the backward's operands Q / K (normalised, rotated) and V head-major [B, heads, L, 128], rq / rk (1 / rms per
- * (token, head)).  tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 forward. */
+ * (token, head)).  V may be NULL (round 6): V is neither normalised nor rotated, so ta_attention_bwd_qkv can read it in place from
+ * qkv0 and the head-major copy is only needed by callers that use it themselves (the KV cache of ta_lm_prefill, ta_attention_bwd).
+ * tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 forward. */
 int ta_attention_fwd_qkv(const void* qkv0, const float* qn_w, const float* kn_w, const float* cosT, const float* sinT,
                          const int* pos, void* Q, void* K, void* V, float* rq, float* rk, void* O, float* LSE,
                          const int* kmask, int B, int Hq, int Hkv, int L, float scale, float eps, hipStream_t st);
@@ -471,7 +473,8 @@ int ta_attention_bwd(const void* Q, const void* QT, const void* K, const void* K
                      void* dQ, void* dK, void* dV, int B, int Hq, int Hkv, int L, int Lp, int head_dim, int causal,
                      float scale, hipStream_t st);
 /* the same with ta_lm_qkv_post_bwd fused into its epilogue (frozen q_norm / k_norm): d(qkv0) token-major [B*L, (Hq + 2 Hkv) * 128] is
- * written directly from the f32 accumulators; no head-major dQ / dK / dV (tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 backward) */
+ * written directly from the f32 accumulators; no head-major dQ / dK / dV (tiny_audio path: TF:models/qwen3/modeling_qwen3.py:211-280 backward).
+ * V == NULL: the V rows are read in place from qkv0 (columns (Hq + Hkv) * 128 ...), see ta_attention_fwd_qkv. */
 int ta_attention_bwd_qkv(const void* Q, const void* K, const void* V, const void* dO, long dO_stride, const float* LSE,
                          const float* Delta, const int* kmask, const void* qkv0, const float* rq, const float* rk,
                          const float* qn_w, const float* kn_w, const float* cosT, const float* sinT, const int* pos,

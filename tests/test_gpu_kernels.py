@@ -359,6 +359,9 @@ def test_attention_bwd_with_fused_qkv_post(L, masked):
     assert relerr(got, ref) < 1.5e-2 and cos_sim(got, ref) > 0.9999
     # the v section is a pure relayout of the same accumulators: identical
     assert torch.equal(got.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:], ref.view(B * L, Hq + 2 * Hkv, hd)[:, Hq + Hkv:])
+    # round 6: V = NULL -- the kernel reads the V rows in place from the q|k|v GEMM output (same values: bit-identical result)
+    got2 = ops.attention_bwd_qkv(Q, K, None, dO, lse, delta, x0, rq, rk, qn, kn, cos, sin, L, scale, kmask=kmask)
+    assert torch.equal(got2, got)
 
 
 # ----------------------------------------------------------------------------- element-wise / movement

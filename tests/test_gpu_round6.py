@@ -42,6 +42,19 @@ def test_layernorm_f32_stream_to_bf16(M, H):
     assert relerr(yk, ref * keep[:, None]) < 8e-3 and float(yk[::3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,H", [(7, 256), (301, 1024), (6144, 1024), (333, 2048)])
+def test_rmsnorm_f32_stream_to_bf16(M, H):
+    """rmsnorm_fwd_f32x8_kernel (f32 -> bf16 only) against torch and against the generic wave-per-row kernel."""
+    from tiny_audio_amd import ops
+    x, w = rnd(M, H, seed=1, scale=2.0), 1 + 0.1 * rnd(H, seed=2)
+    r = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
+    ref = w * (x * r)
+    yb, yf, rstd = ops.rmsnorm_fwd(x, w, 1e-6, out_bf16=True, out_f32=False)
+    assert yf is None and relerr(yb, ref) < 8e-3 and relerr(rstd, r.flatten()) < 1e-5
+    gb, gf, grstd = ops.rmsnorm_fwd(x, w, 1e-6, out_bf16=True, out_f32=True)     # generic kernel
+    assert float((yb != gb).float().mean()) < 2e-3 and relerr(rstd, grstd) < 1e-6
+
+
 @pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "12"])
 def test_gemm_f32_residual_in_place_every_variant(monkeypatch, variant):
     """x_f32 += A W^T + bias, in place (the fp32-stream residual GEMMs): the epilogues that batch the residual loads -- pairs of

@@ -225,6 +225,8 @@ LmDims lm_dims(const ta_lm_weights* w, int B, int L) {
   d.NQKV = (d.nq + 2 * d.nkv) * d.hd; d.Lp = pad64(L); d.M = (long)B * L;
   return d;
 }
+// short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging (ta_attention_fwd_qkv)
+inline bool lm_attn_fused(const LmDims& d, int L) { return d.hd == 128 && L <= 192 && (d.nq / d.nkv) * ((L + 31) / 32) <= 12; }
 LmTape lm_tape(const ta_lm_weights* w, int B, int L, int n_lab, void* base, LmLayerTape* store) {
   const LmDims d = lm_dims(w, B, L);
   Carver c(base);
@@ -434,9 +436,11 @@ static int lm_layers_forward(const ta_lm_weights* w, const LmDims& d, int B, int
     if (lgm & 1) RC(lora_fwd(xn, d.D, p.i_qkv, p.xa_qkv, 3));
     RC(gemm_opt(xn, Lw.wqkv, p.qkv0, M, d.NQKV, d.D, nullptr, nullptr, 0, 1, take_ext(), st));
     // short causal sequences: QK-norm + RoPE + head split ride in the attention kernel's staging; longer ones take two kernels
-    const bool fused_fwd = d.hd == 128 && L <= 192 && (d.nq / d.nkv) * ((L + 31) / 32) <= 12;
+    const bool fused_fwd = lm_attn_fused(d, L);
     if (fused_fwd)
-      RC(ta_attention_fwd_qkv(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.rq, p.rk, p.ao, p.lse, kmask,
+      // the head-major copy of V exists for the KV cache (prefill) and for the un-fused backward (trainable q_norm / k_norm); the fused
+      // backward reads V in place from qkv0, which the tape keeps anyway
+      RC(ta_attention_fwd_qkv(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, (kcache || w->train_base) ? p.v : nullptr, p.rq, p.rk, p.ao, p.lse, kmask,
                               B, d.nq, d.nkv, L, scale, w->eps, st));
     else
       RC(ta_lm_qkv_post_fwd(p.qkv0, Lw.qn_w, Lw.kn_w, w->rope_cos, w->rope_sin, pos, p.q, p.k, p.v, p.qt, p.kt, p.vt, p.rq,
@@ -697,7 +701,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
     // kernel -- 87.3 us against 67.2 + 9.5; profiles/r04_g/h_*, r04_zj_*.)
     RC(ta_attn_bwd_prep(s.dao, p.ao, s.delta, s.dot, B, d.nq, L, d.Lp, st));
     if (!(g && (g->dqn || g->dkn))) {
-      RC(ta_attention_bwd_qkv(p.q, p.k, p.v, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
+      RC(ta_attention_bwd_qkv(p.q, p.k, (w->train_base || !lm_attn_fused(d, L)) ? p.v : nullptr, s.dao, (long)d.nq * d.hd, p.lse, s.delta, kmask, p.qkv0, p.rq, p.rk, Lw.qn_w, Lw.kn_w,
                               w->rope_cos, w->rope_sin, pos, s.dqkv, B, d.nq, d.nkv, L, d.Lp, d.hd, 1, scale, st));
     } else {
       RC(ta_attention_bwd(p.q, p.qt, p.k, p.kt, p.v, s.dao, (long)d.nq * d.hd, s.dot, p.lse, s.delta, kmask, s.dq, s.dk, s.dv,

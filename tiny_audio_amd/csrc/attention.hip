@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_gqa_qkv_kernel(const bf16_t*
         *(uint4*)kp = kv;                             // in place: this thread is the only reader and writer of its chunk
         if (krow < L) {
           *(uint4*)(Ko + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = kv;
-          *(uint4*)(Vo + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = vin;
+          if (Vo) *(uint4*)(Vo + ((long)(b * Hkv + hk) * L + krow) * HD + c * 8) = vin;
           if (c == 0) rk[tok * Hkv + hk] = rr;
         }
       }
@@ -959,7 +959,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
   const int qr = qrow < L ? qrow : L - 1;
   const bf16_t* Qb = Q + ((long)(b * Hq + h) * L) * HD;
   const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
-  const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
+  // V == nullptr (round 6, the fused q|k|v form): V is read in place from the token-major q|k|v GEMM output (V is neither normalised
+  // nor rotated, so the forward need not write a head-major copy: 49 KB less for each of its store-bound workgroups)
+  const long ldq = (long)(Hq + 2 * Hkv) * HD;
+  const bf16_t* Vb = V ? V + ((long)(b * Hkv + hk) * L) * HD : F.qkv0 + (long)b * L * ldq + (long)(Hq + Hkv + hk) * HD;
+  const long v_rs = V ? HD : ldq;
   (void)KT; (void)Lp;
   const bf16_t* dOb = dO + (long)b * L * dO_stride + (long)h * HD;   // token-major rows
   const float sl2 = scale * LOG2E;
@@ -984,7 +988,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, int block_id, const
   auto issue = [&](int t) {
     const unsigned dst = lds0 + (t & 1) * BWD_BUF;
     dma_rowtile128(Kb, HD, t * KV_TILE, L, dst, wave, lane);
-    dma_rowtile128(Vb, HD, t * KV_TILE, L, dst + RowTile<HD>::BYTES, wave, lane);
+    dma_rowtile128(Vb, v_rs, t * KV_TILE, L, dst + RowTile<HD>::BYTES, wave, lane);
     if (tid < 64) { const int kk = t * KV_TILE + tid; pm = (kk < L) ? (kmask ? kmask[(long)b * L + kk] : 1) : 0; }
   };
   ATTN_STAMP(gridDim.x - 1 - blockIdx.x + 4096, 0, 0);   // (dq blocks are stamped from 4096 up, by their distance from the grid's end)
@@ -1080,13 +1084,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, int block_id, cons
   const int krow = kt_idx * 64 + wave * 16 + l15;
   const int kr = krow < L ? krow : L - 1;
   const bf16_t* Kb = K + ((long)(b * Hkv + hk) * L) * HD;
-  const bf16_t* Vb = V + ((long)(b * Hkv + hk) * L) * HD;
+  const long ldq = (long)(Hq + 2 * Hkv) * HD;              // V == nullptr: V rows in place in the q|k|v GEMM output (see the dQ body)
+  const bf16_t* Vb = V ? V + ((long)(b * Hkv + hk) * L) * HD : F.qkv0 + (long)b * L * ldq + (long)(Hq + Hkv + hk) * HD;
+  const long v_rs = V ? HD : ldq;
   const float sl2 = scale * LOG2E;
   bf16x8 kf[HD / 32], vf[HD / 32];
 #pragma unroll
   for (int ks = 0; ks < HD / 32; ++ks) {
     kf[ks] = *(const bf16x8*)(Kb + (long)kr * HD + ks * 32 + g * 8);
-    vf[ks] = *(const bf16x8*)(Vb + (long)kr * HD + ks * 32 + g * 8);
+    vf[ks] = *(const bf16x8*)(Vb + (long)kr * v_rs + ks * 32 + g * 8);
   }
   const bool kvalid = (krow < L) && (kmask ? kmask[(long)b * L + kr] != 0 : true);
   f32x4 dk[HD / 16], dv[HD / 16];
@@ -1312,7 +1318,7 @@ extern "C" int ta_attention_fwd_qkv(const void* qkv0, const float* qn_w, const f
                                     const int* pos, void* Q, void* K, void* V, float* rq, float* rk, void* O, float* LSE,
                                     const int* kmask, int B, int Hq, int Hkv, int L, float scale, float eps, hipStream_t st) {
   if (B <= 0 || L <= 0) return TA_OK;
-  if (!qkv0 || !Q || !K || !V || !rq || !rk || !O || Hkv <= 0 || Hq % Hkv) return TA_ERR_ARG;
+  if (!qkv0 || !Q || !K || !rq || !rk || !O || Hkv <= 0 || Hq % Hkv) return TA_ERR_ARG;     // V may be NULL: no head-major copy of V
   const int grp = Hq / Hkv;
   if (L > 192 || grp * ((L + 31) / 32) > 12) return TA_ERR_ARG;
   constexpr int MAXT = 3, QS = 2, NW = 6;

@@ -251,6 +251,43 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_bf16x8_kernel(const bf16_t* _
   }
 }
 
+// f32 -> bf16 RMSNorm (the LM's residual stream in the fp32-stream mode, round 6): the half-wave-per-row layout of
+// rmsnorm_fwd_bf16x8_kernel with two 16-byte loads per chunk and lane.  H = 256 * NCH.
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_f32x8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                bf16_t* __restrict__ y, float* __restrict__ rstd_out, int M,
+                                                                float eps) {
+  constexpr int H = NCH * 256;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const int l = threadIdx.x & 31;
+  const float4* xr = (const float4*)(x + (long)row * H);
+  float v[NCH][8];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const float4 a = xr[(l + i * 32) * 2], b = xr[(l + i * 32) * 2 + 1];
+    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += v[i][j] * v[i][j];
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)H + eps);
+  if (rstd_out && l == 0) rstd_out[row] = rstd;
+  uint4* yr = (uint4*)(y + (long)row * H);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (l + i * 32) * 8;
+    const float4 w0 = *(const float4*)(w + c), w1 = *(const float4*)(w + c + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * ww[j];
+    yr[l + i * 32] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
 // y = w * (x * rstd)   [ACT==1: y = gelu(y)];  x f32 [M,H]
 template <int MAXV, int ACT, bool IN_BF16 = false>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -455,6 +492,16 @@ extern "C" int ta_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, floa
   if (M <= 0) return TA_OK;
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
   dim3 grid(ta_cdiv(M, 4)), blk(256);
+  if (!act_gelu && y_bf16 && !y_f32 && (H % 256) == 0 && H <= 2048) {      // f32 -> bf16 only: the half-wave-per-row variant
+    dim3 g8(ta_cdiv(M, 8));
+    switch (H / 256) {
+#define RFF(N) case N: TA_LAUNCH((rmsnorm_fwd_f32x8_kernel<N>), g8, blk, 0, st, x, w, (bf16_t*)y_bf16, rstd, M, eps); break;
+      RFF(1) RFF(2) RFF(3) RFF(4) RFF(5) RFF(6) RFF(7) RFF(8)
+#undef RFF
+    }
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
 #define RF_CALL(V)                                                                                                 \
   if (act_gelu)                                                                                                    \
     TA_LAUNCH((rmsnorm_fwd_kernel<V, 1>), grid, blk, 0, st, x, w, (bf16_t*)y_bf16, y_f32, rstd, M, H, eps); \
