@@ -439,6 +439,10 @@ int ta_rmsnorm_bwd_bf16(const void* dy, int dy_is_bf16, const void* x_bf16, cons
  * f32 consumer follows: the embedding / audio-row gather at the bottom of the stack) */
 int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* x_bf16, const float* rstd, const float* w,
                          const void* dres_bf16, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st);
+/* the fp32-stream counterpart (round 6): x, dres, dx_f32 fp32, the incoming gradient bf16 (under the recipe's bf16 autocast the
+ * gradient of a Linear's bf16 input IS a bf16 tensor), a bf16 image of dx beside it (either output may be NULL) */
+int ta_rmsnorm_bwd_dyb(const void* dy_bf16, const float* x, const float* rstd, const float* w, const float* dres, float* dx_f32,
+                       void* dx_bf16, int M, int H, hipStream_t st);
 
 /* d loss / d weight of an RMSNorm (y = w * x * rstd): dw_accum[h] += sum_m dy[m,h] * x[m,h] * rstd[m]; dy and x are f32 or bf16 */
 int ta_rmsnorm_dw(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* rstd, float* dw_accum, int M,

@@ -55,6 +55,37 @@ def test_rmsnorm_f32_stream_to_bf16(M, H):
     assert float((yb != gb).float().mean()) < 2e-3 and relerr(rstd, grstd) < 1e-6
 
 
+@pytest.mark.parametrize("M,H", [(5, 256), (301, 1024), (6144, 1024), (77, 2048), (40, 1280)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_rmsnorm_bwd_half_wave_forms(M, H, with_res):
+    """Both forms the LM backward runs (the all-bf16 one on rmsnorm_bwd_bf16x8_kernel): bf16 everything with the d(x) stream updated IN PLACE
+    (ta_rmsnorm_bwd_bf16s) and fp32 stream + bf16 incoming gradient (ta_rmsnorm_bwd_dyb), against torch autograd on the same inputs."""
+    from tiny_audio_amd import _lib
+    from tiny_audio_amd.ops import ptr, stream
+    L_ = _lib.lib()
+    x32 = rnd(M, H, seed=1, scale=2.0)
+    w = 1 + 0.1 * rnd(H, seed=2)
+    dy = rnd(M, H, seed=3).to(BF16)
+    dres32 = rnd(M, H, seed=4)
+    for f32 in (True, False):
+        x = x32 if f32 else x32.to(BF16)
+        dres = (dres32 if f32 else dres32.to(BF16)) if with_res else None
+        xr = x.float().clone().requires_grad_(True)
+        r = torch.rsqrt((xr * xr).mean(-1, keepdim=True) + 1e-6)
+        (w * (xr * r)).backward(dy.float())
+        ref = xr.grad + (dres.float() if with_res else 0.0)
+        rstd = r.detach().flatten().contiguous()
+        dxf = torch.empty(M, H, device=DEV, dtype=F32)
+        if f32:
+            dxb = torch.empty(M, H, device=DEV, dtype=BF16)
+            _lib.check(L_.ta_rmsnorm_bwd_dyb(ptr(dy), ptr(x), ptr(rstd), ptr(w), ptr(dres), ptr(dxf), ptr(dxb), M, H, stream()))
+        else:
+            dxb = dres.clone() if with_res else torch.empty(M, H, device=DEV, dtype=BF16)      # in place: dres IS the output image
+            _lib.check(L_.ta_rmsnorm_bwd_bf16s(ptr(dy), 1, ptr(x), ptr(rstd), ptr(w), ptr(dxb) if with_res else None, ptr(dxf), ptr(dxb), M, H, stream()))
+        assert relerr(dxf, ref) < 2e-5, (f32, relerr(dxf, ref))
+        assert relerr(dxb, ref) < 8e-3
+
+
 @pytest.mark.parametrize("variant", [None, "0", "3", "4", "5", "10", "12"])
 def test_gemm_f32_residual_in_place_every_variant(monkeypatch, variant):
     """x_f32 += A W^T + bias, in place (the fp32-stream residual GEMMs): the epilogues that batch the residual loads -- pairs of

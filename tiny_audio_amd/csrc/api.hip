@@ -670,7 +670,7 @@ extern "C" int ta_lm_backward(const ta_lm_weights* w, const int* src_row, const 
                       bool last = false) -> int {
     if (dx_bf16) return ta_rmsnorm_bwd_bf16s(dy, dyb, x, r, gw, dres ? s.dxb : nullptr, last ? dxf : nullptr, s.dxb, M, d.D, st);
     if (lm_res_bf16(w)) return ta_rmsnorm_bwd_bf16(dy, dyb, x, r, gw, dres, dxf, s.dxb, M, d.D, st);
-    return dyb ? ta_i_rmsnorm_bwd_dyb(dy, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
+    return dyb ? ta_rmsnorm_bwd_dyb(dy, x, r, gw, dres, dxf, s.dxb, M, d.D, st)
                : ta_rmsnorm_bwd(dy, x, r, gw, dres, dxf, s.dxb, nullptr, M, d.D, 0, st);
   };
   RC(norm_bwd(s.dhn, 0, t.x_final, t.r_f, w->norm_w, nullptr, dx, w->n_layers == 0));

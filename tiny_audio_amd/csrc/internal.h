@@ -26,10 +26,6 @@ struct LoraReduceDesc { float* out[8]; long out_ls[8]; long size[8]; long part_o
 int ta_i_lora_reduce_parts(const LoraReduceDesc& d, int layers, hipStream_t st);
 int ta_i_lora_skinny_nt(const void* X, int K, const void* W, void* out, int M, int R, hipStream_t st);   // out[M,64] = X[M,K] W[64,K]^T; rows >= R of W are zero
 
-// RMSNorm backward over an fp32 residual stream with a bf16 incoming gradient (norm.hip; ta_lm_backward in the fp32-stream mode)
-int ta_i_rmsnorm_bwd_dyb(const void* dy_bf16, const float* x, const float* rstd, const float* w, const float* dres, float* dx_f32,
-                         void* dx_bf16, int M, int H, hipStream_t st);
-
 // fused decode-step kernels for batch <= 32 (csrc/decode_fused.hip); TA_ERR_ARG = outside the envelope, take the unfused path
 bool ta_i_dec_fused_serves(int B, int D, int F, int bq, int Hq, int Hkv, int Lmax);
 // what the NEXT kernel of the step streams, fetched one kernel early by `wgs` extra workgroups (0 = 96): a contiguous range

@@ -414,6 +414,62 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
 }
 
+// RMSNorm backward, half a wave per row with 16-byte accesses (round 6): the all-bf16 form the LM backward runs 56 times per step in the
+// bf16-stream mode -- x, the incoming gradient, dres and the d(x) image bf16 (dres may BE dxb: the stream updated in place), optional
+// f32 copy; no GELU, no weight gradient.  H = 256 * NCH.  11.3 -> 10.3 us per launch at M = 6144, H = 1024 (profiles/r06_g_*).  (The
+// fp32-stream counterpart -- five streams, 100 MB per launch -- measured SLOWER in this layout, 19.5 against 18.6 us, and stays on the
+// wave-per-row kernel.)
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                 const float* __restrict__ rstd_in, const float* __restrict__ w,
+                                                                 const bf16_t* dres, float* dxf, bf16_t* dxb, int M) {
+  constexpr int H = NCH * 256;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const int l = threadIdx.x & 31;
+  const float r = rstd_in[row];
+  float xh[NCH][8], dn[NCH][8];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = l + i * 32;                                   // 8-column chunk index inside the row
+    const uint4 u = ((const uint4*)(x + (long)row * H))[c8];
+    const uint4 du = ((const uint4*)(dy + (long)row * H))[c8];
+    const uint32_t t[4] = {u.x, u.y, u.z, u.w}, dt[4] = {du.x, du.y, du.z, du.w};
+    const float4 w0 = *(const float4*)(w + c8 * 8), w1 = *(const float4*)(w + c8 * 8 + 4);
+    const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = bf2f((bf16_t)((j & 1) ? (t[j >> 1] >> 16) : (t[j >> 1] & 0xffff)));
+      const float d = bf2f((bf16_t)((j & 1) ? (dt[j >> 1] >> 16) : (dt[j >> 1] & 0xffff)));
+      xh[i][j] = xv * r;
+      dn[i][j] = d * ww[j];
+      dot += dn[i][j] * xh[i][j];
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);          // lanes 0-31 / 32-63 reduce separately
+  const float mdot = dot / (float)H;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c8 = l + i * 32;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = r * (dn[i][j] - xh[i][j] * mdot);
+    if (dres) {
+      const uint4 e = ((const uint4*)(dres + (long)row * H))[c8];
+      const uint32_t et[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[2 * j] += bf2f((bf16_t)(et[j] & 0xffff)); o[2 * j + 1] += bf2f((bf16_t)(et[j] >> 16)); }
+    }
+    if (dxf) {
+      float4* fr = (float4*)(dxf + (long)row * H);
+      fr[c8 * 2] = make_float4(o[0], o[1], o[2], o[3]); fr[c8 * 2 + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+    if (dxb) ((uint4*)(dxb + (long)row * H))[c8] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+  }
+}
+
 // ----------------------------------------------------------------------------- C-ABI
 #define DISPATCH_MAXV(H, CALL)            \
   do {                                    \
@@ -555,6 +611,16 @@ extern "C" int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* 
                                     const void* dres_bf16, float* dx_f32, void* dx_bf16, int M, int H, hipStream_t st) {
   if (M <= 0) return TA_OK;
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
+  if (dy_is_bf16 && (H % 256) == 0 && H <= 2048) {
+    dim3 g8(ta_cdiv(M, 8)), blk8(256);
+    switch (H / 256) {
+#define RBX(N) case N: TA_LAUNCH((rmsnorm_bwd_bf16x8_kernel<N>), g8, blk8, 0, st, (const bf16_t*)dy, (const bf16_t*)x_bf16, rstd, w, (const bf16_t*)dres_bf16, dx_f32, (bf16_t*)dx_bf16, M); break;
+      RBX(1) RBX(2) RBX(3) RBX(4) RBX(5) RBX(6) RBX(7) RBX(8)
+#undef RBX
+    }
+    TA_CHECK_LAUNCH();
+    return TA_OK;
+  }
   const float* x = (const float*)x_bf16;
   const float* dyf = (const float*)dy;
   const float* dres = (const float*)dres_bf16;
@@ -568,9 +634,9 @@ extern "C" int ta_rmsnorm_bwd_bf16s(const void* dy, int dy_is_bf16, const void* 
   return TA_OK;
 }
 
-// fp32 residual stream, bf16 incoming gradient (internal: ta_lm_backward in the fp32-stream mode -- under the recipe's bf16 autocast
+// fp32 residual stream, bf16 incoming gradient (ta_lm_backward in the fp32-stream mode -- under the recipe's bf16 autocast
 // the gradient of a Linear's bf16 input IS a bf16 tensor, cast up afterwards, so nothing is lost by keeping its 2 bytes)
-int ta_i_rmsnorm_bwd_dyb(const void* dy_bf16, const float* x, const float* rstd, const float* w, const float* dres, float* dx_f32,
+extern "C" int ta_rmsnorm_bwd_dyb(const void* dy_bf16, const float* x, const float* rstd, const float* w, const float* dres, float* dx_f32,
                          void* dx_bf16, int M, int H, hipStream_t st) {
   if (M <= 0) return TA_OK;
   if ((H & 3) || H > 64 * 4 * MAXV_LIMIT) return TA_ERR_ARG;
