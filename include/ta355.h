@@ -25,7 +25,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define TA_ERR_LAUNCH 2
 
 int ta_version(void); /* ABI version, currently 4 (round 6: the residual-stream storage mode left process-wide state -- ta_set_stream_modes /
-                          ta_get_stream_modes are gone, ta_encoder_weights.res_f32 and ta_lm_weights.res_f32 / dx_f32 carry it per handle.
+                          ta_get_stream_modes are gone, ta_encoder_weights.res_f32 and ta_lm_weights.res_f32 / dx_f32 carry it per handle; ta_rmsnorm_bwd_dyb is new;
+                          ta_attention_fwd_qkv / ta_attention_bwd_qkv accept V = NULL.
                           Version 3 was round 5's: the opt-in paths that measured slower left the library -- ta_enc_layer lost its
                           wqk_il / *_ln image fields, ta_gemm_opts its swiglu_* / lnf_* fields, ta_layernorm_stats / ta_attention_bwd_gqa /
                           ta_attention_bwd_qkv_o went.  Version 2 was round 3's: ta_gemm_opts.rope_cols, ta_enc_layer.wqkv_fa / bqkv_fa,
